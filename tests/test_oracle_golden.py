@@ -1,0 +1,129 @@
+"""The oracle (oracle/meme_oracle.py) against the golden vectors generated from
+transformers' BertModel / ViTModel + nn.CrossEntropyLoss + torch.optim.Adam
+(oracle/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import meme_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _checksum(p):
+    return np.array([float(sum(v.double().sum() for v in p.values())),
+                     float(sum(v.double().abs().sum() for v in p.values()))])
+
+
+def _sample(t, n=6):
+    f = t.detach().reshape(-1)
+    return f[torch.linspace(0, f.numel() - 1, n).long()].numpy()
+
+
+@pytest.mark.parametrize("name,pool", [("tiny_cls", "cls"), ("tiny_last", "last")])
+def test_tiny_forward_backward_adam(golden_dir, name, pool):
+    z = _load(golden_dir, name)
+    cfg = O.tiny_config(pool)
+    p = O.init_params(cfg, int(z["seed"]))
+    np.testing.assert_allclose(_checksum(p), z["param_checksum"], rtol=1e-9,
+                               err_msg="init_params RNG stream drifted from the fixture")
+    text, image, mask, labels = (torch.from_numpy(z[k]) for k in ("text", "image", "mask", "labels"))
+    st = O.AdamState()
+    names = [str(n) for n in z["grad_names"]]
+    # d(loss)/d(key bias) is analytically 0 (softmax is shift-invariant over keys): its computed
+    # gradient is rounding noise and Adam's g/sqrt(v) turns noise into +-lr steps, so the
+    # key-bias *updates* are not comparable between two correct implementations.
+    stable = np.array([".key.bias" not in n for n in names])
+    steps = int(z["steps"])
+    for s in range(steps):
+        p_new, logits, loss, grads = O.train_step(p, st, text, image, mask, labels, cfg, lr=2e-5)
+        if s == 0:
+            np.testing.assert_allclose(logits.numpy(), z["logits"], atol=2e-6, rtol=1e-5)
+            np.testing.assert_allclose(float(loss), float(z["loss"]), rtol=1e-6)
+            norms = np.array([float(grads[n].double().norm()) for n in names])
+            np.testing.assert_allclose(norms, z["grad_norms"], rtol=2e-4, atol=1e-9)
+            samples = np.stack([_sample(grads[n]) for n in names])
+            np.testing.assert_allclose(samples, z["grad_samples"], rtol=2e-3, atol=2e-7)
+        if s in (0, steps - 1):
+            delta = np.array([float((p_new[n] - O.init_params(cfg, int(z["seed"]))[n]).double().norm())
+                              for n in names]) if s == 0 else None
+            if delta is not None:
+                np.testing.assert_allclose(delta[stable], z["param_delta_norm_step1"][stable], rtol=1e-3, atol=1e-9)
+            samples = np.stack([_sample(p_new[n]) for n in names])
+            np.testing.assert_allclose(samples[stable], z[f"param_samples_step{s + 1}"][stable], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(samples, z[f"param_samples_step{s + 1}"], atol=2.1e-5 * (s + 1))
+        p = p_new
+    logits_after = O.forward(p, text, image, mask, cfg)
+    np.testing.assert_allclose(logits_after.numpy(), z["logits_after"], atol=5e-6, rtol=1e-4)
+
+
+@pytest.mark.slow
+def test_config3_logits(golden_dir):
+    """(iv) full ViT-B/16 + BERT-base(V=64000), B=2: logits and tower samples."""
+    z = _load(golden_dir, "config3_b2")
+    cfg = O.config3("cls")
+    p = O.init_params(cfg, int(z["seed"]))
+    np.testing.assert_allclose(_checksum(p), z["param_checksum"], rtol=1e-9)
+    text, image, mask = (torch.from_numpy(z[k]) for k in ("text", "image", "mask"))
+    with torch.no_grad():
+        th = O.text_tower(p, text, mask, cfg.text)
+        ih = O.image_tower(p, image, cfg.image)
+        logits = O.forward(p, text, image, mask, cfg)
+    np.testing.assert_allclose(th[:, :, :4].numpy(), z["text_hidden_sample"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(ih[:, 0].numpy(), z["image_cls"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(logits.numpy(), z["logits"], atol=1e-5, rtol=1e-4)
+
+
+def test_index_fixtures(golden_dir):
+    """(iii) bit-exact indexing: patch order of a counting image, token-row gather."""
+    z = _load(golden_dir, "index_fixtures")
+    img = torch.from_numpy(z["counting_image"])
+    assert np.array_equal(O.patchify(img, 16).numpy(), z["patches"])
+    tab = torch.from_numpy(z["table"])
+    assert np.array_equal(tab[torch.from_numpy(z["ids"])].numpy(), z["gathered"])
+
+
+def test_param_count_config3():
+    # 221.7 M parameters (BERT-base V=64000 no pooler + ViT-B/16 + heads)
+    n = O.n_params(O.config3())
+    assert abs(n - 221.7e6) < 0.1e6, n
+
+
+def test_known_answer_distilbert_param_count():
+    """Upstream known answer (example_scripts/DistilBERT_example_task2A.ipynb:4301):
+    DistilBERT-mcased seq-cls has 135 326 210 trainable parameters.  Encoder part
+    restated with the oracle's shape table (type_vocab=0, 6 layers, V=119547) +
+    pre_classifier(768,768) + classifier(768,2)."""
+    c = O.TextConfig(vocab_size=119547, layers=6, type_vocab=0)
+    n = sum(int(np.prod(s)) for s in O._text_shapes(c).values())
+    n += 768 * 768 + 768 + 768 * 2 + 2
+    assert n == 135_326_210
+
+
+def test_adam_matches_torch_optim():
+    torch.manual_seed(0)
+    w = torch.randn(37, 5)
+    ref = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    st = O.AdamState()
+    p = {"w": w.clone()}
+    for i in range(4):
+        g = torch.randn(37, 5) * (0 if i == 2 else 1)   # a zero-grad step keeps momentum moving
+        ref.grad = g.clone()
+        opt.step()
+        p = O.adam_step(p, {"w": g}, st, lr=1e-2)
+        np.testing.assert_allclose(p["w"].numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_clip_matches_torch():
+    torch.manual_seed(1)
+    w = torch.nn.Parameter(torch.randn(10, 3))
+    g = torch.randn(10, 3) * 5
+    w.grad = g.clone()
+    torch.nn.utils.clip_grad_norm_([w], 1.0)
+    n = O.global_grad_norm({"w": g})
+    np.testing.assert_allclose((g * min(1.0, float(1.0 / (n + 1e-6)))).numpy(), w.grad.numpy(), rtol=1e-6)
