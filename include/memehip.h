@@ -1,0 +1,209 @@
+/* memehip -- C ABI of the MI355X (gfx950) kernels behind the Subtask-2C fine-tune step.
+ *
+ * The reference (KevinMathewT/multimodal-propaganda-meme-classification) is 100 % Python and has
+ * no FFI: its hot path reaches the arithmetic through PyTorch / transformers / timm calls.  Each
+ * entry point below names the reference call site whose implied kernel it replaces
+ * (paths relative to /root/reference/example_scripts).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; no ownership transfer, no
+ *     allocation, no synchronisation inside; work is enqueued on `stream` (a hipStream_t).
+ *   - bf16 = raw uint16 bfloat16 storage; f32 = float; ids/masks/labels = int64 (torch.long),
+ *     exactly the tensors the reference Dataset yields (Multimodal_example_task2C.txt:61-71).
+ *   - return value: MH_OK (0) or an MhStatus code; nothing throws across the ABI.
+ */
+#ifndef MEMEHIP_H
+#define MEMEHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum MhStatus {
+    MH_OK = 0,
+    MH_EINVAL = 1,  /* null pointer / bad flag */
+    MH_ESHAPE = 2,  /* shape not supported by the gfx950 tiling (see each function) */
+    MH_ELAUNCH = 3  /* hipLaunch / runtime error (hipGetLastError) */
+} MhStatus;
+
+typedef void* mh_stream_t; /* hipStream_t */
+
+const char* mh_version(void);
+const char* mh_status_str(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped bf16 GEMM with fused epilogue:  C = epi(A . B^T)   (fp32 accumulate on MFMA)
+ * replaces every nn.Linear inside both encoders, forward / dgrad / wgrad
+ * (BertModel / timm ViT via Multimodal_example_task2C.txt:175,183 ; loss.backward() :216).
+ *
+ *   a_kmajor == 0 : A is [M][K] row-major (lda elements per row)     -- K contiguous
+ *   a_kmajor == 1 : A is [K][M] row-major (lda elements per K row)   -- K strided
+ *   b_kmajor == 0 : B is [N][K] (nn.Linear weight layout)            -- K contiguous
+ *   b_kmajor == 1 : B is [K][N]                                      -- K strided
+ *   forward  y = x W^T      : (0,0)  A=x[T][K]      B=W[N][K]
+ *   dgrad    dx = dy W      : (0,1)  A=dy[T][N']    B=W[N'][K']   (contracts over N')
+ *   wgrad    dW = dy^T x    : (1,1)  A=dy[T][N']    B=x[T][K']    (contracts over T)
+ *
+ * Epilogue order:  v = acc (+ bias[n]);  if aux: aux[m,n] = bf16(v);  if GELU: v = gelu_erf(v);
+ *                  if mul_dgelu: v *= gelu'(mul[m,n]);  if residual: v += residual[m,n];
+ *                  C[m,n] = v  (bf16, or f32 when MH_GEMM_OUT_F32; += when MH_GEMM_ACCUM with f32).
+ * rowsum (wgrad only, a_kmajor==1): rowsum[m] = sum_k A(m,k)  -- the bias gradient.
+ * Constraints: N % 128 == 0; K % 64 == 0 unless the contraction dim is the leading (row) index
+ * of both operands (a_kmajor && b_kmajor), in which case any K; M any when a_kmajor==0, else
+ * M % 128 == 0; ld* % 8 == 0; all bases 16-byte aligned; up to MH_GEMM_MAX_GROUP problems.
+ * ------------------------------------------------------------------------------------------ */
+#define MH_GEMM_MAX_GROUP 8
+#define MH_GEMM_GELU 1
+#define MH_GEMM_OUT_F32 2
+#define MH_GEMM_ACCUM 4
+
+typedef struct MhGemmProblem {
+    const void* A;        /* bf16 */
+    const void* B;        /* bf16 */
+    void* C;              /* bf16 [M][ldc] or f32 [M][ldc] */
+    const float* bias;    /* f32 [N] or NULL */
+    const void* residual; /* bf16 [M][ldc] or NULL */
+    void* aux;            /* bf16 [M][ldc] pre-activation copy or NULL */
+    const void* mul;      /* bf16 [M][ldc] pre-activation whose gelu' scales the result, or NULL */
+    float* rowsum;        /* f32 [M] or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    int32_t flags;
+    int32_t reserved;
+} MhGemmProblem;
+
+int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems, int a_kmajor,
+                         int b_kmajor, mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (D % 8 == 0, D <= 4096), one wavefront per row.
+ * replaces nn.LayerNorm inside BertModel (eps 1e-12, post-LN) and timm ViT (eps 1e-6, pre-LN).
+ *   fwd:  y = (x - mean) * rstd * gamma + beta ; saves mean[rows], rstd[rows] (f32)
+ *   bwd:  dx (bf16; added to dx_add when non-NULL), partial dgamma/dbeta in
+ *         part[2][n_part][D] (f32, one row per workgroup; the launch uses n_part workgroups) --
+ *         finish with mh_colsum_partials_f32.
+ * ------------------------------------------------------------------------------------------ */
+int mh_layernorm_fwd(const void* x /*bf16*/, const float* gamma, const float* beta, void* y /*bf16*/,
+                     float* mean, float* rstd, int rows, int D, float eps, mh_stream_t stream);
+int mh_layernorm_bwd(const void* dy /*bf16*/, const void* x /*bf16*/, const float* gamma,
+                     const float* mean, const float* rstd, const void* dx_add /*bf16 or NULL*/,
+                     void* dx /*bf16*/, float* part /*[2][n_part][D]*/, int n_part, int rows, int D,
+                     mh_stream_t stream);
+/* batched finish of the partial column sums: for every job, out0[d] = sum_i part[0][i][d] and
+ * out1[d] = sum_i part[1][i][d] (fixed order => bitwise reproducible); NULL outputs are skipped. */
+#define MH_COLSUM_MAX_JOBS 64
+typedef struct MhColsumJob {
+    const float* part; /* [2][n_part][D] */
+    float* out0;       /* [D] dgamma */
+    float* out1;       /* [D] dbeta  */
+} MhColsumJob;
+int mh_colsum_partials_f32(const MhColsumJob* jobs /*host*/, int n_jobs, int n_part, int D,
+                           mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-head attention (head dim 64), flash-style, bf16 in / f32 softmax.
+ * replaces BertSelfAttention / timm Attention (scores = q k^T / 8 + (1-mask)*min; softmax; P v).
+ *   qkv : bf16 [B][S][3][H][64]  (the fused QKV projection output; row pitch 3*H*64)
+ *   key_mask : int64 [B][S] (1 = attend) or NULL (ViT)
+ *   out : bf16 [B][S][H][64] ; lse : f32 [B][H][S]  (log-sum-exp of the scaled scores)
+ *   bwd : dqkv bf16 [B][S][3][H][64] from dout, recomputing P from lse; delta = rowsum(dout*out)
+ *         is computed inside (workspace delta f32 [B][H][S]).
+ * ------------------------------------------------------------------------------------------ */
+int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int B, int S, int H,
+                mh_stream_t stream);
+int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
+                const float* lse, float* delta, void* dqkv, int B, int S, int H, mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BERT embeddings: x = LN(word[ids] + pos[s] + type[0]) (BertEmbeddings; ids are the Dataset's
+ * int64 `text`, Multimodal_example_task2C.txt:63).  type may be NULL (DistilBERT).
+ * fwd saves the pre-LN sum (bf16) + mean/rstd for the backward.
+ * bwd: d_pre = LN-backward; dword[id] += d_pre rows (deterministic, first-occurrence owner sums
+ *      duplicates in position order; rows with id == pad_id get no gradient, as nn.Embedding
+ *      padding_idx does); dpos[s] = sum_b ; dtype0 = sum_{b,s}.
+ *      dword must be zero on entry except rows this call writes (it overwrites touched rows).
+ * ------------------------------------------------------------------------------------------ */
+int mh_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                      const float* gamma, const float* beta, void* pre /*bf16 [T][D]*/,
+                      void* y /*bf16 [T][D]*/, float* mean, float* rstd, int B, int S, int D, int vocab,
+                      float eps, mh_stream_t stream);
+int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre /*bf16 [T][D]*/, float* dword /*[V][D]*/,
+                      float* dpos /*[P][D]*/, float* dtype0 /*[D] or NULL*/, int B, int S, int D,
+                      int vocab, int64_t pad_id, mh_stream_t stream);
+/* zero the rows of dword named by ids (cheap re-zero of the dense table after the optimizer step) */
+int mh_zero_rows_f32(const int64_t* ids, float* table, int n_ids, int D, int vocab, mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ViT patch embedding (timm PatchEmbed conv 16x16/s16 == im2col + GEMM):
+ *   mh_patchify: image f32 [B][C][H][W] -> patches bf16 [B*gh*gw][C*p*p], feature order (c,i,j),
+ *                patch order row-major over (h,w)  (bit-exact cast-free gather, then RNE to bf16)
+ *   mh_vit_assemble_fwd: x[b][0] = cls + pos[0]; x[b][1+p] = proj[b][p] + pos[1+p]   (bf16 out)
+ *   mh_vit_assemble_bwd: dproj[b][p] = dx[b][1+p] (bf16); dpos[t] = sum_b dx[b][t]; dcls = sum_b dx[b][0]
+ * ------------------------------------------------------------------------------------------ */
+int mh_patchify(const float* image, void* patches, int B, int C, int H, int W, int P, mh_stream_t stream);
+int mh_vit_assemble_fwd(const void* proj /*bf16 [B*Np][D]*/, const float* cls, const float* pos,
+                        void* x /*bf16 [B][Np+1][D]*/, int B, int Np, int D, mh_stream_t stream);
+int mh_vit_assemble_bwd(const void* dx /*bf16 [B][Np+1][D]*/, void* dproj /*bf16 [B*Np][D]*/,
+                        float* dcls, float* dpos, int B, int Np, int D, mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Late-fusion head + cross-entropy, fp32 (Multimodal_example_task2C.txt:178-195, :248, :214):
+ *   t = W_t h_t[:, pool] + b ; v = W_i h_i[:, 0] + b ; f = W_f [t;v] + b ; z = W_o f + b
+ *   loss = mean_b( logsumexp(z_b) - z_b[y_b] )
+ * mh_head_fwd writes logits [B][C], per-row loss terms, and keeps t|v (feat [B][2P]) and f ([B][P]).
+ * mh_head_bwd consumes dlogits [B][C] (f32) and produces all head grads (f32, overwritten) and
+ *   d_text_hidden / d_image_hidden rows (bf16, written into the [T][D] gradient buffers at the
+ *   pooled token rows; the other rows must be zero-filled by the caller).
+ * mh_ce_fwd_bwd: loss (scalar f32), dlogits = (softmax - onehot)/B, n_correct (argmax == label).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct MhHeadParams {
+    const float *Wt, *bt;   /* bert_fc   [P][Dt], [P] */
+    const float *Wi, *bi;   /* image_fc  [P][Di], [P] */
+    const float *Wf, *bf_;  /* fusion_fc [P][2P], [P] */
+    const float *Wo, *bo;   /* output_fc [C][P],  [C] */
+} MhHeadParams;
+typedef struct MhHeadGrads {
+    float *Wt, *bt, *Wi, *bi, *Wf, *bf_, *Wo, *bo;
+} MhHeadGrads;
+
+int mh_head_fwd(const MhHeadParams* p /*host*/, const void* text_hidden /*bf16 [B][S][Dt]*/,
+                const void* image_hidden /*bf16 [B][Nt][Di]*/, int text_pool_index, float* pooled
+                /*[B][Dt+Di] f32*/, float* feat /*[B][2P]*/, float* fused /*[B][P]*/,
+                float* logits /*[B][C]*/, int B, int S, int Nt, int Dt, int Di, int P, int C,
+                mh_stream_t stream);
+int mh_head_bwd(const MhHeadParams* p /*host*/, const MhHeadGrads* g /*host*/, const float* dlogits,
+                const float* pooled, const float* feat, const float* fused, float* dfeat /*[B][2P]*/,
+                float* dfused /*[B][P]*/, void* d_text_hidden /*bf16 [B][S][Dt]*/,
+                void* d_image_hidden /*bf16 [B][Nt][Di]*/, int text_pool_index, int B, int S, int Nt,
+                int Dt, int Di, int P, int C, mh_stream_t stream);
+int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                  int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer (torch.optim.Adam / AdamW, Multimodal_example_task2C.txt:249,217; HF Trainer
+ * adamw_torch + max_grad_norm, DistilBERT_example_task2A.ipynb:3211-3213,3280):
+ *   mh_sumsq_f32: out[0] = sum g^2 over n elements (two-pass deterministic; workspace >= 1024 f32)
+ *   mh_adam_step: dense single-launch update over the flat parameter buffer.  Every per-step
+ *     scalar is read from DEVICE memory so a captured hipGraph of the step can be replayed:
+ *     hyper = f32[8] {lr, beta1, beta2, eps, weight_decay, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale}
+ *     g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq)*|grad_scale| + 1e-6)) (clip only
+ *          when gnorm_sq != NULL)
+ *     m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ *     (L2 wd folds into g', decoupled wd scales p first); also refreshes the bf16 shadow copy
+ *     p_bf16[i] for i < n_shadow (the GEMM operands).  n, n_shadow multiples of 4.
+ *   mh_cast_f32_bf16: shadow refresh on its own (after load_state_dict).
+ * ------------------------------------------------------------------------------------------ */
+int mh_sumsq_f32(const float* g, int64_t n, float* workspace /*>=1024 f32*/, float* out,
+                 mh_stream_t stream);
+int mh_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t n,
+                 int64_t n_shadow, const float* hyper /*device f32[8]*/, int decoupled,
+                 const float* gnorm_sq /*device or NULL*/, float max_norm, mh_stream_t stream);
+int mh_cast_f32_bf16(const float* src, void* dst, int64_t n, mh_stream_t stream);
+int mh_cast_bf16_f32(const void* src, float* dst, int64_t n, mh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMEHIP_H */

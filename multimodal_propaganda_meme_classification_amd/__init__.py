@@ -1,0 +1,6 @@
+"""MI355X-native dual-encoder fine-tuning path for Subtask-2C meme classification.
+
+Host side is Python (the reference is Python); all arithmetic runs in hand-written HIP kernels
+for gfx950 behind the C ABI in include/memehip.h (libmemehip.so).  No CPU fallback.
+"""
+from . import _lib  # noqa: F401

@@ -1,0 +1,101 @@
+"""ctypes binding of libmemehip.so (the C ABI declared in include/memehip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C multimodal_propaganda_meme_classification_amd/csrc``.  There is no
+fallback: if it is missing, importing the compute path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmemehip.so")
+
+MH_GEMM_MAX_GROUP = 8
+MH_GEMM_GELU = 1
+MH_GEMM_OUT_F32 = 2
+MH_GEMM_ACCUM = 4
+MH_COLSUM_MAX_JOBS = 64
+
+c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class MhGemmProblem(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p),
+                ("residual", c_void_p), ("aux", c_void_p), ("mul", c_void_p), ("rowsum", c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MhColsumJob(C.Structure):
+    _fields_ = [("part", c_void_p), ("out0", c_void_p), ("out1", c_void_p)]
+
+
+class MhHeadParams(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("Wt", "bt", "Wi", "bi", "Wf", "bf_", "Wo", "bo")]
+
+
+class MhHeadGrads(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("Wt", "bt", "Wi", "bi", "Wf", "bf_", "Wo", "bo")]
+
+
+# name -> argtypes; every function returns int (MhStatus) unless listed in _RESTYPES
+_PROTOS = {
+    "mh_gemm_bf16_grouped": [C.POINTER(MhGemmProblem), c_int, c_int, c_int, c_void_p],
+    "mh_layernorm_fwd": [c_void_p] * 6 + [c_int, c_int, c_float, c_void_p],
+    "mh_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p],
+    "mh_colsum_partials_f32": [C.POINTER(MhColsumJob), c_int, c_int, c_int, c_void_p],
+    "mh_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p],
+    "mh_attn_bwd": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p],
+    "mh_bert_embed_fwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "mh_bert_embed_bwd": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int64, c_void_p],
+    "mh_zero_rows_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mh_patchify": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
+    "mh_vit_assemble_fwd": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
+    "mh_vit_assemble_bwd": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
+    "mh_head_fwd": [C.POINTER(MhHeadParams), c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p],
+    "mh_head_bwd": [C.POINTER(MhHeadParams), C.POINTER(MhHeadGrads)] + [c_void_p] * 8 + [c_int] * 8 + [c_void_p],
+    "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
+    "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    "mh_adam_step": [c_void_p] * 5 + [c_int64, c_int64, c_void_p, c_int, c_void_p, c_float, c_void_p],
+    "mh_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
+    "mh_cast_bf16_f32": [c_void_p, c_void_p, c_int64, c_void_p],
+    "mh_version": [],
+    "mh_status_str": [c_int],
+}
+_RESTYPES = {"mh_version": C.c_char_p, "mh_status_str": C.c_char_p}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+_lib = None
+
+
+class MemehipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libmemehip.so (once).  Raises MemehipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MemehipError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C "
+            "multimodal_propaganda_meme_classification_amd/csrc). There is no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().mh_status_str(status).decode()
+        raise MemehipError(f"{what} failed: status {status} ({msg})")

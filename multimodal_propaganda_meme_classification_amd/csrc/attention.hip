@@ -1,0 +1,470 @@
+// Fused multi-head attention for head dim 64 on gfx950: forward, and backward as two kernels
+// (dQ sweep over key tiles; dK/dV sweep over query tiles).  See include/memehip.h.
+//
+// All products are v_mfma_f32_32x32x16_bf16 with the softmax'd tile produced in the accumulator
+// layout that the NEXT product consumes directly as an operand (no LDS round trip for P / dS):
+//   forward   S^T = K Q^T  (key on the row/register index, query on the lane)
+//             O^T = V^T P^T  with P^T's accumulator registers re-used as the B operand;
+//             per-query softmax statistics are per-lane scalars.
+//   dQ        S^T, dP^T = V dO^T as above, dS^T = P^T o (dP^T - delta);  dQ^T = K^T dS^T.
+//   dK/dV     S = Q K^T, dP = dO V^T (query on the register index, key on the lane);
+//             dV^T = dO^T P, dK^T = Q^T dS.
+// A 32x32 accumulator used as an operand carries rows in the permuted order
+//   row(s, h, j) = 16 s + 8 (j >> 2) + 4 h + (j & 3)   (k-step s, lane half h, element j)
+// so the other operand is fetched from LDS with ds_read_b64_tr_b16 at exactly those rows.
+// Tiles of 64 rows x 64 d (128-B rows) are staged global -> VGPR -> LDS in up to two images:
+//   row image: 16-B chunk c of row r at chunk c ^ (r & 7)            (ds_read_b128 fragments)
+//   tr  image: 32-B unit u of row r at unit u ^ (((r >> 1) & 1) << 1) (ds_read_b64_tr_b16)
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;       // head dim
+constexpr int TILE = 64;     // rows per staged tile
+constexpr int IMG = TILE * HD * 2;  // 8 KiB per image
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+MH_DEV int row_img_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+MH_DEV int tr_img_off(int row, int unit) { return row * 128 + ((unit ^ (((row >> 1) & 1) << 1)) << 5); }
+
+// stage one [64][64] bf16 tile (rows row0.., clipped at nrows -> zeros) into a row image and/or tr image
+template <int NT>
+MH_DEV void stage_tile(const bf16* __restrict__ base, size_t pitch, int row0, int nrows, int tid,
+                       char* row_img, char* tr_img) {
+#pragma unroll
+    for (int q = tid; q < TILE * 8; q += NT) {
+        const int r = q >> 3, c = q & 7;
+        i32x4 v = {0, 0, 0, 0};
+        if (row0 + r < nrows) v = *(const i32x4*)(base + (size_t)(row0 + r) * pitch + c * 8);
+        if (row_img) *(i32x4*)(row_img + row_img_off(r, c)) = v;
+        if (tr_img) *(i32x4*)(tr_img + tr_img_off(r, c >> 1) + ((c & 1) << 4)) = v;
+    }
+}
+
+// A/B fragment from a row image: rows rb..rb+31 (lane&31), d = 16 s + 8 h + j
+MH_DEV bf16x8 frag_rows(const char* img, int rb, int s, int lane) {
+    Pack8 u;
+    u.v = *(const i32x4*)(img + row_img_off(rb + (lane & 31), 2 * s + (lane >> 5)));
+    return u.h;
+}
+// A fragment of the TRANSPOSED tile: result row = d (dbase + lane&31), k = tile rows in the
+// accumulator-operand order row(s,h,j) within the 32-row block starting at rb.
+MH_DEV bf16x8 frag_tr(const char* img, int rb, int s, int dbase, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3;
+    const int chalf = (lane >> 4) & 1, h = lane >> 5;
+    const int unit = (dbase >> 4) + chalf;
+    const int r0 = rb + 16 * s + 4 * h + q;
+    const int r1 = r0 + 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, img + tr_img_off(r0, unit) + 8 * p));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, img + tr_img_off(r1, unit) + 8 * p));
+    union {
+        struct { s16x4 lo, hi; } s;
+        bf16x8 h8;
+    } cv;
+    cv.s.lo = lo;
+    cv.s.hi = hi;
+    return cv.h8;
+}
+// registers 8s..8s+7 of a 32x32 accumulator as a bf16 operand fragment
+MH_DEV bf16x8 acc_frag(const f32x16& x, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (bf16)x[8 * s + j];
+    return f;
+}
+// row index inside a 32x32 accumulator of register g for lane half h
+MH_DEV int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+// 32 rows x 64 d fragment straight from global: row (lane&31), d = 16 s + 8 h + j ; zero when row >= nrows
+MH_DEV void load_rows_frag(const bf16* __restrict__ base, size_t pitch, int row0, int nrows, int lane,
+                           bf16x8 (&f)[4]) {
+    const int r = row0 + (lane & 31);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        Pack8 u;
+        u.v = i32x4{0, 0, 0, 0};
+        if (r < nrows) u.v = *(const i32x4*)(base + (size_t)r * pitch + 16 * s + 8 * (lane >> 5));
+        f[s] = u.h;
+    }
+}
+
+// store a transposed result X^T (two 32x32 accumulators = 64 d x 32 rows; lane = row, regs = d)
+MH_DEV void store_rows_from_T(bf16* __restrict__ base, size_t pitch, int row0, int nrows, int lane,
+                              const f32x16 (&acc)[2], float scale) {
+    const int r = row0 + (lane & 31), h = lane >> 5;
+    if (r >= nrows) return;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            Pack4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u.e[e] = (bf16)(acc[dt][4 * g4 + e] * scale);
+            *(i32x2*)(base + (size_t)r * pitch + dt * 32 + 8 * g4 + 4 * h) = u.v;
+        }
+}
+
+// ----------------------------------------------------------------------------------------------
+// forward
+// ----------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16* __restrict__ qkv,
+                                                           const int64_t* __restrict__ key_mask,
+                                                           bf16* __restrict__ out, float* __restrict__ lse,
+                                                           int B, int S, int H) {
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG + TILE * 4];
+    char* k_img = smem;
+    char* v_img = smem + IMG;
+    float* kbias = (float*)(smem + 2 * IMG);
+
+    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+    const int q0 = blockIdx.x * (NW * 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const size_t pitch = (size_t)3 * H * HD;
+    const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    const bf16* kb = qb + (size_t)H * HD;
+    const bf16* vb = qb + (size_t)2 * H * HD;
+    const int wq0 = q0 + wave * 32;
+    const bool active = wq0 < S;
+
+    bf16x8 qf[4];
+    load_rows_frag(qb, pitch, wq0, S, lane, qf);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) o[i][g] = 0.f;
+    float m = NEG_BIG, l = 0.f;
+    const float c = 0.125f * LOG2E;  // 1/sqrt(64) folded with log2(e)
+
+    for (int k0 = 0; k0 < S; k0 += TILE) {
+        __syncthreads();
+        stage_tile<NT>(kb, pitch, k0, S, tid, k_img, nullptr);
+        stage_tile<NT>(vb, pitch, k0, S, tid, nullptr, v_img);
+        if (tid < TILE) {
+            const int key = k0 + tid;
+            float bias = NEG_BIG;
+            if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) bias = 0.f;
+            kbias[tid] = bias;
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        f32x16 st[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) st[sub][g] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(k_img, sub * 32, s, lane), qf[s],
+                                                                  st[sub], 0, 0, 0);
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 kb4 = *(const f32x4*)(kbias + sub * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = st[sub][4 * g4 + e] * c + kb4[e];
+                    st[sub][4 * g4 + e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float p = __builtin_amdgcn_exp2f(st[sub][g] - mn);
+                st[sub][g] = p;
+                ps += p;
+            }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) o[i][g] *= alpha;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = acc_frag(st[sub], s);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(v_img, sub * 32, s, dt * 32, lane), pf,
+                                                                    o[dt], 0, 0, 0);
+            }
+    }
+    if (!active) return;
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    store_rows_from_T(out + (size_t)b * S * H * HD + hh * HD, (size_t)H * HD, wq0, S, lane, o, inv);
+    const int q = wq0 + (lane & 31);
+    if (h == 0 && q < S) lse[((size_t)b * H + hh) * S + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
+}
+
+// delta[b][h][s] = sum_d dout * out
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ out,
+                                                         const bf16* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int S, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // (b, s, h)
+    if (idx >= B * S * H) return;
+    const int hh = idx % H, bs = idx / H, s = bs % S, b = bs / S;
+    const bf16* o = out + (size_t)idx * HD;
+    const bf16* d = dout + (size_t)idx * HD;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        Pack8 x, y;
+        x.v = *(const i32x4*)(o + c * 8);
+        y.v = *(const i32x4*)(d + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += mh_bf2f(x.e[e]) * mh_bf2f(y.e[e]);
+    }
+    delta[((size_t)b * H + hh) * S + s] = acc;
+}
+
+// ----------------------------------------------------------------------------------------------
+// backward, dQ:  one wave = 32 queries, sweep key tiles
+// ----------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv,
+                                                              const int64_t* __restrict__ key_mask,
+                                                              const bf16* __restrict__ dout,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ delta,
+                                                              bf16* __restrict__ dqkv, int B, int S, int H) {
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) char smem[3 * IMG + TILE * 4];
+    char* k_img = smem;
+    char* kt_img = smem + IMG;
+    char* v_img = smem + 2 * IMG;
+    float* kbias = (float*)(smem + 3 * IMG);
+
+    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+    const int q0 = blockIdx.x * (NW * 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const size_t pitch = (size_t)3 * H * HD;
+    const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    const bf16* kb = qb + (size_t)H * HD;
+    const bf16* vb = qb + (size_t)2 * H * HD;
+    const bf16* dob = dout + (size_t)b * S * H * HD + hh * HD;
+    const int wq0 = q0 + wave * 32;
+    const bool active = wq0 < S;
+    const int q = wq0 + (lane & 31);
+
+    bf16x8 qf[4], dof[4];
+    load_rows_frag(qb, pitch, wq0, S, lane, qf);
+    load_rows_frag(dob, (size_t)H * HD, wq0, S, lane, dof);
+    const float c = 0.125f * LOG2E;
+    float lse2 = 0.f, dl = 0.f;
+    if (q < S) {
+        lse2 = lse[((size_t)b * H + hh) * S + q] * LOG2E;
+        dl = delta[((size_t)b * H + hh) * S + q];
+    }
+    f32x16 dq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dq[i][g] = 0.f;
+
+    for (int k0 = 0; k0 < S; k0 += TILE) {
+        __syncthreads();
+        stage_tile<NT>(kb, pitch, k0, S, tid, k_img, kt_img);
+        stage_tile<NT>(vb, pitch, k0, S, tid, v_img, nullptr);
+        if (tid < TILE) {
+            const int key = k0 + tid;
+            float bias = NEG_BIG;
+            if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) bias = 0.f;
+            kbias[tid] = bias;
+        }
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(k_img, sub * 32, s, lane), qf[s], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(v_img, sub * 32, s, lane), dof[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 kb4 = *(const f32x4*)(kbias + sub * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int g = 4 * g4 + e;
+                    const float p = __builtin_amdgcn_exp2f(st[g] * c + kb4[e] - lse2);
+                    st[g] = p * (dp[g] - dl);  // dS^T (unscaled)
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 df = acc_frag(st, s);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt_img, sub * 32, s, dt * 32, lane), df,
+                                                                     dq[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+    store_rows_from_T(dqkv + (size_t)b * S * pitch + hh * HD, pitch, wq0, S, lane, dq, 0.125f);
+}
+
+// ----------------------------------------------------------------------------------------------
+// backward, dK / dV:  one wave = 32 keys, sweep query tiles
+// ----------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv,
+                                                               const int64_t* __restrict__ key_mask,
+                                                               const bf16* __restrict__ dout,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               bf16* __restrict__ dqkv, int B, int S, int H) {
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 2 * TILE * 4];
+    char* q_img = smem;
+    char* qt_img = smem + IMG;
+    char* do_img = smem + 2 * IMG;
+    char* dot_img = smem + 3 * IMG;
+    float* lse_t = (float*)(smem + 4 * IMG);
+    float* dl_t = lse_t + TILE;
+
+    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+    const int kblk0 = blockIdx.x * (NW * 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const size_t pitch = (size_t)3 * H * HD;
+    const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    const bf16* kb = qb + (size_t)H * HD;
+    const bf16* vb = qb + (size_t)2 * H * HD;
+    const bf16* dob = dout + (size_t)b * S * H * HD + hh * HD;
+    const int wk0 = kblk0 + wave * 32;
+    const bool active = wk0 < S;
+    const int key = wk0 + (lane & 31);
+
+    bf16x8 kf[4], vf[4];
+    load_rows_frag(kb, pitch, wk0, S, lane, kf);
+    load_rows_frag(vb, pitch, wk0, S, lane, vf);
+    float kbias = NEG_BIG;
+    if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) kbias = 0.f;
+    const float c = 0.125f * LOG2E;
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { dk[i][g] = 0.f; dv[i][g] = 0.f; }
+
+    for (int q0 = 0; q0 < S; q0 += TILE) {
+        __syncthreads();
+        stage_tile<NT>(qb, pitch, q0, S, tid, q_img, qt_img);
+        stage_tile<NT>(dob, (size_t)H * HD, q0, S, tid, do_img, dot_img);
+        if (tid < TILE) {
+            const int qq = q0 + tid;
+            // rows past S: lse = +big makes P = exp2(-big) = 0, so they add nothing
+            lse_t[tid] = qq < S ? lse[((size_t)b * H + hh) * S + qq] * LOG2E : 1.0e30f;
+            dl_t[tid] = qq < S ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
+        }
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 st, dp;  // rows = queries (register), cols = keys (lane)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(q_img, sub * 32, s, lane), kf[s], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(do_img, sub * 32, s, lane), vf[s], dp, 0, 0, 0);
+            }
+            f32x16 pp;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *(const f32x4*)(lse_t + sub * 32 + 8 * g4 + 4 * h);
+                const f32x4 d4 = *(const f32x4*)(dl_t + sub * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int g = 4 * g4 + e;
+                    const float p = __builtin_amdgcn_exp2f(st[g] * c + kbias - l4[e]);
+                    pp[g] = p;
+                    st[g] = p * (dp[g] - d4[e]);  // dS (unscaled)
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = acc_frag(pp, s);
+                const bf16x8 df = acc_frag(st, s);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_img, sub * 32, s, dt * 32, lane), pf,
+                                                                     dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt_img, sub * 32, s, dt * 32, lane), df,
+                                                                     dk[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    bf16* dkb = dqkv + (size_t)b * S * pitch + (size_t)H * HD + hh * HD;
+    bf16* dvb = dqkv + (size_t)b * S * pitch + (size_t)2 * H * HD + hh * HD;
+    store_rows_from_T(dkb, pitch, wk0, S, lane, dk, 0.125f);
+    store_rows_from_T(dvb, pitch, wk0, S, lane, dv, 1.0f);
+}
+
+}  // namespace
+
+extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int B, int S,
+                           int H, mh_stream_t stream) {
+    if (!qkv || !out || !lse) return MH_EINVAL;
+    if (B < 1 || S < 1 || H < 1) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (S % 128 == 0 || S > 512) {
+        dim3 grid((S + 127) / 128, B * H);
+        hipLaunchKernelGGL((attn_fwd_kernel<4>), grid, dim3(256), 0, s, (const bf16*)qkv, key_mask, (bf16*)out,
+                           lse, B, S, H);
+    } else {
+        dim3 grid((S + 63) / 64, B * H);
+        hipLaunchKernelGGL((attn_fwd_kernel<2>), grid, dim3(128), 0, s, (const bf16*)qkv, key_mask, (bf16*)out,
+                           lse, B, S, H);
+    }
+    return mh_launch_status();
+}
+
+extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
+                           const float* lse, float* delta, void* dqkv, int B, int S, int H,
+                           mh_stream_t stream) {
+    if (!qkv || !out || !dout || !lse || !delta || !dqkv) return MH_EINVAL;
+    if (B < 1 || S < 1 || H < 1) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = B * S * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16*)out,
+                       (const bf16*)dout, delta, B, S, H);
+    if (S % 128 == 0 || S > 512) {
+        dim3 grid((S + 127) / 128, B * H);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<4>), grid, dim3(256), 0, s, (const bf16*)qkv, key_mask,
+                           (const bf16*)dout, lse, delta, (bf16*)dqkv, B, S, H);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4>), grid, dim3(256), 0, s, (const bf16*)qkv, key_mask,
+                           (const bf16*)dout, lse, delta, (bf16*)dqkv, B, S, H);
+    } else {
+        dim3 grid((S + 63) / 64, B * H);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<2>), grid, dim3(128), 0, s, (const bf16*)qkv, key_mask,
+                           (const bf16*)dout, lse, delta, (bf16*)dqkv, B, S, H);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), grid, dim3(128), 0, s, (const bf16*)qkv, key_mask,
+                           (const bf16*)dout, lse, delta, (bf16*)dqkv, B, S, H);
+    }
+    return mh_launch_status();
+}

@@ -1,0 +1,68 @@
+// Shared device helpers for the memehip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/memehip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define MH_DEV __device__ __forceinline__
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// Buffer resource over [base, base+bytes): loads past the end return 0, stores are dropped.
+MH_DEV __amdgpu_buffer_rsrc_t mh_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+MH_DEV i32x4 mh_buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+MH_DEV void mh_buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, i32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);
+}
+
+MH_DEV float mh_bf2f(bf16 x) { return (float)x; }
+MH_DEV bf16 mh_f2bf(float x) { return (bf16)x; }
+
+union Pack8 {
+    i32x4 v;
+    bf16x8 h;
+    bf16 e[8];
+};
+union Pack4 {
+    i32x2 v;
+    bf16x4 h;
+    bf16 e[4];
+};
+
+MH_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+MH_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU and its derivative, fp32
+MH_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+MH_DEV float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+static inline int mh_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MH_OK : MH_ELAUNCH;
+}

@@ -1,0 +1,324 @@
+// BERT embedding gather + LayerNorm forward, deterministic embedding backward, ViT patch
+// gather / token assembly.  HBM-bound row kernels: one wavefront per row, 16/32-B accesses.
+// See include/memehip.h.
+#include "common.h"
+
+namespace {
+
+// ---- BERT embeddings forward: one wave per token ------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void bert_embed_fwd_kernel(
+    const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+    const float* __restrict__ type0, const float* __restrict__ gamma, const float* __restrict__ beta,
+    bf16* __restrict__ pre, bf16* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int T, int S,
+    int D, int vocab, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    int64_t id = ids[t];
+    if (id < 0 || id >= vocab) id = 0;  // never read outside the table
+    const int s = t % S;
+    const float* w = word + (size_t)id * D;
+    const float* p = pos + (size_t)s * D;
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x4 a = *(const f32x4*)(w + c + 4 * hh);
+                const f32x4 b = *(const f32x4*)(p + c + 4 * hh);
+                a += b;
+                if (type0) a += *(const f32x4*)(type0 + c + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[i][4 * hh + e] = a[e]; sum += a[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+    const float mu = wave_sum(sum) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const bool ok = (lane + 64 * i) * 8 < D;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = ok ? v[i][e] - mu : 0.f;
+            ss += d * d;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            Pack8 up, uy;
+            const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                up.e[e] = mh_f2bf(v[i][e]);
+                const float g = e < 4 ? g0[e & 3] : g1[e & 3];
+                const float b = e < 4 ? b0[e & 3] : b1[e & 3];
+                uy.e[e] = mh_f2bf((v[i][e] - mu) * rs * g + b);
+            }
+            *(i32x4*)(pre + (size_t)t * D + c) = up.v;
+            *(i32x4*)(y + (size_t)t * D + c) = uy.v;
+        }
+    }
+    if (lane == 0) { mean[t] = mu; rstd[t] = rs; }
+}
+
+// ---- word-embedding gradient: the first occurrence of an id owns the row and sums all of its
+// duplicates in position order (bitwise reproducible, no atomics) -----------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const int64_t* __restrict__ ids,
+                                                                  const bf16* __restrict__ d_pre,
+                                                                  float* __restrict__ dword, int T, int D,
+                                                                  int vocab, int64_t pad_id) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int64_t id = ids[t];
+    if (id == pad_id || id < 0 || id >= vocab) return;
+    // owner test: any earlier token with the same id?
+    for (int c0 = 0; c0 < t; c0 += 64) {
+        const int j = c0 + lane;
+        const bool hit = (j < t) && (ids[j] == id);
+        if (__ballot(hit)) return;
+    }
+    float acc[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    for (int c0 = (t / 64) * 64; c0 < T; c0 += 64) {
+        const int j = c0 + lane;
+        const bool hit = (j >= t) && (j < T) && (ids[j] == id);
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            const bf16* row = d_pre + (size_t)(c0 + bit) * D;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = (lane + 64 * i) * 8;
+                if (c < D) {
+                    Pack8 u;
+                    u.v = *(const i32x4*)(row + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][e] += mh_bf2f(u.e[e]);
+                }
+            }
+        }
+    }
+    float* out = dword + (size_t)id * D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            *(f32x4*)(out + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+            *(f32x4*)(out + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+        }
+    }
+}
+
+// dpos[s] = sum_b d[b][s]  (rows: tokens per sample = S, B samples); one wave per s
+template <int NCH>
+__global__ __launch_bounds__(256) void sum_over_batch_kernel(const bf16* __restrict__ d, float* __restrict__ out,
+                                                             int B, int S, int D) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    float acc[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const bf16* row = d + ((size_t)b * S + s) * D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < D) {
+                Pack8 u;
+                u.v = *(const i32x4*)(row + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][e] += mh_bf2f(u.e[e]);
+            }
+        }
+    }
+    float* o = out + (size_t)s * D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            *(f32x4*)(o + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+            *(f32x4*)(o + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+        }
+    }
+}
+
+// out[d] = sum_{r<R} in[r][d]   (R small: <= 1024 rows), thread per column
+__global__ __launch_bounds__(256) void colsum_rows_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              int R, int D) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += in[(size_t)r * D + d];
+    out[d] = s;
+}
+
+__global__ __launch_bounds__(256) void zero_rows_kernel(const int64_t* __restrict__ ids, float* __restrict__ table,
+                                                        int n_ids, int D, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_ids) return;
+    const int64_t id = ids[t];
+    if (id < 0 || id >= vocab) return;
+    float* row = table + (size_t)id * D;
+    for (int c = lane * 4; c < D; c += 256) *(f32x4*)(row + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// ---- ViT: im2col gather (f32 image -> bf16 patch rows), 8 outputs per thread ---------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B,
+                                                       int C, int H, int W, int P) {
+    const int gh = H / P, gw = W / P, Kp = C * P * P;
+    const size_t total = (size_t)B * gh * gw * (Kp / 8);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ck = (int)(idx % (Kp / 8));
+    const size_t row = idx / (Kp / 8);
+    const int pw = (int)(row % gw), ph = (int)((row / gw) % gh), b = (int)(row / ((size_t)gw * gh));
+    const int col = ck * 8;
+    const int c = col / (P * P), i = (col / P) % P, j = col % P;
+    const float* src = img + (((size_t)b * C + c) * H + (ph * P + i)) * W + pw * P + j;
+    const f32x4 a = *(const f32x4*)src, d = *(const f32x4*)(src + 4);
+    Pack8 u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { u.e[e] = mh_f2bf(a[e]); u.e[4 + e] = mh_f2bf(d[e]); }
+    *(i32x4*)(out + row * Kp + col) = u.v;
+}
+
+__global__ __launch_bounds__(256) void vit_assemble_fwd_kernel(const bf16* __restrict__ proj,
+                                                               const float* __restrict__ cls,
+                                                               const float* __restrict__ pos, bf16* __restrict__ x,
+                                                               int B, int Np, int D) {
+    const int NT = Np + 1;
+    const size_t total = (size_t)B * NT * (D / 8);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % (D / 8)) * 8;
+    const size_t tok = idx / (D / 8);
+    const int t = (int)(tok % NT), b = (int)(tok / NT);
+    float v[8];
+    if (t == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = cls[c + e];
+    } else {
+        Pack8 u;
+        u.v = *(const i32x4*)(proj + ((size_t)b * Np + (t - 1)) * D + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mh_bf2f(u.e[e]);
+    }
+    Pack8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = mh_f2bf(v[e] + pos[(size_t)t * D + c + e]);
+    *(i32x4*)(x + tok * D + c) = o.v;
+}
+
+__global__ __launch_bounds__(256) void vit_assemble_bwd_copy_kernel(const bf16* __restrict__ dx,
+                                                                    bf16* __restrict__ dproj, int B, int Np,
+                                                                    int D) {
+    const size_t total = (size_t)B * Np * (D / 8);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % (D / 8)) * 8;
+    const size_t row = idx / (D / 8);
+    const int p = (int)(row % Np), b = (int)(row / Np);
+    *(i32x4*)(dproj + row * D + c) = *(const i32x4*)(dx + ((size_t)b * (Np + 1) + 1 + p) * D + c);
+}
+
+}  // namespace
+
+#define NCH_DISPATCH(NAME, ...)                                         \
+    do {                                                                \
+        const int nch = (D / 8 + 63) / 64;                              \
+        if (nch <= 1) hipLaunchKernelGGL((NAME<1>), __VA_ARGS__);       \
+        else if (nch <= 2) hipLaunchKernelGGL((NAME<2>), __VA_ARGS__);  \
+        else if (nch <= 4) hipLaunchKernelGGL((NAME<4>), __VA_ARGS__);  \
+        else hipLaunchKernelGGL((NAME<8>), __VA_ARGS__);                \
+    } while (0)
+
+extern "C" int mh_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                                 const float* gamma, const float* beta, void* pre, void* y, float* mean,
+                                 float* rstd, int B, int S, int D, int vocab, float eps, mh_stream_t stream) {
+    if (!ids || !word || !pos || !gamma || !beta || !pre || !y || !mean || !rstd) return MH_EINVAL;
+    if (B < 1 || S < 1 || D < 8 || (D % 8) || D > 4096 || vocab < 1) return MH_ESHAPE;
+    const int T = B * S;
+    hipStream_t s = (hipStream_t)stream;
+    NCH_DISPATCH(bert_embed_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, word, pos, type0, gamma, beta,
+                 (bf16*)pre, (bf16*)y, mean, rstd, T, S, D, vocab, eps);
+    return mh_launch_status();
+}
+
+extern "C" int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre, float* dword, float* dpos, float* dtype0,
+                                 int B, int S, int D, int vocab, int64_t pad_id, mh_stream_t stream) {
+    if (!ids || !d_pre || !dword || !dpos) return MH_EINVAL;
+    if (B < 1 || S < 1 || D < 8 || (D % 8) || D > 4096 || vocab < 1) return MH_ESHAPE;
+    const int T = B * S;
+    hipStream_t s = (hipStream_t)stream;
+    NCH_DISPATCH(bert_embed_bwd_word_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, (const bf16*)d_pre, dword, T,
+                 D, vocab, pad_id);
+    NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const bf16*)d_pre, dpos, B, S, D);
+    if (dtype0)
+        hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dpos, dtype0, S, D);
+    return mh_launch_status();
+}
+
+extern "C" int mh_zero_rows_f32(const int64_t* ids, float* table, int n_ids, int D, int vocab, mh_stream_t stream) {
+    if (!ids || !table) return MH_EINVAL;
+    if (n_ids < 1 || D < 4 || (D % 4) || vocab < 1) return MH_ESHAPE;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((n_ids + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, table,
+                       n_ids, D, vocab);
+    return mh_launch_status();
+}
+
+extern "C" int mh_patchify(const float* image, void* patches, int B, int C, int H, int W, int P,
+                           mh_stream_t stream) {
+    if (!image || !patches) return MH_EINVAL;
+    if (B < 1 || C < 1 || P < 8 || (P % 8) || (H % P) || (W % P) || (W % 4)) return MH_ESHAPE;
+    const size_t total = (size_t)B * (H / P) * (W / P) * (C * P * P / 8);
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       image, (bf16*)patches, B, C, H, W, P);
+    return mh_launch_status();
+}
+
+extern "C" int mh_vit_assemble_fwd(const void* proj, const float* cls, const float* pos, void* x, int B, int Np,
+                                   int D, mh_stream_t stream) {
+    if (!proj || !cls || !pos || !x) return MH_EINVAL;
+    if (B < 1 || Np < 1 || D < 8 || (D % 8)) return MH_ESHAPE;
+    const size_t total = (size_t)B * (Np + 1) * (D / 8);
+    hipLaunchKernelGGL(vit_assemble_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16*)proj, cls, pos, (bf16*)x, B, Np, D);
+    return mh_launch_status();
+}
+
+extern "C" int mh_vit_assemble_bwd(const void* dx, void* dproj, float* dcls, float* dpos, int B, int Np, int D,
+                                   mh_stream_t stream) {
+    if (!dx || !dproj || !dcls || !dpos) return MH_EINVAL;
+    if (B < 1 || Np < 1 || D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)B * Np * (D / 8);
+    hipLaunchKernelGGL(vit_assemble_bwd_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const bf16*)dx, (bf16*)dproj, B, Np, D);
+    const int S = Np + 1;
+    NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const bf16*)dx, dpos, B, S, D);
+    // d cls = sum_b dx[b][0] = dpos row 0
+    hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dpos, dcls, 1, D);
+    return mh_launch_status();
+}

@@ -1,0 +1,189 @@
+// Late-fusion head (4 small Linear layers, batch rows <= a few dozen) and cross-entropy, in fp32.
+// Latency-bound (2.6 MFLOP): plain VALU kernels with coalesced weight reads.  See include/memehip.h.
+#include "common.h"
+
+namespace {
+
+constexpr int RB = 32;  // batch rows held in registers per pass
+
+// pooled[b] = [ text_hidden[b][pool][:], image_hidden[b][0][:] ]  (bf16 -> f32)
+__global__ __launch_bounds__(256) void pool_kernel(const bf16* __restrict__ th, const bf16* __restrict__ ih,
+                                                   float* __restrict__ pooled, int B, int S, int Nt, int Dt, int Di,
+                                                   int pool) {
+    const int Dp = Dt + Di;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * Dp) return;
+    const int b = idx / Dp, d = idx % Dp;
+    pooled[idx] = d < Dt ? mh_bf2f(th[((size_t)b * S + pool) * Dt + d]) : mh_bf2f(ih[(size_t)b * Nt * Di + (d - Dt)]);
+}
+
+// y[m][n] = b[n] + sum_k x[m][k] W[n][k] ; one wave per output column n
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int ldy, int M, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* w = W + (size_t)n * K;
+    for (int m0 = 0; m0 < M; m0 += RB) {
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float wk = w[k];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (m0 + r < M) acc[r] += wk * x[(size_t)(m0 + r) * ldx + k];
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0 && m0 + r < M) y[(size_t)(m0 + r) * ldy + n] = s + bias[n];
+        }
+    }
+}
+
+// dx[m][k] = sum_n dy[m][n] W[n][k] ; thread per (m, k), wave rows share m
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, int ldy,
+                                                        const float* __restrict__ W, void* __restrict__ dx,
+                                                        size_t ldx, int M, int N, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (k >= K) return;
+    const float* d = dy + (size_t)m * ldy;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) acc += d[n] * W[(size_t)n * K + k];
+    if (OUT_BF16) ((bf16*)dx)[(size_t)m * ldx + k] = mh_f2bf(acc);
+    else ((float*)dx)[(size_t)m * ldx + k] = acc;
+}
+
+// dW[n][k] = sum_m dy[m][n] x[m][k] ; db[n] = sum_m dy[m][n]
+__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, int ldy,
+                                                        const float* __restrict__ x, int ldx,
+                                                        float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                        int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (k >= K) return;
+    float acc = 0.f, accb = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float g = dy[(size_t)m * ldy + n];
+        acc += g * x[(size_t)m * ldx + k];
+        accb += g;
+    }
+    dW[(size_t)n * K + k] = acc;
+    if (k == 0) db[n] = accb;
+}
+
+// cross-entropy forward + dlogits, one block; B <= 1024
+__global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                  float* __restrict__ loss, float* __restrict__ dlogits,
+                                                  int32_t* __restrict__ n_correct, int B, int C, float grad_scale) {
+    __shared__ float red[16];
+    __shared__ int redc[16];
+    const int b = threadIdx.x;
+    float li = 0.f;
+    int ok = 0;
+    if (b < B) {
+        const float* z = logits + (size_t)b * C;
+        float mx = z[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c)
+            if (z[c] > mx) { mx = z[c]; am = c; }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+        const float lse = mx + logf(se);
+        int64_t y = labels[b];
+        if (y < 0 || y >= C) y = 0;
+        li = lse - z[y];
+        ok = (am == (int)y);
+        const float inv = grad_scale / (float)B;
+        for (int c = 0; c < C; ++c)
+            dlogits[(size_t)b * C + c] = (expf(z[c] - lse) - (c == (int)y ? 1.f : 0.f)) * inv;
+    }
+    float s = wave_sum(li);
+    int cs = ok;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o, 64);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; redc[threadIdx.x >> 6] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        int tc = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { t += red[i]; tc += redc[i]; }
+        *loss = t / (float)B;
+        if (n_correct) *n_correct = tc;
+    }
+}
+
+int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N, int K,
+               hipStream_t s) {
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, ldx, W, b, y, ldy, M, N, K);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mh_head_fwd(const MhHeadParams* p, const void* text_hidden, const void* image_hidden,
+                           int text_pool_index, float* pooled, float* feat, float* fused, float* logits, int B,
+                           int S, int Nt, int Dt, int Di, int P, int C, mh_stream_t stream) {
+    if (!p || !text_hidden || !image_hidden || !pooled || !feat || !fused || !logits) return MH_EINVAL;
+    if (!p->Wt || !p->bt || !p->Wi || !p->bi || !p->Wf || !p->bf_ || !p->Wo || !p->bo) return MH_EINVAL;
+    if (B < 1 || text_pool_index < 0 || text_pool_index >= S || Nt < 1 || P < 1 || C < 1) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int Dp = Dt + Di;
+    hipLaunchKernelGGL(pool_kernel, dim3((B * Dp + 255) / 256), dim3(256), 0, s, (const bf16*)text_hidden,
+                       (const bf16*)image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index);
+    linear_fwd(pooled, Dp, p->Wt, p->bt, feat, 2 * P, B, P, Dt, s);
+    linear_fwd(pooled + Dt, Dp, p->Wi, p->bi, feat + P, 2 * P, B, P, Di, s);
+    linear_fwd(feat, 2 * P, p->Wf, p->bf_, fused, P, B, P, 2 * P, s);
+    linear_fwd(fused, P, p->Wo, p->bo, logits, C, B, C, P, s);
+    return mh_launch_status();
+}
+
+extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const float* dlogits, const float* pooled,
+                           const float* feat, const float* fused, float* dfeat, float* dfused, void* d_text_hidden,
+                           void* d_image_hidden, int text_pool_index, int B, int S, int Nt, int Dt, int Di, int P,
+                           int C, mh_stream_t stream) {
+    if (!p || !g || !dlogits || !pooled || !feat || !fused || !dfeat || !dfused || !d_text_hidden ||
+        !d_image_hidden)
+        return MH_EINVAL;
+    if (!g->Wt || !g->bt || !g->Wi || !g->bi || !g->Wf || !g->bf_ || !g->Wo || !g->bo) return MH_EINVAL;
+    if (B < 1 || text_pool_index < 0 || text_pool_index >= S) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int Dp = Dt + Di;
+    auto blocks = [](int k) { return (k + 255) / 256; };
+    // output_fc
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(P), C), dim3(256), 0, s, dlogits, C, fused, P, g->Wo, g->bo, B,
+                       C, P);
+    hipLaunchKernelGGL((linear_dx_kernel<false>), dim3(blocks(P), B), dim3(256), 0, s, dlogits, C, p->Wo,
+                       (void*)dfused, (size_t)P, B, C, P);
+    // fusion_fc
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(2 * P), P), dim3(256), 0, s, dfused, P, feat, 2 * P, g->Wf,
+                       g->bf_, B, P, 2 * P);
+    hipLaunchKernelGGL((linear_dx_kernel<false>), dim3(blocks(2 * P), B), dim3(256), 0, s, dfused, P, p->Wf,
+                       (void*)dfeat, (size_t)(2 * P), B, P, 2 * P);
+    // bert_fc / image_fc
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(Dt), P), dim3(256), 0, s, dfeat, 2 * P, pooled, Dp, g->Wt,
+                       g->bt, B, P, Dt);
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(Di), P), dim3(256), 0, s, dfeat + P, 2 * P, pooled + Dt, Dp,
+                       g->Wi, g->bi, B, P, Di);
+    // gradients of the pooled rows go straight into the [B][S][D] hidden-state gradient buffers
+    hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Dt), B), dim3(256), 0, s, dfeat, 2 * P, p->Wt,
+                       (void*)((bf16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt, B, P, Dt);
+    hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Di), B), dim3(256), 0, s, dfeat + P, 2 * P, p->Wi,
+                       d_image_hidden, (size_t)Nt * Di, B, P, Di);
+    return mh_launch_status();
+}
+
+extern "C" int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                             int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream) {
+    if (!logits || !labels || !loss || !dlogits) return MH_EINVAL;
+    if (B < 1 || B > 1024 || C < 1) return MH_ESHAPE;
+    const int threads = ((B + 63) / 64) * 64;
+    hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, logits, labels, loss, dlogits,
+                       n_correct, B, C, grad_scale);
+    return mh_launch_status();
+}

@@ -1,0 +1,241 @@
+// LayerNorm forward / backward, one 64-lane wavefront per row, 16-B bf16 loads (HBM-bound).
+// See include/memehip.h.  Rows of D <= 4096 live in registers (NCH chunks of 8 per lane).
+#include "common.h"
+
+namespace {
+
+template <int NCH>
+MH_DEV void load_row(const bf16* __restrict__ p, int D, int lane, float (&v)[NCH][8]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            Pack8 u;
+            u.v = *(const i32x4*)(p + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = mh_bf2f(u.e[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+}
+template <int NCH>
+MH_DEV void load_row_f32(const float* __restrict__ p, int D, int lane, float (&v)[NCH][8]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            const f32x4 a = *(const f32x4*)(p + c), b = *(const f32x4*)(p + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        }
+    }
+}
+template <int NCH>
+MH_DEV void store_row(bf16* __restrict__ p, int D, int lane, const float (&v)[NCH][8]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            Pack8 u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u.e[e] = mh_f2bf(v[i][e]);
+            *(i32x4*)(p + c) = u.v;
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NCH][8], g[NCH][8], b[NCH][8];
+    load_row<NCH>(x + (size_t)row * D, D, lane, v);
+    load_row_f32<NCH>(gamma, D, lane, g);
+    load_row_f32<NCH>(beta, D, lane, b);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+    const float mu = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const bool ok = (lane + 64 * i) * 8 < D;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = ok ? v[i][e] - mu : 0.f;
+            ss += d * d;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] - mu) * rs * g[i][e] + b[i][e];
+    store_row<NCH>(y + (size_t)row * D, D, lane, v);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const bf16* __restrict__ dx_add, bf16* __restrict__ dx,
+                                                     float* __restrict__ part, int n_part, int rows, int D) {
+    __shared__ float red[4][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][8], dg[NCH][8], db[NCH][8];
+    load_row_f32<NCH>(gamma, D, lane, g);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+    const float invD = 1.0f / (float)D;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        float xv[NCH][8], dv[NCH][8];
+        load_row<NCH>(x + (size_t)row * D, D, lane, xv);
+        load_row<NCH>(dy + (size_t)row * D, D, lane, dv);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const bool ok = (lane + 64 * i) * 8 < D;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = ok ? (xv[i][e] - mu) * rs : 0.f;
+                const float dyg = dv[i][e] * g[i][e];
+                xv[i][e] = xh;
+                dg[i][e] += dv[i][e] * xh;
+                db[i][e] += dv[i][e];
+                c1 += dyg;
+                c2 += dyg * xh;
+            }
+        }
+        c1 = wave_sum(c1) * invD;
+        c2 = wave_sum(c2) * invD;
+        if (dx_add) {
+            float av[NCH][8];
+            load_row<NCH>(dx_add + (size_t)row * D, D, lane, av);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    dv[i][e] = rs * (dv[i][e] * g[i][e] - c1 - xv[i][e] * c2) + av[i][e];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[i][e] = rs * (dv[i][e] * g[i][e] - c1 - xv[i][e] * c2);
+        }
+        store_row<NCH>(dx + (size_t)row * D, D, lane, dv);
+    }
+    // cross-wave reduce of the column partials, one chunk slot at a time
+    float* pg = part + (size_t)blockIdx.x * D;
+    float* pb = part + (size_t)n_part * D + (size_t)blockIdx.x * D;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = pass == 0 ? dg[i][e] : db[i][e];
+            __syncthreads();
+            // 512 columns of this chunk slot, 256 threads -> 2 each
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int cidx = threadIdx.x + 256 * k;  // = l*8+e
+                const int col = (cidx >> 3) * 8 + 64 * 8 * i + (cidx & 7);
+                if (col < D) {
+                    const float s = red[0][cidx] + red[1][cidx] + red[2][cidx] + red[3][cidx];
+                    (pass == 0 ? pg : pb)[col] = s;
+                }
+            }
+        }
+    }
+}
+
+struct ColsumJobs {
+    int n;
+    const float* part[MH_COLSUM_MAX_JOBS];
+    float* out0[MH_COLSUM_MAX_JOBS];
+    float* out1[MH_COLSUM_MAX_JOBS];
+};
+
+// grid (ceil(D/64), 2, n_jobs), block 256: 4 waves split the partial rows, lane = column
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs jobs, int n_part, int D) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int which = blockIdx.y, job = blockIdx.z;
+    float* out = which == 0 ? jobs.out0[job] : jobs.out1[job];
+    if (!out) return;
+    const float* p = jobs.part[job] + (size_t)which * n_part * D;
+    float s = 0.f;
+    if (col < D)
+        for (int i = wave; i < n_part; i += 4) s += p[(size_t)i * D + col];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < D) out[col] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+}  // namespace
+
+#define LN_DISPATCH(NAME, ...)                                          \
+    do {                                                                \
+        const int nch = (D / 8 + 63) / 64;                              \
+        if (nch <= 1) hipLaunchKernelGGL((NAME<1>), __VA_ARGS__);       \
+        else if (nch <= 2) hipLaunchKernelGGL((NAME<2>), __VA_ARGS__);  \
+        else if (nch <= 4) hipLaunchKernelGGL((NAME<4>), __VA_ARGS__);  \
+        else hipLaunchKernelGGL((NAME<8>), __VA_ARGS__);                \
+    } while (0)
+
+extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                float* rstd, int rows, int D, float eps, mh_stream_t stream) {
+    if (!x || !gamma || !beta || !y) return MH_EINVAL;
+    if (rows < 1 || D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    LN_DISPATCH(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean,
+                rstd, rows, D, eps);
+    return mh_launch_status();
+}
+
+extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                const float* rstd, const void* dx_add, void* dx, float* part, int n_part, int rows,
+                                int D, mh_stream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !part) return MH_EINVAL;
+    if (rows < 1 || n_part < 1 || D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    LN_DISPATCH(ln_bwd_kernel, dim3(n_part), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd,
+                (const bf16*)dx_add, (bf16*)dx, part, n_part, rows, D);
+    return mh_launch_status();
+}
+
+extern "C" int mh_colsum_partials_f32(const MhColsumJob* jobs, int n_jobs, int n_part, int D, mh_stream_t stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > MH_COLSUM_MAX_JOBS) return MH_EINVAL;
+    if (n_part < 1 || D < 1) return MH_ESHAPE;
+    ColsumJobs j;
+    j.n = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!jobs[i].part) return MH_EINVAL;
+        j.part[i] = jobs[i].part;
+        j.out0[i] = jobs[i].out0;
+        j.out1[i] = jobs[i].out1;
+    }
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64, 2, n_jobs), dim3(256), 0, (hipStream_t)stream, j,
+                       n_part, D);
+    return mh_launch_status();
+}

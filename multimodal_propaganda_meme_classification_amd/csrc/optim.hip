@@ -1,0 +1,159 @@
+// Fused dense Adam / AdamW over the flat parameter buffer + grad-norm + casts (HBM-bound,
+// 16-B accesses, grid-stride).  All per-step scalars come from DEVICE memory so a captured
+// hipGraph of the whole step can be replayed with new values.  See include/memehip.h.
+#include "common.h"
+
+namespace {
+
+constexpr int OPT_BLOCKS = 2048;
+
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, int64_t n,
+                                                         float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(g + 4 * i);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = g[4 * n4 + threadIdx.x];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int n,
+                                                          float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// hyper (device, f32[8]): lr, beta1, beta2, eps, weight_decay, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* __restrict__ g,
+                                                   bf16* __restrict__ shadow, int64_t n, int64_t n_shadow,
+                                                   const float* __restrict__ hyper, int decoupled,
+                                                   const float* __restrict__ gnorm_sq, float max_norm) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+    const float inv_bc1 = hyper[5], inv_sqrt_bc2 = hyper[6];
+    float gs = hyper[7];
+    if (gnorm_sq) {
+        const float nrm = sqrtf(gnorm_sq[0]) * fabsf(gs);
+        gs *= fminf(1.0f, max_norm / (nrm + 1e-6f));
+    }
+    const float step = lr * inv_bc1;
+    const float decay = decoupled ? 1.0f - lr * wd : 1.0f;
+    const float l2 = decoupled ? 0.f : wd;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pv = *(const f32x4*)(p + 4 * i);
+        f32x4 mv = *(const f32x4*)(m + 4 * i);
+        f32x4 vv = *(const f32x4*)(v + 4 * i);
+        const f32x4 gv = *(const f32x4*)(g + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float w = pv[e] * decay;
+            const float gg = gv[e] * gs + l2 * w;
+            const float mm = mv[e] * b1 + (1.0f - b1) * gg;
+            const float v2 = vv[e] * b2 + (1.0f - b2) * gg * gg;
+            w -= step * (mm / (sqrtf(v2) * inv_sqrt_bc2 + eps));
+            pv[e] = w; mv[e] = mm; vv[e] = v2;
+        }
+        *(f32x4*)(p + 4 * i) = pv;
+        *(f32x4*)(m + 4 * i) = mv;
+        *(f32x4*)(v + 4 * i) = vv;
+        if (shadow && 4 * i + 3 < n_shadow) {
+            Pack4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u.e[e] = mh_f2bf(pv[e]);
+            *(i32x2*)(shadow + 4 * i) = u.v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                            int64_t n) {
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f32x4 a = *(const f32x4*)(src + 8 * i), b = *(const f32x4*)(src + 8 * i + 4);
+        Pack8 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { u.e[e] = mh_f2bf(a[e]); u.e[4 + e] = mh_f2bf(b[e]); }
+        *(i32x4*)(dst + 8 * i) = u.v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[8 * n8 + threadIdx.x] = mh_f2bf(src[8 * n8 + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* __restrict__ src, float* __restrict__ dst,
+                                                            int64_t n) {
+    const int64_t n8 = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        Pack8 u;
+        u.v = *(const i32x4*)(src + 8 * i);
+        *(f32x4*)(dst + 8 * i) = f32x4{mh_bf2f(u.e[0]), mh_bf2f(u.e[1]), mh_bf2f(u.e[2]), mh_bf2f(u.e[3])};
+        *(f32x4*)(dst + 8 * i + 4) = f32x4{mh_bf2f(u.e[4]), mh_bf2f(u.e[5]), mh_bf2f(u.e[6]), mh_bf2f(u.e[7])};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[8 * n8 + threadIdx.x] = mh_bf2f(src[8 * n8 + threadIdx.x]);
+}
+
+int grid_for(int64_t work_items) {
+    int64_t b = (work_items + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b > OPT_BLOCKS ? OPT_BLOCKS : b);
+}
+
+}  // namespace
+
+extern "C" int mh_sumsq_f32(const float* g, int64_t n, float* workspace, float* out, mh_stream_t stream) {
+    if (!g || !workspace || !out) return MH_EINVAL;
+    if (n < 1 || ((uintptr_t)g & 15)) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = grid_for(n / 4 / 8 + 1) > 1024 ? 1024 : grid_for(n / 4 / 8 + 1);
+    hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(256), 0, s, g, n, workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, workspace, nb, out);
+    return mh_launch_status();
+}
+
+extern "C" int mh_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t n,
+                            int64_t n_shadow, const float* hyper, int decoupled, const float* gnorm_sq,
+                            float max_norm, mh_stream_t stream) {
+    if (!p || !m || !v || !g || !hyper) return MH_EINVAL;
+    if (n < 4 || (n & 3) || (n_shadow & 3) || n_shadow > n) return MH_ESHAPE;
+    if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
+                       (bf16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm);
+    return mh_launch_status();
+}
+
+extern "C" int mh_cast_f32_bf16(const float* src, void* dst, int64_t n, mh_stream_t stream) {
+    if (!src || !dst) return MH_EINVAL;
+    if (n < 1 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MH_ESHAPE;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16*)dst, n);
+    return mh_launch_status();
+}
+extern "C" int mh_cast_bf16_f32(const void* src, float* dst, int64_t n, mh_stream_t stream) {
+    if (!src || !dst) return MH_EINVAL;
+    if (n < 1 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MH_ESHAPE;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)src, dst, n);
+    return mh_launch_status();
+}
+
+extern "C" const char* mh_version(void) { return "memehip 0.1 (gfx950)"; }
+extern "C" const char* mh_status_str(int status) {
+    switch (status) {
+        case MH_OK: return "ok";
+        case MH_EINVAL: return "invalid argument (null / misaligned pointer or bad flag)";
+        case MH_ESHAPE: return "shape not supported by the gfx950 tiling";
+        case MH_ELAUNCH: return "HIP launch/runtime error";
+        default: return "unknown status";
+    }
+}

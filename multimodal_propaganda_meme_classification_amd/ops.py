@@ -1,0 +1,312 @@
+"""Tensor-level wrappers over the memehip C ABI (one call = one fused HIP op).
+
+PyTorch here is plumbing only: it owns device memory and the current stream.
+Every wrapper validates device / dtype / contiguity on the host (a kernel that
+faults can reset the GPU), then enqueues on ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhColsumJob, MhGemmProblem, MhHeadGrads,
+                   MhHeadParams, check)
+
+BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise _lib.MemehipError(f"{name}: memehip kernels need a HIP device tensor (got {t.device}); no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------
+
+class Gemm:
+    """One problem of a grouped launch (see MhGemmProblem in include/memehip.h)."""
+
+    __slots__ = ("A", "B", "C", "bias", "residual", "aux", "mul", "rowsum", "M", "N", "K", "lda", "ldb", "ldc",
+                 "flags")
+
+    def __init__(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, residual=None, aux=None, mul=None,
+                 rowsum=None, gelu=False, accum=False):
+        self.A, self.B, self.C = A, B, C
+        self.bias, self.residual, self.aux, self.mul, self.rowsum = bias, residual, aux, mul, rowsum
+        self.M, self.N, self.K, self.lda, self.ldb, self.ldc = M, N, K, lda, ldb, ldc
+        self.flags = (MH_GEMM_GELU if gelu else 0) | (MH_GEMM_OUT_F32 if C.dtype == F32 else 0) | \
+                     (MH_GEMM_ACCUM if accum else 0)
+
+
+def _min_elems(rows: int, ld: int, cols: int) -> int:
+    return (rows - 1) * ld + cols
+
+
+def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
+    n = len(problems)
+    arr = (MhGemmProblem * n)()
+    for i, g in enumerate(problems):
+        _chk(g.A, BF16, "A", False), _chk(g.B, BF16, "B", False)
+        if g.C.dtype not in (BF16, F32) or not g.C.is_cuda:
+            raise TypeError("C must be a bf16 or f32 device tensor")
+        # extents the kernel will touch
+        a_need = _min_elems(g.K, g.lda, g.M) if a_kmajor else _min_elems(g.M, g.lda, g.K)
+        b_need = _min_elems(g.K, g.ldb, g.N) if b_kmajor else _min_elems(g.N, g.ldb, g.K)
+        c_need = _min_elems(g.M, g.ldc, g.N)
+        if g.A.numel() < a_need or g.B.numel() < b_need or g.C.numel() < c_need:
+            raise ValueError(f"gemm problem {i}: operand smaller than M/N/K/ld imply")
+        for nm, t, dt, need in (("bias", g.bias, F32, g.N), ("residual", g.residual, BF16, c_need),
+                                ("aux", g.aux, BF16, c_need), ("mul", g.mul, BF16, c_need),
+                                ("rowsum", g.rowsum, F32, g.M)):
+            if t is not None:
+                _chk(t, dt, nm, False)
+                if t.numel() < need:
+                    raise ValueError(f"gemm problem {i}: {nm} too small")
+        a = arr[i]
+        a.A, a.B, a.C = _p(g.A), _p(g.B), _p(g.C)
+        a.bias, a.residual, a.aux, a.mul, a.rowsum = _p(g.bias), _p(g.residual), _p(g.aux), _p(g.mul), _p(g.rowsum)
+        a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.flags = g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.flags
+    check(_lib.load().mh_gemm_bf16_grouped(arr, n, int(a_kmajor), int(b_kmajor), _stream()), "mh_gemm_bf16_grouped")
+
+
+def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False):
+    """y[T,N] = epi(x[T,K] @ w[N,K]^T)"""
+    T, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((T, N), dtype=BF16, device=x.device)
+    gemm_grouped([Gemm(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual,
+                       aux=aux, gelu=gelu)], False, False)
+    return out
+
+
+def linear_dgrad(dy, w, out=None, mul=None, residual=None):
+    """dx[T,K] = dy[T,N] @ w[N,K]  (optionally * gelu'(mul), + residual)"""
+    T, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty((T, K), dtype=BF16, device=dy.device)
+    gemm_grouped([Gemm(dy, w, out, T, K, N, dy.stride(0), w.stride(0), out.stride(0), mul=mul, residual=residual)],
+                 False, True)
+    return out
+
+
+def linear_wgrad(dy, x, dw, dbias=None, accum=False):
+    """dw[N,K] (f32) = dy[T,N]^T @ x[T,K] ; dbias[N] = colsum(dy)"""
+    T, N = dy.shape
+    K = x.shape[1]
+    gemm_grouped([Gemm(dy, x, dw, N, K, T, dy.stride(0), x.stride(0), dw.stride(0), rowsum=dbias, accum=accum)],
+                 True, True)
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------
+
+def layernorm_fwd(x, gamma, beta, eps, y=None, mean=None, rstd=None):
+    _chk(x, BF16, "x"), _chk(gamma, F32, "gamma"), _chk(beta, F32, "beta")
+    rows, D = x.shape
+    y = torch.empty_like(x) if y is None else _chk(y, BF16, "y")
+    mean = torch.empty(rows, dtype=F32, device=x.device) if mean is None else mean
+    rstd = torch.empty(rows, dtype=F32, device=x.device) if rstd is None else rstd
+    check(_lib.load().mh_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps),
+                                       _stream()), "mh_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, part, dx=None, dx_add=None):
+    _chk(dy, BF16, "dy"), _chk(x, BF16, "x"), _chk(gamma, F32, "gamma"), _chk(part, F32, "part")
+    rows, D = x.shape
+    n_part = part.shape[1]
+    assert part.shape == (2, n_part, D) and mean.numel() >= rows and rstd.numel() >= rows
+    dx = torch.empty_like(x) if dx is None else _chk(dx, BF16, "dx")
+    check(_lib.load().mh_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(part),
+                                       n_part, rows, D, _stream()), "mh_layernorm_bwd")
+    return dx
+
+
+def colsum_partials(jobs, n_part: int, D: int):
+    """jobs: list of (part[2,n_part,D], out0 or None, out1 or None)"""
+    for i in range(0, len(jobs), _lib.MH_COLSUM_MAX_JOBS):
+        chunk = jobs[i:i + _lib.MH_COLSUM_MAX_JOBS]
+        arr = (MhColsumJob * len(chunk))()
+        for j, (part, o0, o1) in enumerate(chunk):
+            _chk(part, F32, "part")
+            assert part.numel() >= 2 * n_part * D
+            for o in (o0, o1):
+                if o is not None:
+                    _chk(o, F32, "out", False)
+                    assert o.numel() >= D
+            arr[j].part, arr[j].out0, arr[j].out1 = _p(part), _p(o0), _p(o1)
+        check(_lib.load().mh_colsum_partials_f32(arr, len(chunk), n_part, D, _stream()), "mh_colsum_partials_f32")
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+
+def attn_fwd(qkv, key_mask, B, S, H, out=None, lse=None):
+    _chk(qkv, BF16, "qkv")
+    assert qkv.numel() == B * S * 3 * H * 64
+    if key_mask is not None:
+        _chk(key_mask, I64, "key_mask")
+        assert key_mask.numel() == B * S
+    out = torch.empty((B * S, H * 64), dtype=BF16, device=qkv.device) if out is None else _chk(out, BF16, "out")
+    lse = torch.empty((B, H, S), dtype=F32, device=qkv.device) if lse is None else _chk(lse, F32, "lse")
+    assert out.numel() == B * S * H * 64 and lse.numel() == B * H * S
+    check(_lib.load().mh_attn_fwd(_p(qkv), _p(key_mask), _p(out), _p(lse), B, S, H, _stream()), "mh_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, key_mask, out, dout, lse, B, S, H, dqkv=None, delta=None):
+    _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse")
+    assert qkv.numel() == B * S * 3 * H * 64 and out.numel() == B * S * H * 64 == dout.numel()
+    assert lse.numel() == B * H * S
+    dqkv = torch.empty_like(qkv) if dqkv is None else _chk(dqkv, BF16, "dqkv")
+    delta = torch.empty((B, H, S), dtype=F32, device=qkv.device) if delta is None else _chk(delta, F32, "delta")
+    assert dqkv.numel() == qkv.numel() and delta.numel() == B * H * S
+    check(_lib.load().mh_attn_bwd(_p(qkv), _p(key_mask), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, S, H,
+                                  _stream()), "mh_attn_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------
+# embeddings / patches
+# ---------------------------------------------------------------------------------------------
+
+def bert_embed_fwd(ids, word, pos, type0, gamma, beta, eps, pre, y, mean, rstd):
+    _chk(ids, I64, "ids"), _chk(word, F32, "word"), _chk(pos, F32, "pos")
+    B, S = ids.shape
+    V, D = word.shape
+    assert pos.shape[0] >= S and pos.shape[1] == D
+    assert pre.numel() >= B * S * D and y.numel() >= B * S * D and mean.numel() >= B * S and rstd.numel() >= B * S
+    check(_lib.load().mh_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta),
+                                        _p(_chk(pre, BF16, "pre")), _p(_chk(y, BF16, "y")), _p(mean), _p(rstd), B, S,
+                                        D, V, float(eps), _stream()), "mh_bert_embed_fwd")
+
+
+def bert_embed_bwd(ids, d_pre, dword, dpos, dtype0, pad_id: int):
+    _chk(ids, I64, "ids"), _chk(d_pre, BF16, "d_pre"), _chk(dword, F32, "dword"), _chk(dpos, F32, "dpos")
+    B, S = ids.shape
+    V, D = dword.shape
+    assert d_pre.numel() >= B * S * D and dpos.shape[0] >= S
+    check(_lib.load().mh_bert_embed_bwd(_p(ids), _p(d_pre), _p(dword), _p(dpos), _p(dtype0), B, S, D, V, int(pad_id),
+                                        _stream()), "mh_bert_embed_bwd")
+
+
+def zero_rows(ids, table):
+    _chk(ids, I64, "ids"), _chk(table, F32, "table")
+    V, D = table.shape
+    check(_lib.load().mh_zero_rows_f32(_p(ids), _p(table), ids.numel(), D, V, _stream()), "mh_zero_rows_f32")
+
+
+def patchify(image, patch: int, out=None):
+    _chk(image, F32, "image")
+    B, Cc, H, W = image.shape
+    rows, K = B * (H // patch) * (W // patch), Cc * patch * patch
+    out = torch.empty((rows, K), dtype=BF16, device=image.device) if out is None else _chk(out, BF16, "patches")
+    assert out.numel() >= rows * K
+    check(_lib.load().mh_patchify(_p(image), _p(out), B, Cc, H, W, patch, _stream()), "mh_patchify")
+    return out
+
+
+def vit_assemble_fwd(proj, cls, pos, x, B, Np, D):
+    _chk(proj, BF16, "proj"), _chk(cls, F32, "cls"), _chk(pos, F32, "pos"), _chk(x, BF16, "x")
+    assert proj.numel() >= B * Np * D and cls.numel() >= D and pos.numel() >= (Np + 1) * D and x.numel() >= B * (Np + 1) * D
+    check(_lib.load().mh_vit_assemble_fwd(_p(proj), _p(cls), _p(pos), _p(x), B, Np, D, _stream()), "mh_vit_assemble_fwd")
+
+
+def vit_assemble_bwd(dx, dproj, dcls, dpos, B, Np, D):
+    _chk(dx, BF16, "dx"), _chk(dproj, BF16, "dproj"), _chk(dcls, F32, "dcls"), _chk(dpos, F32, "dpos")
+    assert dx.numel() >= B * (Np + 1) * D and dproj.numel() >= B * Np * D and dcls.numel() >= D and dpos.numel() >= (Np + 1) * D
+    check(_lib.load().mh_vit_assemble_bwd(_p(dx), _p(dproj), _p(dcls), _p(dpos), B, Np, D, _stream()), "mh_vit_assemble_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# head / loss / optimizer
+# ---------------------------------------------------------------------------------------------
+
+def _head_struct(cls, tensors):
+    s = cls()
+    for name, t in zip(("Wt", "bt", "Wi", "bi", "Wf", "bf_", "Wo", "bo"), tensors):
+        _chk(t, F32, name)
+        setattr(s, name, _p(t))
+    return s
+
+
+def head_fwd(params, text_hidden, image_hidden, pool_index, pooled, feat, fused, logits, B, S, Nt, Dt, Di, P, Cn):
+    hp = _head_struct(MhHeadParams, params)
+    _chk(text_hidden, BF16, "text_hidden"), _chk(image_hidden, BF16, "image_hidden")
+    assert text_hidden.numel() >= B * S * Dt and image_hidden.numel() >= B * Nt * Di
+    assert pooled.numel() >= B * (Dt + Di) and feat.numel() >= B * 2 * P and fused.numel() >= B * P and logits.numel() >= B * Cn
+    assert params[0].numel() == P * Dt and params[2].numel() == P * Di and params[4].numel() == P * 2 * P and params[6].numel() == Cn * P
+    check(_lib.load().mh_head_fwd(C.byref(hp), _p(text_hidden), _p(image_hidden), pool_index, _p(pooled), _p(feat),
+                                  _p(fused), _p(logits), B, S, Nt, Dt, Di, P, Cn, _stream()), "mh_head_fwd")
+
+
+def head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, d_text_hidden, d_image_hidden, pool_index,
+             B, S, Nt, Dt, Di, P, Cn):
+    hp = _head_struct(MhHeadParams, params)
+    hg = _head_struct(MhHeadGrads, grads)
+    for a, b in zip(params, grads):
+        assert a.numel() == b.numel()
+    _chk(d_text_hidden, BF16, "d_text_hidden"), _chk(d_image_hidden, BF16, "d_image_hidden")
+    assert d_text_hidden.numel() >= B * S * Dt and d_image_hidden.numel() >= B * Nt * Di
+    assert dfeat.numel() >= B * 2 * P and dfused.numel() >= B * P and dlogits.numel() >= B * Cn
+    check(_lib.load().mh_head_bwd(C.byref(hp), C.byref(hg), _p(dlogits), _p(pooled), _p(feat), _p(fused), _p(dfeat),
+                                  _p(dfused), _p(d_text_hidden), _p(d_image_hidden), pool_index, B, S, Nt, Dt, Di, P,
+                                  Cn, _stream()), "mh_head_bwd")
+
+
+def ce_fwd_bwd(logits, labels, loss, dlogits, n_correct=None, grad_scale: float = 1.0):
+    _chk(logits, F32, "logits"), _chk(labels, I64, "labels"), _chk(loss, F32, "loss"), _chk(dlogits, F32, "dlogits")
+    B, Cn = logits.shape
+    assert labels.numel() >= B and dlogits.numel() >= B * Cn
+    if n_correct is not None:
+        _chk(n_correct, torch.int32, "n_correct")
+    check(_lib.load().mh_ce_fwd_bwd(_p(logits), _p(labels), _p(loss), _p(dlogits), _p(n_correct), B, Cn,
+                                    float(grad_scale), _stream()), "mh_ce_fwd_bwd")
+
+
+def sumsq(g, workspace, out):
+    _chk(g, F32, "g"), _chk(workspace, F32, "workspace"), _chk(out, F32, "out")
+    assert workspace.numel() >= 1024
+    check(_lib.load().mh_sumsq_f32(_p(g), g.numel(), _p(workspace), _p(out), _stream()), "mh_sumsq_f32")
+
+
+def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0):
+    for nm, t in (("p", p), ("m", m), ("v", v), ("g", g), ("hyper", hyper)):
+        _chk(t, F32, nm)
+    n = p.numel()
+    assert m.numel() == n and v.numel() == n and g.numel() == n and hyper.numel() >= 8
+    if shadow is not None:
+        _chk(shadow, BF16, "shadow")
+        assert shadow.numel() >= n_shadow
+    check(_lib.load().mh_adam_step(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, n_shadow if shadow is not None else 0,
+                                   _p(hyper), int(decoupled), _p(gnorm_sq), float(max_norm), _stream()), "mh_adam_step")
+
+
+def cast_f32_bf16(src, dst):
+    _chk(src, F32, "src"), _chk(dst, BF16, "dst")
+    assert dst.numel() >= src.numel()
+    check(_lib.load().mh_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "mh_cast_f32_bf16")

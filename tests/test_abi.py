@@ -1,0 +1,67 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads, and exports exactly the
+symbols include/memehip.h declares; the Python binding covers all of them; and the product refuses
+to run without a HIP device (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "memehip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from multimodal_propaganda_meme_classification_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported(lib):
+    names = _declared()
+    assert len(names) >= 20
+    cdll = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(cdll, n), f"{n} declared in include/memehip.h but not exported"
+
+
+def test_binding_covers_header(lib):
+    assert sorted(lib.EXPORTED_SYMBOLS) == _declared()
+    handle = lib.load()
+    assert handle.mh_version().startswith(b"memehip")
+    assert b"shape" in handle.mh_status_str(2)
+
+
+def test_struct_layout_matches_header(lib):
+    # 8 pointers + 8 int32 = 96 bytes; a drift here would corrupt every grouped launch
+    assert ctypes.sizeof(lib.MhGemmProblem) == 96
+    assert ctypes.sizeof(lib.MhColsumJob) == 24
+    assert ctypes.sizeof(lib.MhHeadParams) == 64 == ctypes.sizeof(lib.MhHeadGrads)
+
+
+def test_no_cpu_fallback(lib):
+    from multimodal_propaganda_meme_classification_amd import ops
+    x = torch.zeros((128, 64), dtype=torch.bfloat16)
+    w = torch.zeros((128, 64), dtype=torch.bfloat16)
+    with pytest.raises(lib.MemehipError):
+        ops.linear_fwd(x, w)
+    with pytest.raises(lib.MemehipError):
+        ops.layernorm_fwd(x, torch.ones(64), torch.zeros(64), 1e-6)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "multimodal_propaganda_meme_classification_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "from .. import oracle" not in src and "import oracle" not in src, f
