@@ -86,7 +86,8 @@ int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems,
  *         finish with mh_colsum_partials_f32.
  * ------------------------------------------------------------------------------------------ */
 int mh_layernorm_fwd(const void* x /*bf16*/, const float* gamma, const float* beta, void* y /*bf16*/,
-                     float* mean, float* rstd, int rows, int D, float eps, mh_stream_t stream);
+                     float* y_f32 /*optional unrounded copy of y, or NULL*/, float* mean, float* rstd,
+                     int rows, int D, float eps, mh_stream_t stream);
 int mh_layernorm_bwd(const void* dy /*bf16*/, const void* x /*bf16*/, const float* gamma,
                      const float* mean, const float* rstd, const void* dx_add /*bf16 or NULL*/,
                      void* dx /*bf16*/, float* part /*[2][n_part][D]*/, int n_part, int rows, int D,
@@ -152,7 +153,8 @@ int mh_vit_assemble_bwd(const void* dx /*bf16 [B][Np+1][D]*/, void* dproj /*bf16
  * Late-fusion head + cross-entropy, fp32 (Multimodal_example_task2C.txt:178-195, :248, :214):
  *   t = W_t h_t[:, pool] + b ; v = W_i h_i[:, 0] + b ; f = W_f [t;v] + b ; z = W_o f + b
  *   loss = mean_b( logsumexp(z_b) - z_b[y_b] )
- * mh_head_fwd writes logits [B][C], per-row loss terms, and keeps t|v (feat [B][2P]) and f ([B][P]).
+ * The towers' final LayerNorm outputs are consumed UNROUNDED (f32) so the head adds no bf16 error.
+ * mh_head_fwd writes logits [B][C] and keeps pooled, t|v (feat [B][2P]) and f ([B][P]).
  * mh_head_bwd consumes dlogits [B][C] (f32) and produces all head grads (f32, overwritten) and
  *   d_text_hidden / d_image_hidden rows (bf16, written into the [T][D] gradient buffers at the
  *   pooled token rows; the other rows must be zero-filled by the caller).
@@ -168,8 +170,8 @@ typedef struct MhHeadGrads {
     float *Wt, *bt, *Wi, *bi, *Wf, *bf_, *Wo, *bo;
 } MhHeadGrads;
 
-int mh_head_fwd(const MhHeadParams* p /*host*/, const void* text_hidden /*bf16 [B][S][Dt]*/,
-                const void* image_hidden /*bf16 [B][Nt][Di]*/, int text_pool_index, float* pooled
+int mh_head_fwd(const MhHeadParams* p /*host*/, const float* text_hidden /*f32 [B][S][Dt]*/,
+                const float* image_hidden /*f32 [B][Nt][Di]*/, int text_pool_index, float* pooled
                 /*[B][Dt+Di] f32*/, float* feat /*[B][2P]*/, float* fused /*[B][P]*/,
                 float* logits /*[B][C]*/, int B, int S, int Nt, int Dt, int Di, int P, int C,
                 mh_stream_t stream);

@@ -4,3 +4,6 @@ Host side is Python (the reference is Python); all arithmetic runs in hand-writt
 for gfx950 behind the C ABI in include/memehip.h (libmemehip.so).  No CPU fallback.
 """
 from . import _lib  # noqa: F401
+from ._lib import MemehipError  # noqa: F401
+from .config import ImageConfig, Layout, ModelConfig, TextConfig  # noqa: F401
+from .model import Adam, CrossEntropyLoss, GraphedStep, MultimodalClassifier  # noqa: F401

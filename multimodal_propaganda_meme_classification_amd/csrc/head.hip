@@ -6,15 +6,15 @@ namespace {
 
 constexpr int RB = 32;  // batch rows held in registers per pass
 
-// pooled[b] = [ text_hidden[b][pool][:], image_hidden[b][0][:] ]  (bf16 -> f32)
-__global__ __launch_bounds__(256) void pool_kernel(const bf16* __restrict__ th, const bf16* __restrict__ ih,
+// pooled[b] = [ text_hidden[b][pool][:], image_hidden[b][0][:] ]
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ th, const float* __restrict__ ih,
                                                    float* __restrict__ pooled, int B, int S, int Nt, int Dt, int Di,
                                                    int pool) {
     const int Dp = Dt + Di;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * Dp) return;
     const int b = idx / Dp, d = idx % Dp;
-    pooled[idx] = d < Dt ? mh_bf2f(th[((size_t)b * S + pool) * Dt + d]) : mh_bf2f(ih[(size_t)b * Nt * Di + (d - Dt)]);
+    pooled[idx] = d < Dt ? th[((size_t)b * S + pool) * Dt + d] : ih[(size_t)b * Nt * Di + (d - Dt)];
 }
 
 // y[m][n] = b[n] + sum_k x[m][k] W[n][k] ; one wave per output column n
@@ -126,7 +126,7 @@ int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y
 
 }  // namespace
 
-extern "C" int mh_head_fwd(const MhHeadParams* p, const void* text_hidden, const void* image_hidden,
+extern "C" int mh_head_fwd(const MhHeadParams* p, const float* text_hidden, const float* image_hidden,
                            int text_pool_index, float* pooled, float* feat, float* fused, float* logits, int B,
                            int S, int Nt, int Dt, int Di, int P, int C, mh_stream_t stream) {
     if (!p || !text_hidden || !image_hidden || !pooled || !feat || !fused || !logits) return MH_EINVAL;
@@ -134,8 +134,8 @@ extern "C" int mh_head_fwd(const MhHeadParams* p, const void* text_hidden, const
     if (B < 1 || text_pool_index < 0 || text_pool_index >= S || Nt < 1 || P < 1 || C < 1) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Dp = Dt + Di;
-    hipLaunchKernelGGL(pool_kernel, dim3((B * Dp + 255) / 256), dim3(256), 0, s, (const bf16*)text_hidden,
-                       (const bf16*)image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index);
+    hipLaunchKernelGGL(pool_kernel, dim3((B * Dp + 255) / 256), dim3(256), 0, s, text_hidden,
+                       image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index);
     linear_fwd(pooled, Dp, p->Wt, p->bt, feat, 2 * P, B, P, Dt, s);
     linear_fwd(pooled + Dt, Dp, p->Wi, p->bi, feat + P, 2 * P, B, P, Di, s);
     linear_fwd(feat, 2 * P, p->Wf, p->bf_, fused, P, B, P, 2 * P, s);

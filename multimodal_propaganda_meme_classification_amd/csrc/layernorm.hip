@@ -52,8 +52,8 @@ MH_DEV void store_row(bf16* __restrict__ p, int D, int lane, const float (&v)[NC
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int D, float eps) {
+                                                     float* __restrict__ y32, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -83,6 +83,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] - mu) * rs * g[i][e] + b[i][e];
     store_row<NCH>(y + (size_t)row * D, D, lane, v);
+    if (y32) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < D) {
+                *(f32x4*)(y32 + (size_t)row * D + c) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                *(f32x4*)(y32 + (size_t)row * D + c + 4) = f32x4{v[i][4], v[i][5], v[i][6], v[i][7]};
+            }
+        }
+    }
     if (lane == 0) {
         if (mean) mean[row] = mu;
         if (rstd) rstd[row] = rs;
@@ -203,13 +213,13 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs j
         else hipLaunchKernelGGL((NAME<8>), __VA_ARGS__);                \
     } while (0)
 
-extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                float* rstd, int rows, int D, float eps, mh_stream_t stream) {
+extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* y_f32,
+                                float* mean, float* rstd, int rows, int D, float eps, mh_stream_t stream) {
     if (!x || !gamma || !beta || !y) return MH_EINVAL;
     if (rows < 1 || D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    LN_DISPATCH(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean,
-                rstd, rows, D, eps);
+    LN_DISPATCH(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, y_f32,
+                mean, rstd, rows, D, eps);
     return mh_launch_status();
 }
 

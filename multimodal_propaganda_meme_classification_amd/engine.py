@@ -1,0 +1,440 @@
+"""Launch plan of one fine-tune step: which HIP kernels run, on which buffers, in which order.
+
+A ``Plan`` is built once per (batch, seq_len): every activation / gradient workspace is allocated
+up front (288 GB of HBM: nothing is recomputed, nothing is freed) and every kernel launch is
+recorded as a prepared C-ABI call.  Running a step is then a replay of prepared calls -- eagerly,
+or captured once into a hipGraph (model.GraphedStep) so the ~600 launches cost one host call.
+
+The two towers run in LOCKSTEP: layer l of the text encoder and layer l of the image encoder
+issue the same GEMM sequence, so each GEMM launch is a *grouped* launch carrying both towers'
+problems (and all eight weight-gradient GEMMs of a layer pair go out as one launch).  That is
+what fills 256 CUs with 128x128 tiles at these small N (768-wide projections give only 192-300
+tiles per tower).
+
+Reference for the math: BertModel / timm ViT as called at
+example_scripts/Multimodal_example_task2C.txt:175,183 and the step at :200-223.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhColsumJob, MhGemmProblem, MhHeadGrads, MhHeadParams
+from .config import Layout, ModelConfig
+
+BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
+LN_PARTS = 512
+
+
+class Segment:
+    """An ordered list of prepared launches."""
+
+    def __init__(self, name: str):
+        self.name = name
+        self.calls: List[Tuple] = []
+
+    def c(self, fn_name: str, *args):
+        self.calls.append((getattr(_lib.load(), fn_name), args, fn_name))
+
+    def py(self, fn: Callable[[], None]):
+        self.calls.append((None, fn, "py"))
+
+    def run(self, stream: int):
+        for fn, args, name in self.calls:
+            if fn is None:
+                args()
+            else:
+                st = fn(*args, stream)
+                if st != 0:
+                    _lib.check(st, name)
+
+    def __len__(self):
+        return len(self.calls)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class Plan:
+    def __init__(self, B: int, S: int):
+        self.B, self.S = B, S
+        self.buf: Dict[str, torch.Tensor] = {}
+        self.keep: list = []                  # ctypes arrays referenced by prepared calls
+        self.fwd = Segment("fwd")
+        self.loss = Segment("loss")
+        self.bwd: List[Segment] = []          # backward segments in execution order
+        self.bucket_after: Dict[str, Tuple[int, int]] = {}   # segment name -> flat grad range complete after it
+        self.n_launches = 0
+
+
+class Engine:
+    def __init__(self, cfg: ModelConfig, layout: Layout, P: torch.Tensor, G: torch.Tensor, SH: torch.Tensor):
+        self.cfg, self.layout = cfg, layout
+        self.P, self.G, self.SH = P, G, SH
+        self.dev = P.device
+        assert P.is_cuda and G.is_cuda and SH.is_cuda, "memehip needs HIP device buffers (no CPU fallback)"
+        self.plans: Dict[Tuple[int, int], Plan] = {}
+
+    # ---- parameter / gradient views -----------------------------------------------------------------
+    def _slice(self, flat: torch.Tensor, name: str, count: int = 1) -> torch.Tensor:
+        s = self.layout.spec[name]
+        return flat[s.offset:s.offset + s.numel * count]
+
+    def p(self, name, count=1):
+        return self._slice(self.P, name, count)
+
+    def g(self, name, count=1):
+        return self._slice(self.G, name, count)
+
+    def w(self, name, count=1):
+        s = self.layout.spec[name]
+        assert s.offset + s.numel * count <= self.layout.n_shadow, name
+        return self.SH[s.offset:s.offset + s.numel * count]
+
+    # ---- call builders ---------------------------------------------------------------------------------
+    def _gemm(self, plan: Plan, seg: Segment, probs: List[dict], a_k: bool, b_k: bool):
+        if not probs:
+            return
+        n = len(probs)
+        assert n <= _lib.MH_GEMM_MAX_GROUP
+        arr = (MhGemmProblem * n)()
+        for i, d in enumerate(probs):
+            A, Bm, Cm = d["A"], d["B"], d["C"]
+            M, N, K = d["M"], d["N"], d["K"]
+            lda, ldb, ldc = d["lda"], d["ldb"], d["ldc"]
+            assert A.dtype == BF16 and Bm.dtype == BF16 and Cm.dtype in (BF16, F32)
+            a_need = (K - 1) * lda + M if a_k else (M - 1) * lda + K
+            b_need = (K - 1) * ldb + N if b_k else (N - 1) * ldb + K
+            assert A.numel() >= a_need and Bm.numel() >= b_need and Cm.numel() >= (M - 1) * ldc + N, (M, N, K)
+            for key, dt, need in (("bias", F32, N), ("residual", BF16, (M - 1) * ldc + N), ("aux", BF16, (M - 1) * ldc + N),
+                                  ("mul", BF16, (M - 1) * ldc + N), ("rowsum", F32, M)):
+                t = d.get(key)
+                assert t is None or (t.dtype == dt and t.numel() >= need), key
+            e = arr[i]
+            e.A, e.B, e.C = _ptr(A), _ptr(Bm), _ptr(Cm)
+            e.bias, e.residual, e.aux = _ptr(d.get("bias")), _ptr(d.get("residual")), _ptr(d.get("aux"))
+            e.mul, e.rowsum = _ptr(d.get("mul")), _ptr(d.get("rowsum"))
+            e.M, e.N, e.K, e.lda, e.ldb, e.ldc = M, N, K, lda, ldb, ldc
+            e.flags = (MH_GEMM_GELU if d.get("gelu") else 0) | (MH_GEMM_OUT_F32 if Cm.dtype == F32 else 0) | \
+                      (MH_GEMM_ACCUM if d.get("accum") else 0)
+        plan.keep.append(arr)
+        seg.c("mh_gemm_bf16_grouped", arr, n, int(a_k), int(b_k))
+
+    @staticmethod
+    def _fwd_prob(x, w, out, T, N, K, **kw):
+        return dict(A=x, B=w, C=out, M=T, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
+
+    @staticmethod
+    def _dgrad_prob(dy, w, out, T, N_out, K_in, **kw):
+        # out[T, K_in] = dy[T, N_out] @ w[N_out, K_in]
+        return dict(A=dy, B=w, C=out, M=T, N=K_in, K=N_out, lda=N_out, ldb=K_in, ldc=K_in, **kw)
+
+    @staticmethod
+    def _wgrad_prob(dy, x, dw, db, T, N_out, K_in):
+        # dw[N_out, K_in] = dy[T, N_out]^T @ x[T, K_in]
+        return dict(A=dy, B=x, C=dw, M=N_out, N=K_in, K=T, lda=N_out, ldb=K_in, ldc=K_in, rowsum=db)
+
+    def _ln_fwd(self, seg, x, gname, bname, y, mean, rstd, rows, D, eps, y32=None):
+        seg.c("mh_layernorm_fwd", _ptr(x), _ptr(self.p(gname)), _ptr(self.p(bname)), _ptr(y), _ptr(y32), _ptr(mean),
+              _ptr(rstd), rows, D, float(eps))
+
+    def _ln_bwd(self, plan, seg, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None):
+        part = torch.empty((2, LN_PARTS, D), dtype=F32, device=self.dev)
+        plan.buf[f"lnpart.{gname}"] = part
+        seg.c("mh_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(self.p(gname)), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
+              _ptr(part), LN_PARTS, rows, D)
+        plan._ln_jobs.setdefault(D, []).append((part, self.g(gname), self.g(bname)))
+
+    # ---- plan ----------------------------------------------------------------------------------------------
+    def plan(self, B: int, S: int) -> Plan:
+        key = (B, S)
+        if key not in self.plans:
+            self.plans[key] = self._build(B, S)
+        return self.plans[key]
+
+    def _build(self, B: int, S: int) -> Plan:
+        cfg, t, v = self.cfg, self.cfg.text, self.cfg.image
+        if S > t.max_position:
+            raise ValueError(f"sequence length {S} > max_position {t.max_position}")
+        if B > 1024:
+            raise ValueError("batch > 1024 not supported by the loss kernel")
+        pl = Plan(B, S)
+        pl._ln_jobs = {}
+        dev = self.dev
+        Dt, It, Ht, Lt = t.hidden, t.intermediate, t.heads, t.layers
+        Di, Ii, Hi, Li = v.hidden, v.intermediate, v.heads, v.layers
+        Np, Nt = v.n_patches, v.n_tokens
+        Kp = v.channels * v.patch * v.patch
+        Tt, Ti = B * S, B * Nt
+        P_, Cn = cfg.proj, cfg.num_classes
+
+        def alloc(name, shape, dtype=BF16, zero=False):
+            tns = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=dev)
+            pl.buf[name] = tns
+            return tns
+
+        # static inputs
+        ids = alloc("ids", (B, S), I64, zero=True)
+        mask = alloc("mask", (B, S), I64, zero=True)
+        image = alloc("image", (B, v.channels, v.image_size, v.image_size), F32, zero=True)
+        labels = alloc("labels", (B,), I64, zero=True)
+        prev_ids = alloc("prev_ids", (B, S), I64, zero=True)
+
+        # ------------------------------------------------------------------ forward ------------------
+        f = pl.fwd
+        TXT, IMG = "bert.", "image_model."
+        # text embeddings
+        pre0 = alloc("t.pre0", (Tt, Dt))
+        xt = [alloc("t.x0", (Tt, Dt))]
+        m0, r0 = alloc("t.m0", (Tt,), F32), alloc("t.r0", (Tt,), F32)
+        type0 = self.p(TXT + "embeddings.token_type_embeddings.weight")[:Dt] if t.type_vocab > 0 else None
+        f.c("mh_bert_embed_fwd", _ptr(ids), _ptr(self.p(TXT + "embeddings.word_embeddings.weight")),
+            _ptr(self.p(TXT + "embeddings.position_embeddings.weight")), _ptr(type0),
+            _ptr(self.p(TXT + "embeddings.LayerNorm.weight")), _ptr(self.p(TXT + "embeddings.LayerNorm.bias")),
+            _ptr(pre0), _ptr(xt[0]), _ptr(m0), _ptr(r0), B, S, Dt, t.vocab_size, float(t.ln_eps))
+        # image embeddings
+        patches = alloc("i.patches", (B * Np, Kp))
+        proj = alloc("i.proj", (B * Np, Di))
+        xi = [alloc("i.x0", (Ti, Di))]
+        f.c("mh_patchify", _ptr(image), _ptr(patches), B, v.channels, v.image_size, v.image_size, v.patch)
+        wp = self.w(IMG + "embeddings.patch_embeddings.projection.weight")
+        self._gemm(pl, f, [self._fwd_prob(patches, wp, proj, B * Np, Di, Kp,
+                                          bias=self.p(IMG + "embeddings.patch_embeddings.projection.bias"))], False, False)
+        f.c("mh_vit_assemble_fwd", _ptr(proj), _ptr(self.p(IMG + "embeddings.cls_token")),
+            _ptr(self.p(IMG + "embeddings.position_embeddings")), _ptr(xi[0]), B, Np, Di)
+
+        xt_last32 = alloc("t.xlast32", (Tt, Dt), F32)   # unrounded tower outputs for the fp32 head
+        xf32 = alloc("i.xf32", (Ti, Di), F32)
+        tl: List[dict] = []   # per-layer saved activations, text
+        il: List[dict] = []
+        for l in range(max(Lt, Li)):
+            has_t, has_i = l < Lt, l < Li
+            LT, LI = f"{TXT}encoder.layer.{l}.", f"{IMG}encoder.layer.{l}."
+            if has_t:
+                a = dict(qkv=alloc(f"t{l}.qkv", (Tt, 3 * Dt)), ctx=alloc(f"t{l}.ctx", (Tt, Dt)),
+                         lse=alloc(f"t{l}.lse", (B, Ht, S), F32), a=alloc(f"t{l}.a", (Tt, Dt)),
+                         y=alloc(f"t{l}.y", (Tt, Dt)), m1=alloc(f"t{l}.m1", (Tt,), F32), r1=alloc(f"t{l}.r1", (Tt,), F32),
+                         h=alloc(f"t{l}.h", (Tt, It)), g=alloc(f"t{l}.g", (Tt, It)), f=alloc(f"t{l}.f", (Tt, Dt)),
+                         m2=alloc(f"t{l}.m2", (Tt,), F32), r2=alloc(f"t{l}.r2", (Tt,), F32))
+                tl.append(a)
+                xt.append(alloc(f"t.x{l + 1}", (Tt, Dt)))
+            if has_i:
+                b_ = dict(u=alloc(f"i{l}.u", (Ti, Di)), m1=alloc(f"i{l}.m1", (Ti,), F32), r1=alloc(f"i{l}.r1", (Ti,), F32),
+                          qkv=alloc(f"i{l}.qkv", (Ti, 3 * Di)), ctx=alloc(f"i{l}.ctx", (Ti, Di)),
+                          lse=alloc(f"i{l}.lse", (B, Hi, Nt), F32), xp=alloc(f"i{l}.xp", (Ti, Di)),
+                          w=alloc(f"i{l}.w", (Ti, Di)), m2=alloc(f"i{l}.m2", (Ti,), F32), r2=alloc(f"i{l}.r2", (Ti,), F32),
+                          h=alloc(f"i{l}.h", (Ti, Ii)), g=alloc(f"i{l}.g", (Ti, Ii)))
+                il.append(b_)
+                xi.append(alloc(f"i.x{l + 1}", (Ti, Di)))
+                self._ln_fwd(f, xi[l], LI + "layernorm_before.weight", LI + "layernorm_before.bias", b_["u"], b_["m1"],
+                             b_["r1"], Ti, Di, v.ln_eps)
+            # QKV
+            pr = []
+            if has_t:
+                pr.append(self._fwd_prob(xt[l], self.w(LT + "attention.self.query.weight", 3), a["qkv"], Tt, 3 * Dt, Dt,
+                                         bias=self.p(LT + "attention.self.query.bias", 3)))
+            if has_i:
+                pr.append(self._fwd_prob(b_["u"], self.w(LI + "attention.attention.query.weight", 3), b_["qkv"], Ti,
+                                         3 * Di, Di, bias=self.p(LI + "attention.attention.query.bias", 3)))
+            self._gemm(pl, f, pr, False, False)
+            if has_t:
+                f.c("mh_attn_fwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(a["lse"]), B, S, Ht)
+            if has_i:
+                f.c("mh_attn_fwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(b_["lse"]), B, Nt, Hi)
+            # attention output projection + residual
+            pr = []
+            if has_t:
+                pr.append(self._fwd_prob(a["ctx"], self.w(LT + "attention.output.dense.weight"), a["a"], Tt, Dt, Dt,
+                                         bias=self.p(LT + "attention.output.dense.bias"), residual=xt[l]))
+            if has_i:
+                pr.append(self._fwd_prob(b_["ctx"], self.w(LI + "attention.output.dense.weight"), b_["xp"], Ti, Di, Di,
+                                         bias=self.p(LI + "attention.output.dense.bias"), residual=xi[l]))
+            self._gemm(pl, f, pr, False, False)
+            if has_t:
+                self._ln_fwd(f, a["a"], LT + "attention.output.LayerNorm.weight", LT + "attention.output.LayerNorm.bias",
+                             a["y"], a["m1"], a["r1"], Tt, Dt, t.ln_eps)
+            if has_i:
+                self._ln_fwd(f, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["w"], b_["m2"],
+                             b_["r2"], Ti, Di, v.ln_eps)
+            # FFN up + GELU (pre-activation kept for the backward)
+            pr = []
+            if has_t:
+                pr.append(self._fwd_prob(a["y"], self.w(LT + "intermediate.dense.weight"), a["g"], Tt, It, Dt,
+                                         bias=self.p(LT + "intermediate.dense.bias"), aux=a["h"], gelu=True))
+            if has_i:
+                pr.append(self._fwd_prob(b_["w"], self.w(LI + "intermediate.dense.weight"), b_["g"], Ti, Ii, Di,
+                                         bias=self.p(LI + "intermediate.dense.bias"), aux=b_["h"], gelu=True))
+            self._gemm(pl, f, pr, False, False)
+            # FFN down + residual
+            pr = []
+            if has_t:
+                pr.append(self._fwd_prob(a["g"], self.w(LT + "output.dense.weight"), a["f"], Tt, Dt, It,
+                                         bias=self.p(LT + "output.dense.bias"), residual=a["y"]))
+            if has_i:
+                pr.append(self._fwd_prob(b_["g"], self.w(LI + "output.dense.weight"), xi[l + 1], Ti, Di, Ii,
+                                         bias=self.p(LI + "output.dense.bias"), residual=b_["xp"]))
+            self._gemm(pl, f, pr, False, False)
+            if has_t:
+                self._ln_fwd(f, a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", xt[l + 1], a["m2"],
+                             a["r2"], Tt, Dt, t.ln_eps, y32=xt_last32 if l == Lt - 1 else None)
+        # final ViT LayerNorm
+        xf = alloc("i.xf", (Ti, Di))
+        mf, rf = alloc("i.mf", (Ti,), F32), alloc("i.rf", (Ti,), F32)
+        self._ln_fwd(f, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", xf, mf, rf, Ti, Di, v.ln_eps, y32=xf32)
+
+        # head
+        pool_index = 0 if cfg.pool == "cls" else S - 1
+        hp, hg = MhHeadParams(), MhHeadGrads()
+        for fld, nm in (("Wt", "bert_fc.weight"), ("bt", "bert_fc.bias"), ("Wi", "image_fc.weight"),
+                        ("bi", "image_fc.bias"), ("Wf", "fusion_fc.weight"), ("bf_", "fusion_fc.bias"),
+                        ("Wo", "output_fc.weight"), ("bo", "output_fc.bias")):
+            setattr(hp, fld, _ptr(self.p(nm)))
+            setattr(hg, fld, _ptr(self.g(nm)))
+        pl.keep += [hp, hg]
+        pooled = alloc("h.pooled", (B, Dt + Di), F32)
+        feat, fused = alloc("h.feat", (B, 2 * P_), F32), alloc("h.fused", (B, P_), F32)
+        logits = alloc("logits", (B, Cn), F32)
+        f.c("mh_head_fwd", C.byref(hp), _ptr(xt_last32), _ptr(xf32), pool_index, _ptr(pooled), _ptr(feat), _ptr(fused),
+            _ptr(logits), B, S, Nt, Dt, Di, P_, Cn)
+
+        # loss
+        loss = alloc("loss", (1,), F32, zero=True)
+        dlogits = alloc("dlogits", (B, Cn), F32, zero=True)
+        ncorrect = alloc("ncorrect", (1,), torch.int32, zero=True)
+        grad_scale = 1.0
+        pl.loss.c("mh_ce_fwd_bwd", _ptr(logits), _ptr(labels), _ptr(loss), _ptr(dlogits), _ptr(ncorrect), B, Cn,
+                  float(grad_scale))
+
+        # ------------------------------------------------------------------ backward -----------------
+        def seg(name):
+            s = Segment(name)
+            pl.bwd.append(s)
+            return s
+
+        s = seg("bwd_head")
+        dXt = [alloc("t.dX0", (Tt, Dt)), alloc("t.dX1", (Tt, Dt))]
+        dXi = [alloc("i.dX0", (Ti, Di)), alloc("i.dX1", (Ti, Di))]
+        dXf = alloc("i.dXf", (Ti, Di))
+        dfeat, dfused = alloc("h.dfeat", (B, 2 * P_), F32), alloc("h.dfused", (B, P_), F32)
+        s.py(dXt[0].zero_)
+        s.py(dXf.zero_)
+        s.c("mh_head_bwd", C.byref(hp), C.byref(hg), _ptr(dlogits), _ptr(pooled), _ptr(feat), _ptr(fused), _ptr(dfeat),
+            _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn)
+        self._ln_bwd(pl, s, dXf, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", mf, rf, dXi[0], Ti, Di)
+
+        # shared backward temporaries
+        t_df, t_dh, t_dy = alloc("t.df", (Tt, Dt)), alloc("t.dh", (Tt, It)), alloc("t.dy", (Tt, Dt))
+        t_da, t_dctx, t_dqkv = alloc("t.da", (Tt, Dt)), alloc("t.dctx", (Tt, Dt)), alloc("t.dqkv", (Tt, 3 * Dt))
+        t_delta = alloc("t.delta", (B, Ht, S), F32)
+        i_dh, i_dw, i_dxp = alloc("i.dh", (Ti, Ii)), alloc("i.dw", (Ti, Di)), alloc("i.dxp", (Ti, Di))
+        i_dctx, i_dqkv, i_du = alloc("i.dctx", (Ti, Di)), alloc("i.dqkv", (Ti, 3 * Di)), alloc("i.du", (Ti, Di))
+        i_delta = alloc("i.delta", (B, Hi, Nt), F32)
+
+        ct, ci = 0, 0   # current ping-pong index of the incoming gradient
+        for l in range(max(Lt, Li) - 1, -1, -1):
+            has_t, has_i = l < Lt, l < Li
+            LT, LI = f"{TXT}encoder.layer.{l}.", f"{IMG}encoder.layer.{l}."
+            s = seg(f"bwd_layer_{l}")
+            a = tl[l] if has_t else None
+            b_ = il[l] if has_i else None
+            if has_t:   # through the output LayerNorm
+                self._ln_bwd(pl, s, dXt[ct], a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", a["m2"],
+                             a["r2"], t_df, Tt, Dt)
+            # d gelu_in = (d_out @ W2) * gelu'(h)
+            pr = []
+            if has_t:
+                pr.append(self._dgrad_prob(t_df, self.w(LT + "output.dense.weight"), t_dh, Tt, Dt, It, mul=a["h"]))
+            if has_i:
+                pr.append(self._dgrad_prob(dXi[ci], self.w(LI + "output.dense.weight"), i_dh, Ti, Di, Ii, mul=b_["h"]))
+            self._gemm(pl, s, pr, False, True)
+            # through W1 (text adds the residual branch df)
+            pr = []
+            if has_t:
+                pr.append(self._dgrad_prob(t_dh, self.w(LT + "intermediate.dense.weight"), t_dy, Tt, It, Dt, residual=t_df))
+            if has_i:
+                pr.append(self._dgrad_prob(i_dh, self.w(LI + "intermediate.dense.weight"), i_dw, Ti, Ii, Di))
+            self._gemm(pl, s, pr, False, True)
+            if has_t:
+                self._ln_bwd(pl, s, t_dy, a["a"], LT + "attention.output.LayerNorm.weight",
+                             LT + "attention.output.LayerNorm.bias", a["m1"], a["r1"], t_da, Tt, Dt)
+            if has_i:
+                self._ln_bwd(pl, s, i_dw, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["m2"],
+                             b_["r2"], i_dxp, Ti, Di, dx_add=dXi[ci])
+            # through the attention output projection
+            pr = []
+            if has_t:
+                pr.append(self._dgrad_prob(t_da, self.w(LT + "attention.output.dense.weight"), t_dctx, Tt, Dt, Dt))
+            if has_i:
+                pr.append(self._dgrad_prob(i_dxp, self.w(LI + "attention.output.dense.weight"), i_dctx, Ti, Di, Di))
+            self._gemm(pl, s, pr, False, True)
+            if has_t:
+                s.c("mh_attn_bwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(t_dctx), _ptr(a["lse"]), _ptr(t_delta),
+                    _ptr(t_dqkv), B, S, Ht)
+            if has_i:
+                s.c("mh_attn_bwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(i_dctx), _ptr(b_["lse"]), _ptr(i_delta),
+                    _ptr(i_dqkv), B, Nt, Hi)
+            # through the QKV projection
+            pr = []
+            if has_t:
+                pr.append(self._dgrad_prob(t_dqkv, self.w(LT + "attention.self.query.weight", 3), dXt[ct ^ 1], Tt, 3 * Dt, Dt,
+                                           residual=t_da))
+            if has_i:
+                pr.append(self._dgrad_prob(i_dqkv, self.w(LI + "attention.attention.query.weight", 3), i_du, Ti, 3 * Di, Di))
+            self._gemm(pl, s, pr, False, True)
+            if has_i:
+                self._ln_bwd(pl, s, i_du, xi[l], LI + "layernorm_before.weight", LI + "layernorm_before.bias", b_["m1"],
+                             b_["r1"], dXi[ci ^ 1], Ti, Di, dx_add=i_dxp)
+            # all weight gradients of the layer pair in one grouped launch (+ bias gradients as row sums)
+            pr = []
+            if has_t:
+                pr += [self._wgrad_prob(t_df, a["g"], self.g(LT + "output.dense.weight"), self.g(LT + "output.dense.bias"), Tt, Dt, It),
+                       self._wgrad_prob(t_dh, a["y"], self.g(LT + "intermediate.dense.weight"), self.g(LT + "intermediate.dense.bias"), Tt, It, Dt),
+                       self._wgrad_prob(t_da, a["ctx"], self.g(LT + "attention.output.dense.weight"), self.g(LT + "attention.output.dense.bias"), Tt, Dt, Dt),
+                       self._wgrad_prob(t_dqkv, xt[l], self.g(LT + "attention.self.query.weight", 3), self.g(LT + "attention.self.query.bias", 3), Tt, 3 * Dt, Dt)]
+            if has_i:
+                pr += [self._wgrad_prob(dXi[ci], b_["g"], self.g(LI + "output.dense.weight"), self.g(LI + "output.dense.bias"), Ti, Di, Ii),
+                       self._wgrad_prob(i_dh, b_["w"], self.g(LI + "intermediate.dense.weight"), self.g(LI + "intermediate.dense.bias"), Ti, Ii, Di),
+                       self._wgrad_prob(i_dxp, b_["ctx"], self.g(LI + "attention.output.dense.weight"), self.g(LI + "attention.output.dense.bias"), Ti, Di, Di),
+                       self._wgrad_prob(i_dqkv, b_["u"], self.g(LI + "attention.attention.query.weight", 3), self.g(LI + "attention.attention.query.bias", 3), Ti, 3 * Di, Di)]
+            self._gemm(pl, s, pr, True, True)
+            if has_t:
+                ct ^= 1
+            if has_i:
+                ci ^= 1
+            rng = [r for r in self.layout.layer_ranges if r[0] == l][0]
+            pl.bucket_after[s.name] = (rng[1], rng[2])
+
+        # embeddings
+        s = seg("bwd_embed")
+        t_dpre = alloc("t.dpre", (Tt, Dt))
+        self._ln_bwd(pl, s, dXt[ct], pre0, TXT + "embeddings.LayerNorm.weight", TXT + "embeddings.LayerNorm.bias", m0, r0,
+                     t_dpre, Tt, Dt)
+        gword = self.g(TXT + "embeddings.word_embeddings.weight")
+        # dense-Adam semantics: the table gradient is dense; only rows touched last step need re-zeroing
+        s.c("mh_zero_rows_f32", _ptr(prev_ids), _ptr(gword), Tt, Dt, t.vocab_size)
+        gtype0 = self.g(TXT + "embeddings.token_type_embeddings.weight")[:Dt] if t.type_vocab > 0 else None
+        s.c("mh_bert_embed_bwd", _ptr(ids), _ptr(t_dpre), _ptr(gword), _ptr(self.g(TXT + "embeddings.position_embeddings.weight")),
+            _ptr(gtype0), B, S, Dt, t.vocab_size, int(t.pad_token_id))
+        s.py(lambda: prev_ids.copy_(ids))
+        i_dproj = alloc("i.dproj", (B * Np, Di))
+        s.c("mh_vit_assemble_bwd", _ptr(dXi[ci]), _ptr(i_dproj), _ptr(self.g(IMG + "embeddings.cls_token")),
+            _ptr(self.g(IMG + "embeddings.position_embeddings")), B, Np, Di)
+        self._gemm(pl, s, [self._wgrad_prob(i_dproj, patches, self.g(IMG + "embeddings.patch_embeddings.projection.weight"),
+                                            self.g(IMG + "embeddings.patch_embeddings.projection.bias"), B * Np, Di, Kp)],
+                   True, True)
+        # finish every LayerNorm's dgamma / dbeta from the partials
+        for D, jobs in pl._ln_jobs.items():
+            for i0 in range(0, len(jobs), _lib.MH_COLSUM_MAX_JOBS):
+                chunk = jobs[i0:i0 + _lib.MH_COLSUM_MAX_JOBS]
+                arr = (MhColsumJob * len(chunk))()
+                for j, (part, o0, o1) in enumerate(chunk):
+                    arr[j].part, arr[j].out0, arr[j].out1 = _ptr(part), _ptr(o0), _ptr(o1)
+                pl.keep.append(arr)
+                s.c("mh_colsum_partials_f32", arr, len(chunk), LN_PARTS, D)
+        pl.bucket_after[s.name] = (self.layout.layer_ranges[-1][2], self.layout.n_total)
+        pl.n_launches = len(pl.fwd) + len(pl.loss) + sum(len(x) for x in pl.bwd)
+        return pl

@@ -1,0 +1,426 @@
+"""MultimodalClassifier / Adam / CrossEntropyLoss: the reference's Python surface over the HIP path.
+
+Mirrors example_scripts/Multimodal_example_task2C.txt:
+  * ``MultimodalClassifier(num_classes)`` with ``forward(text, image, mask) -> logits`` (:152-197,
+    positional order text, image, mask), ``.to() / .train() / .eval() / .parameters() /
+    .state_dict()``;
+  * ``criterion = CrossEntropyLoss()`` (:248) and ``optimizer = Adam(model.parameters(), lr=2e-5)``
+    (:249) with ``zero_grad() / step()``, used exactly as the reference loop does (:205-217):
+    ``output = model(text, image, mask); loss = criterion(output, labels); loss.backward();
+    optimizer.step()``.
+Pooling: ``pool="last"`` is the organizers' ``[:, -1, :]`` (:178); ``pool="cls"`` is
+Multimodal_example_task2C.py:359-360.  Unknown pooling raises ValueError like ...task2C.py:352.
+
+Everything numeric runs in libmemehip.so on the current HIP stream.  ``torch.autograd`` only sees
+two opaque nodes (the model, the loss); parameters are fp32 views of one flat buffer, gradients
+fp32 views of a second one, GEMM operands a bf16 shadow of the matrix prefix.
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .config import Layout, ModelConfig, TextConfig, ImageConfig  # noqa: F401
+from .engine import Engine, Plan
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+# flat-parameter storage address -> owning model (lets Adam(model.parameters()) find the bf16 shadow)
+_REGISTRY: "weakref.WeakValueDictionary[int, MultimodalClassifier]" = weakref.WeakValueDictionary()
+
+
+class _Node(nn.Module):
+    """Name-space container so state_dict() keys equal the transformers / reference names."""
+
+
+def _register(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    node.register_parameter(parts[-1], param)
+
+
+class _ModelFn(torch.autograd.Function):
+    """Opaque autograd node: forward = Plan.fwd, backward = the backward segments."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, plan):
+        ctx.model, ctx.plan = model, plan
+        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        return plan.buf["logits"].clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, plan = ctx.model, ctx.plan
+        plan.buf["dlogits"].copy_(dlogits.to(F32))
+        model._run_backward(plan)
+        return None, None, None
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, crit):
+        B, Cn = logits.shape
+        w = crit._workspace(logits.device, B, Cn)
+        ops.ce_fwd_bwd(logits.contiguous(), labels, w["loss"], w["dlogits"], w["ncorrect"])
+        ctx.dl = w["dlogits"]
+        return w["loss"][0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ctx.dl * gout, None, None
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() stand-in (mean reduction) running the fused HIP loss kernel; also
+    exposes ``last_correct`` = #argmax==label of the last call (the reference computes it with
+    torch.max, ...task2C.txt:219-220)."""
+
+    def __init__(self):
+        super().__init__()
+        self._ws: Dict = {}
+
+    def _workspace(self, device, B, Cn):
+        key = (str(device), B, Cn)
+        if key not in self._ws:
+            self._ws[key] = dict(loss=torch.zeros(1, device=device), dlogits=torch.zeros((B, Cn), device=device),
+                                 ncorrect=torch.zeros(1, dtype=torch.int32, device=device))
+        self._last = self._ws[key]
+        return self._ws[key]
+
+    @property
+    def last_correct(self) -> torch.Tensor:
+        return self._last["ncorrect"]
+
+    def forward(self, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        if not logits.is_cuda:
+            raise _lib.MemehipError("CrossEntropyLoss: logits must be on the HIP device (no CPU fallback)")
+        return _LossFn.apply(logits, labels, self)
+
+
+class MultimodalClassifier(nn.Module):
+    """Dual-encoder late-fusion classifier (BERT-family text tower + ViT image tower)."""
+
+    def __init__(self, num_classes: int = 2, config: Optional[ModelConfig] = None, device="cpu", seed: int = 0,
+                 init: bool = True):
+        super().__init__()
+        cfg = config if config is not None else ModelConfig(num_classes=num_classes)
+        if config is None:
+            cfg.num_classes = num_classes
+        cfg.validate()
+        self.config = cfg
+        self.layout = Layout(cfg)
+        n = self.layout.n_total
+        self._P = torch.zeros(n, dtype=F32, device=device)
+        self._G = torch.zeros(n, dtype=F32, device=device)
+        self._SH = torch.zeros(self.layout.n_shadow, dtype=BF16, device=device)
+        self._names = self.layout.state_dict_order()
+        self._params: Dict[str, nn.Parameter] = {}
+        for name in self._names:
+            s = self.layout.spec[name]
+            prm = nn.Parameter(self._P[s.offset:s.offset + s.numel].view(s.shape), requires_grad=True)
+            self._params[name] = prm
+            _register(self, name, prm)
+        self._engine: Optional[Engine] = None
+        self._shadow_stale = True
+        if init:
+            self.reset_parameters(seed)
+        self._attach_grads()
+        _REGISTRY[self._P.untyped_storage().data_ptr()] = self
+
+    # ---- construction helpers -------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config: ModelConfig, device="cpu", seed: int = 0, init: bool = True):
+        return cls(config.num_classes, config=config, device=device, seed=seed, init=init)
+
+    def reset_parameters(self, seed: int = 0):
+        """Random init with the towers' initializer_range 0.02 (no checkpoints offline) and
+        nn.Linear defaults for the head."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        with torch.no_grad():
+            for s in self.layout.specs:
+                kind = s.init
+                if kind == "normal":
+                    val = torch.randn(s.numel, generator=g) * 0.02
+                elif kind == "ones":
+                    val = torch.ones(s.numel)
+                elif kind == "zeros":
+                    val = torch.zeros(s.numel)
+                else:
+                    bound = 1.0 / math.sqrt(int(kind.split(":")[1]))
+                    val = (torch.rand(s.numel, generator=g) * 2 - 1) * bound
+                self._P[s.offset:s.offset + s.numel].copy_(val)
+        self._shadow_stale = True
+
+    def _attach_grads(self):
+        for name, prm in self._params.items():
+            s = self.layout.spec[name]
+            prm.grad = self._G[s.offset:s.offset + s.numel].view(s.shape)
+
+    # ---- nn.Module protocol ---------------------------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        new_p = fn(self._P)
+        if new_p.dtype != F32:
+            raise TypeError("MultimodalClassifier keeps fp32 master parameters; bf16 compute is internal")
+        if new_p.device != self._P.device or new_p.data_ptr() != self._P.data_ptr():
+            self._P = new_p
+            self._G = fn(self._G)
+            self._SH = torch.zeros(self.layout.n_shadow, dtype=BF16, device=new_p.device)
+            for name, prm in self._params.items():
+                s = self.layout.spec[name]
+                prm.data = self._P[s.offset:s.offset + s.numel].view(s.shape)
+            self._attach_grads()
+            self._engine = None
+            self._shadow_stale = True
+            _REGISTRY[self._P.untyped_storage().data_ptr()] = self
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = {("image_fc" + k[len("resnet_fc"):] if k.startswith("resnet_fc") else k): v for k, v in state_dict.items()}
+        missing = [k for k in self._names if k not in sd]
+        unexpected = [k for k in sd if k not in self._params]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:4]} unexpected {unexpected[:4]}")
+        with torch.no_grad():
+            for k, val in sd.items():
+                if k in self._params:
+                    if tuple(val.shape) != tuple(self._params[k].shape):
+                        raise RuntimeError(f"size mismatch for {k}: {tuple(val.shape)} vs {tuple(self._params[k].shape)}")
+                    self._params[k].data.copy_(val.to(F32))
+        self._shadow_stale = True
+        return nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # ---- engine ------------------------------------------------------------------------------------------------
+    def _get_engine(self) -> Engine:
+        if not self._P.is_cuda:
+            raise _lib.MemehipError("MultimodalClassifier runs only on a HIP device: call .to('cuda') first "
+                                    "(libmemehip has no CPU fallback)")
+        if self._engine is None:
+            self._engine = Engine(self.config, self.layout, self._P, self._G, self._SH)
+        return self._engine
+
+    def refresh_shadow(self):
+        """bf16 copy of the GEMM matrices (kept in sync by Adam.step(); call after editing weights by hand)."""
+        self._get_engine()
+        ops.cast_f32_bf16(self._P[:self.layout.n_shadow], self._SH)
+        self._shadow_stale = False
+
+    def mark_weights_changed(self):
+        self._shadow_stale = True
+
+    def _prepare(self, text, image, mask, labels=None) -> Plan:
+        eng = self._get_engine()
+        if text.dim() != 2 or mask.shape != text.shape:
+            raise ValueError("text and mask must be [B, S] int64 tensors of the same shape")
+        B, S = text.shape
+        v = self.config.image
+        if tuple(image.shape) != (B, v.channels, v.image_size, v.image_size):
+            raise ValueError(f"image must be [B,{v.channels},{v.image_size},{v.image_size}], got {tuple(image.shape)}")
+        plan = eng.plan(B, S)
+        if self._shadow_stale:
+            self.refresh_shadow()
+        plan.buf["ids"].copy_(text.to(torch.int64), non_blocking=True)
+        plan.buf["mask"].copy_(mask.to(torch.int64), non_blocking=True)
+        plan.buf["image"].copy_(image.to(F32), non_blocking=True)
+        if labels is not None:
+            plan.buf["labels"].copy_(labels.to(torch.int64), non_blocking=True)
+        return plan
+
+    def _run_backward(self, plan: Plan, hook=None):
+        stream = torch.cuda.current_stream().cuda_stream
+        for seg in plan.bwd:
+            seg.run(stream)
+            if hook is not None:
+                hook(seg.name, plan.bucket_after.get(seg.name))
+        self._attach_grads()
+
+    def forward(self, text: torch.Tensor, image: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        plan = self._prepare(text, image, mask)
+        if torch.is_grad_enabled() and self.training:
+            anchor = self._params[self._names[0]]
+            return _ModelFn.apply(anchor, self, plan)
+        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        return plan.buf["logits"].clone()
+
+    # ---- fused step (no autograd): forward + loss + backward ---------------------------------------------------
+    def forward_backward(self, text, image, mask, labels, grad_hook=None):
+        """Returns (loss[1], n_correct[1], logits[B,C]) device tensors; gradients land in .grad."""
+        plan = self._prepare(text, image, mask, labels)
+        stream = torch.cuda.current_stream().cuda_stream
+        plan.fwd.run(stream)
+        plan.loss.run(stream)
+        self._run_backward(plan, grad_hook)
+        return plan.buf["loss"], plan.buf["ncorrect"], plan.buf["logits"]
+
+    @property
+    def flat_params(self):
+        return self._P
+
+    @property
+    def flat_grads(self):
+        return self._G
+
+    @property
+    def flat_shadow(self):
+        return self._SH
+
+
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam / AdamW semantics over the model's flat buffers in ONE fused HIP launch
+    (dense over all parameters, as the reference's optim.Adam is).  ``max_grad_norm`` adds the
+    HF-Trainer clip (DistilBERT_example_task2A.ipynb:3280) fused into the same launch."""
+
+    def __init__(self, params: Iterable[nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, decoupled_weight_decay: bool = False, max_grad_norm: Optional[float] = None,
+                 model: Optional[MultimodalClassifier] = None):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("the fused Adam takes one parameter group (all of model.parameters())")
+        self.decoupled = decoupled_weight_decay
+        self.max_grad_norm = max_grad_norm
+        self._model = model
+        self._flat = None
+        self._step = 0
+        self.grad_scale = 1.0          # DDP sets 1/world_size (all-reduce sums)
+
+    def _bind(self):
+        if self._flat is not None:
+            return
+        ps = self.param_groups[0]["params"]
+        base = min(ps, key=lambda p: p.data_ptr())
+        storage = base.untyped_storage()
+        n = storage.nbytes() // 4
+        P = torch.empty(0, dtype=F32, device=base.device).set_(storage, 0, (n,), (1,))
+        if not P.is_cuda:
+            raise _lib.MemehipError("Adam: parameters must live on the HIP device (no CPU fallback)")
+        for p in ps:
+            if p.untyped_storage().data_ptr() != storage.data_ptr():
+                raise ValueError("the fused Adam needs the parameters of ONE MultimodalClassifier (one flat buffer)")
+        g0 = base.grad
+        if g0 is None:
+            raise RuntimeError("Adam.step() before any backward")
+        gs = g0.untyped_storage()
+        G = torch.empty(0, dtype=F32, device=base.device).set_(gs, 0, (n,), (1,))
+        if self._model is None:
+            self._model = _REGISTRY.get(storage.data_ptr())
+        dev = base.device
+        self._flat = dict(P=P, G=G, M=torch.zeros(n, device=dev), V=torch.zeros(n, device=dev),
+                          hyper=torch.zeros(8, device=dev), ws=torch.zeros(1024, device=dev),
+                          nrm=torch.zeros(1, device=dev),
+                          ring=[torch.zeros(8, dtype=F32).pin_memory() for _ in range(32)])
+
+    def zero_grad(self, set_to_none: bool = False):
+        # every gradient is overwritten by the next backward (the embedding table re-zeroes the rows
+        # it touched), so there is nothing to clear; the views stay attached.
+        return None
+
+    def _write_hyper(self):
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        t = self._step
+        host = self._flat["ring"][t % 32]
+        host.copy_(torch.tensor([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1.0 / (1.0 - b1 ** t),
+                                 1.0 / math.sqrt(1.0 - b2 ** t), self.grad_scale], dtype=F32))
+        self._flat["hyper"].copy_(host, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._bind()
+        self._step += 1
+        self._write_hyper()
+        self.launch()
+
+    def launch(self):
+        """Enqueue grad-norm (if clipping) + the fused update; reads hyper-parameters from device memory."""
+        f = self._flat
+        model = self._model
+        shadow, n_shadow = (model.flat_shadow, model.layout.n_shadow) if model is not None else (None, 0)
+        nrm = None
+        if self.max_grad_norm is not None:
+            ops.sumsq(f["G"], f["ws"], f["nrm"])
+            nrm = f["nrm"]
+        ops.adam_step(f["P"], f["M"], f["V"], f["G"], shadow, n_shadow, f["hyper"], self.decoupled, nrm,
+                      float(self.max_grad_norm or 0.0))
+        if model is not None:
+            model._shadow_stale = False
+
+    def state_dict(self):
+        self._bind()
+        return dict(step=self._step, exp_avg=self._flat["M"], exp_avg_sq=self._flat["V"],
+                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+
+class GraphedStep:
+    """Whole fine-tune step (forward, loss, backward, clip, Adam) captured once into a hipGraph and
+    replayed per batch: the ~600 kernel launches of a step cost one host call."""
+
+    def __init__(self, model: MultimodalClassifier, optimizer: Adam, batch: int, seq_len: int, use_graph: bool = True):
+        self.model, self.opt = model, optimizer
+        optimizer._model = model
+        eng = model._get_engine()
+        self.plan = eng.plan(batch, seq_len)
+        if model._shadow_stale:
+            model.refresh_shadow()
+        self.graph = None
+        self.use_graph = use_graph
+        self._captured = False
+
+    def _body(self):
+        stream = torch.cuda.current_stream().cuda_stream
+        self.plan.fwd.run(stream)
+        self.plan.loss.run(stream)
+        for seg in self.plan.bwd:
+            seg.run(stream)
+        self.opt.launch()
+
+    def load_batch(self, text, image, mask, labels):
+        b = self.plan.buf
+        b["ids"].copy_(text, non_blocking=True)
+        b["mask"].copy_(mask, non_blocking=True)
+        b["image"].copy_(image, non_blocking=True)
+        b["labels"].copy_(labels, non_blocking=True)
+
+    def step(self):
+        """One step on the batch currently in the static input buffers. Returns (loss, n_correct) device tensors."""
+        opt = self.opt
+        if opt._flat is None:
+            self.model._attach_grads()
+            opt._bind()
+        opt._step += 1
+        opt._write_hyper()
+        if not self.use_graph:
+            self._body()
+        else:
+            if not self._captured:
+                self._capture()
+            self.graph.replay()
+        return self.plan.buf["loss"], self.plan.buf["ncorrect"]
+
+    def _capture(self):
+        # one warm-up run on a side stream (lazy module loads, workspace allocation), undone afterwards so
+        # it does not count as a training step; then capture the same launches into a graph
+        f = self.opt._flat
+        snap = (f["P"].clone(), f["M"].clone(), f["V"].clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        f["P"].copy_(snap[0]); f["M"].copy_(snap[1]); f["V"].copy_(snap[2])
+        self.model.refresh_shadow()
+        # (the warm-up left prev_ids == ids, so the first real step re-zeroes exactly the embedding-gradient
+        #  rows the warm-up wrote)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        self._captured = True

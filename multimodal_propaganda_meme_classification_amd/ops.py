@@ -123,14 +123,17 @@ def linear_wgrad(dy, x, dw, dbias=None, accum=False):
 # LayerNorm
 # ---------------------------------------------------------------------------------------------
 
-def layernorm_fwd(x, gamma, beta, eps, y=None, mean=None, rstd=None):
+def layernorm_fwd(x, gamma, beta, eps, y=None, mean=None, rstd=None, y_f32=None):
     _chk(x, BF16, "x"), _chk(gamma, F32, "gamma"), _chk(beta, F32, "beta")
     rows, D = x.shape
     y = torch.empty_like(x) if y is None else _chk(y, BF16, "y")
     mean = torch.empty(rows, dtype=F32, device=x.device) if mean is None else mean
     rstd = torch.empty(rows, dtype=F32, device=x.device) if rstd is None else rstd
-    check(_lib.load().mh_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, float(eps),
-                                       _stream()), "mh_layernorm_fwd")
+    if y_f32 is not None:
+        _chk(y_f32, F32, "y_f32")
+        assert y_f32.numel() >= rows * D
+    check(_lib.load().mh_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(y_f32), _p(mean), _p(rstd), rows, D,
+                                       float(eps), _stream()), "mh_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -256,7 +259,7 @@ def _head_struct(cls, tensors):
 
 def head_fwd(params, text_hidden, image_hidden, pool_index, pooled, feat, fused, logits, B, S, Nt, Dt, Di, P, Cn):
     hp = _head_struct(MhHeadParams, params)
-    _chk(text_hidden, BF16, "text_hidden"), _chk(image_hidden, BF16, "image_hidden")
+    _chk(text_hidden, F32, "text_hidden"), _chk(image_hidden, F32, "image_hidden")
     assert text_hidden.numel() >= B * S * Dt and image_hidden.numel() >= B * Nt * Di
     assert pooled.numel() >= B * (Dt + Di) and feat.numel() >= B * 2 * P and fused.numel() >= B * P and logits.numel() >= B * Cn
     assert params[0].numel() == P * Dt and params[2].numel() == P * Di and params[4].numel() == P * 2 * P and params[6].numel() == Cn * P

@@ -133,11 +133,13 @@ def test_layernorm_fwd_bwd(ops, rows, D, eps):
     x = rnd(rows, D, seed=1)
     g = (1 + 0.1 * torch.randn(D)).to(dev())
     b = (0.1 * torch.randn(D)).to(dev())
-    y, mean, rstd = ops.layernorm_fwd(x, g, b, eps)
+    y32 = torch.empty((rows, D), device=dev())
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, eps, y_f32=y32)
     xf = x.float().requires_grad_(True)
     gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
     ref = torch.nn.functional.layer_norm(xf, (D,), gf, bf, eps)
     close(y, ref, 8e-3, 8e-3, "ln fwd")
+    close(y32, ref, 1e-5, 1e-5, "ln fwd (unrounded copy)")
     close(mean, xf.mean(1), 1e-5, 1e-5, "ln mean")
     dy = rnd(rows, D, seed=2)
     add = rnd(rows, D, seed=3)
@@ -284,7 +286,7 @@ def test_head_ce_fwd_bwd(ops, B, pool):
     pooled = torch.empty((B, Dt + Di), device=dev())
     feat, fused = torch.empty((B, 2 * P), device=dev()), torch.empty((B, P), device=dev())
     logits = torch.empty((B, Cn), device=dev())
-    ops.head_fwd(params, th, ih, pool, pooled, feat, fused, logits, B, S, Nt, Dt, Di, P, Cn)
+    ops.head_fwd(params, th.float(), ih.float(), pool, pooled, feat, fused, logits, B, S, Nt, Dt, Di, P, Cn)
     labels = torch.randint(0, Cn, (B,), generator=g).to(dev())
     loss = torch.empty(1, device=dev())
     dlogits = torch.empty_like(logits)

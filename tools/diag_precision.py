@@ -1,0 +1,45 @@
+"""Diagnostic (GPU box): print HIP-vs-oracle errors for the tiny and config-3 models."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import multimodal_propaganda_meme_classification_amd as pkg
+from oracle import meme_oracle as O
+
+
+def run(name, cfg, B, S, seed):
+    params = O.init_params(cfg, seed)
+    model = pkg.MultimodalClassifier.from_config(pkg.ModelConfig.from_dict(cfg.to_dict()), init=False)
+    model.load_state_dict(params)
+    model.to("cuda")
+    text, image, mask, labels = O.synthetic_batch(cfg, B, S, seed=seed + 100)
+    t0 = time.time()
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(params, text, image, mask, labels, cfg)
+    t1 = time.time()
+    loss, ncorr, logits = model.forward_backward(text.cuda(), image.cuda(), mask.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    got = logits.float().cpu()
+    print(f"[{name}] oracle {t1 - t0:.1f}s  logits max err {float((got - ref_logits).abs().max()):.3e} "
+          f"(|logit| max {float(ref_logits.abs().max()):.3f})  loss {float(loss):.6f} vs {float(ref_loss):.6f}")
+    # autocast(bf16) version of the oracle, for scale
+    with torch.autocast("cpu", dtype=torch.bfloat16), torch.no_grad():
+        ac = O.forward(params, text, image, mask, cfg).float()
+    print(f"[{name}] torch CPU bf16-autocast oracle vs fp32 oracle: {float((ac - ref_logits).abs().max()):.3e}")
+    errs = []
+    for n, p in model.named_parameters():
+        r = ref_grads[n]
+        g = p.grad.float().cpu()
+        errs.append((float((g - r).norm()) / (float(r.norm()) + 1e-12), n, float(r.norm())))
+    errs.sort(reverse=True)
+    for e, n, rn in errs[:8]:
+        print(f"    grad rel err {e:.3e}  |ref|={rn:.3e}  {n}")
+    import statistics
+    print(f"    median rel err {statistics.median(e for e, _, _ in errs):.3e}")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(16)
+    run("tiny", O.tiny_config("cls"), 4, 16, 1)
+    run("tiny-last", O.tiny_config("last"), 4, 16, 2)
+    if "--full" in sys.argv:
+        run("config3", O.config3("cls"), 2, 128, 3)
+        run("config3-b4", O.config3("cls"), 4, 128, 4)
