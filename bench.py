@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Headline benchmark: memes/sec of one full fine-tune step (forward + cross-entropy + backward +
+Adam) of the Subtask-2C dual encoder, ViT-B/16 + BERT-base(V=64000), 224x224 + 128 tokens, batch 32
+per GPU (BASELINE.json configs[2]; configs[3] = the same per-GPU work on N GPUs, weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Inputs are synthetic and already resident in HBM when the timed
+region starts; a "step" is one pass of the hot path over one batch.
+`roofline` prices the dominant kernel (the grouped bf16 MFMA GEMM with the largest share of the
+step) from HIP events recorded around each of its launches on the launch stream, in an
+instrumented eager replay of the same prepared launches right after the timed region.
+`cpu_baseline` times the CPU oracle (oracle/meme_oracle.py, a port -- the reference itself cannot
+run here) on a bounded sample of the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_MEME = 172.42e9          # fwd+bwd algorithmic FLOPs per meme, config 3
+MFMA_PEAK_TFLOPS = 2500.0         # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="memes per GPU")
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--tiny", action="store_true", help="tiny model (debug only; not a bench line)")
+    return ap.parse_args()
+
+
+def synthetic_batch(cfg, batch, seq, seed, device):
+    """image ~ N(0,1); ids ~ U{5..V-1}, id[:,0] = CLS-like, PAD 0; ragged masks."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ic = cfg.image
+    image = torch.randn((batch, ic.channels, ic.image_size, ic.image_size), generator=g)
+    text = torch.randint(5, cfg.text.vocab_size, (batch, seq), generator=g, dtype=torch.int64)
+    lens = torch.randint(min(8, seq), seq + 1, (batch,), generator=g)
+    mask = (torch.arange(seq)[None] < lens[:, None]).to(torch.int64)
+    text = text * mask
+    text[:, 0] = 2
+    labels = (torch.rand((batch,), generator=g) < 0.28).to(torch.int64)
+    return [t.to(device) for t in (text, image, mask, labels)]
+
+
+def cpu_baseline(batch, seq, tiny):
+    """Oracle fine-tune step (fp32, eager PyTorch CPU, dropout 0) on a bounded sample."""
+    from oracle import meme_oracle as O
+    cfg = O.tiny_config("cls") if tiny else O.config3("cls")
+    threads = torch.get_num_threads()
+    params = O.init_params(cfg, seed=0)
+    text, image, mask, labels = O.synthetic_batch(cfg, batch, seq, seed=1234)
+    st = O.AdamState()
+    params, *_ = O.train_step(params, st, text, image, mask, labels, cfg, lr=2e-5)      # warm-up
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        params, *_ = O.train_step(params, st, text, image, mask, labels, cfg, lr=2e-5)
+        times.append(time.perf_counter() - t0)
+    t = min(times)
+    return {"value": round(batch / t, 3), "unit": "memes/s", "cores": threads, "kind": "port",
+            "sample": f"oracle train_step (fwd+CE+bwd+Adam, fp32) at batch {batch}, seq {seq}: 1 warm-up + 2 timed steps, "
+                      f"best {t:.2f} s/step on {threads} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import multimodal_propaganda_meme_classification_amd as pkg
+    from multimodal_propaganda_meme_classification_amd import ddp
+
+    if args.tiny:
+        cfg = pkg.ModelConfig(text=pkg.TextConfig(vocab_size=512, hidden=128, layers=2, heads=2, intermediate=256, max_position=64),
+                              image=pkg.ImageConfig(image_size=32, hidden=128, layers=2, heads=2, intermediate=256), proj=128)
+    else:
+        cfg = pkg.ModelConfig()            # config 3
+    model = pkg.MultimodalClassifier.from_config(cfg, device=device, seed=0)
+    model.train()
+    reducer = None
+    if world > 1:
+        ddp.broadcast_parameters(model.flat_params)
+        model.mark_weights_changed()
+        reducer = ddp.GradientReducer(model.flat_grads)
+    opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)
+    step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer)
+    if reducer is not None:
+        ddp.check_bucket_cover(step.plan.bucket_after, model.layout.n_total)
+    batch = synthetic_batch(cfg, args.batch, args.seq, seed=1234 + rank, device=device)
+    step.load_batch(*batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):       # >= 1: the first call captures the graph(s)
+        step.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: instrumented eager replay on the launch stream -------
+        plan = step.plan
+        stream = torch.cuda.current_stream().cuda_stream
+        tags = ("gemm<0,0>", "gemm<0,1>", "gemm<1,1>")
+        per_tag = {}
+        for tag in tags:
+            recs = []
+            for _ in range(3):
+                plan.fwd.run_timed(stream, tag, recs)
+                plan.loss.run(stream)
+                for seg in plan.bwd:
+                    seg.run_timed(stream, tag, recs)
+            torch.cuda.synchronize()
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in recs]
+            per_tag[tag] = dict(launches=len(recs) // 3, total_ms=sum(ms) / 3, flops=sum(w for _, _, w in recs) / 3)
+        dom = max(per_tag, key=lambda k: per_tag[k]["total_ms"])
+        d = per_tag[dom]
+        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        flop_per_meme = FLOP_PER_MEME if not args.tiny else plan.gemm_flops / args.batch
+        out = {
+            "metric": "memes/sec (fine-tune step) ViT-B/16+BERT-base bs=32, 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "memes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Subtask-2C fine-tune step: ViT-B/16 (224x224, 197 tokens) + BERT-base (V=64000, "
+                                   f"S={args.seq}) late-fusion, fwd+CE+bwd+Adam, batch {args.batch}/GPU, random-init weights"
+                                   + (" [TINY DEBUG MODEL]" if args.tiny else ""),
+                       "global_batch": args.batch * world, "seq_len": args.seq, "image": "3x224x224",
+                       "params": model.layout.n_total, "parallelism": f"dp{world}",
+                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph per backward segment + RCCL all-reduce"),
+                       "kernel_launches_per_step": plan.n_launches, "final_loss": round(final_loss, 5)},
+            "roofline": {"bound": "mfma", "kernel": f"gemm_kernel{dom[4:]} (grouped bf16 MFMA GEMM)",
+                         "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": d["launches"], "avg_launch_us": round(d["total_ms"] / d["launches"] * 1e3, 2),
+                         "flops_per_launch": round(d["flops"] / d["launches"]),
+                         "all_gemm_kernels": {k: {"ms_per_step": round(v["total_ms"], 3),
+                                                  "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1)}
+                                              for k, v in per_tag.items()},
+                         "step_mfma_frac": round(flop_per_meme * value / world / (MFMA_PEAK_TFLOPS * 1e12), 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.seq, args.tiny)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,20 +36,38 @@ class Segment:
         self.name = name
         self.calls: List[Tuple] = []
 
-    def c(self, fn_name: str, *args):
-        self.calls.append((getattr(_lib.load(), fn_name), args, fn_name))
+    def c(self, fn_name: str, *args, tag: Optional[str] = None, work: float = 0.0):
+        self.calls.append((getattr(_lib.load(), fn_name), args, fn_name, tag or fn_name, work))
 
     def py(self, fn: Callable[[], None]):
-        self.calls.append((None, fn, "py"))
+        self.calls.append((None, fn, "py", "py", 0.0))
 
     def run(self, stream: int):
-        for fn, args, name in self.calls:
+        for fn, args, name, _, _ in self.calls:
             if fn is None:
                 args()
             else:
                 st = fn(*args, stream)
                 if st != 0:
                     _lib.check(st, name)
+
+    def run_timed(self, stream: int, tag: str, out: list):
+        """Eager replay that brackets every launch tagged `tag` with events on the launch stream;
+        appends (start_event, end_event, work) to `out`."""
+        for fn, args, name, t, work in self.calls:
+            if fn is None:
+                args()
+                continue
+            if t == tag:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                st = fn(*args, stream)
+                e1.record()
+                out.append((e0, e1, work))
+            else:
+                st = fn(*args, stream)
+            if st != 0:
+                _lib.check(st, name)
 
     def __len__(self):
         return len(self.calls)
@@ -69,6 +87,7 @@ class Plan:
         self.bwd: List[Segment] = []          # backward segments in execution order
         self.bucket_after: Dict[str, Tuple[int, int]] = {}   # segment name -> flat grad range complete after it
         self.n_launches = 0
+        self.gemm_flops = 0.0                 # algorithmic GEMM FLOPs of one step (fwd + dgrad + wgrad)
 
 
 class Engine:
@@ -122,7 +141,9 @@ class Engine:
             e.flags = (MH_GEMM_GELU if d.get("gelu") else 0) | (MH_GEMM_OUT_F32 if Cm.dtype == F32 else 0) | \
                       (MH_GEMM_ACCUM if d.get("accum") else 0)
         plan.keep.append(arr)
-        seg.c("mh_gemm_bf16_grouped", arr, n, int(a_k), int(b_k))
+        flops = float(sum(2.0 * d["M"] * d["N"] * d["K"] for d in probs))
+        plan.gemm_flops += flops
+        seg.c("mh_gemm_bf16_grouped", arr, n, int(a_k), int(b_k), tag=f"gemm<{int(a_k)},{int(b_k)}>", work=flops)
 
     @staticmethod
     def _fwd_prob(x, w, out, T, N, K, **kw):

@@ -360,27 +360,48 @@ class Adam(torch.optim.Optimizer):
 
 
 class GraphedStep:
-    """Whole fine-tune step (forward, loss, backward, clip, Adam) captured once into a hipGraph and
-    replayed per batch: the ~600 kernel launches of a step cost one host call."""
+    """Whole fine-tune step (forward, loss, backward, clip, Adam) captured into hipGraphs and
+    replayed per batch, so the ~600 kernel launches of a step cost a handful of host calls.
 
-    def __init__(self, model: MultimodalClassifier, optimizer: Adam, batch: int, seq_len: int, use_graph: bool = True):
+    Single GPU: ONE graph.  Data parallel (``reducer`` given): one graph for forward+loss, one per
+    backward segment, one for the optimizer; after each backward segment's graph is launched the
+    gradient slice it completed is handed to the RCCL all-reduce, which overlaps the next segment.
+    """
+
+    def __init__(self, model: MultimodalClassifier, optimizer: Adam, batch: int, seq_len: int, use_graph: bool = True,
+                 reducer=None):
         self.model, self.opt = model, optimizer
         optimizer._model = model
         eng = model._get_engine()
         self.plan = eng.plan(batch, seq_len)
         if model._shadow_stale:
             model.refresh_shadow()
-        self.graph = None
         self.use_graph = use_graph
-        self._captured = False
+        self.reducer = reducer
+        if reducer is not None:
+            optimizer.grad_scale = reducer.grad_scale
+        self.graphs = None
 
-    def _body(self):
+    # ---- pieces ------------------------------------------------------------------------------------------
+    def _pieces(self):
+        p = self.plan
+        def fwd(stream):
+            p.fwd.run(stream)
+            p.loss.run(stream)
+        pieces = [("fwd", fwd, None)]
+        for seg in p.bwd:
+            pieces.append((seg.name, seg.run, p.bucket_after.get(seg.name)))
+        pieces.append(("opt", lambda stream: self.opt.launch(), None))
+        return pieces
+
+    def _run_eager(self):
         stream = torch.cuda.current_stream().cuda_stream
-        self.plan.fwd.run(stream)
-        self.plan.loss.run(stream)
-        for seg in self.plan.bwd:
-            seg.run(stream)
-        self.opt.launch()
+        for name, fn, rng in self._pieces():
+            if name == "opt" and self.reducer is not None:
+                self.reducer.wait()
+            fn(stream)
+            if self.reducer is not None:
+                self.reducer.reduce_range(rng)
 
     def load_batch(self, text, image, mask, labels):
         b = self.plan.buf
@@ -398,29 +419,50 @@ class GraphedStep:
         opt._step += 1
         opt._write_hyper()
         if not self.use_graph:
-            self._body()
+            self._run_eager()
         else:
-            if not self._captured:
+            if self.graphs is None:
                 self._capture()
-            self.graph.replay()
+            for g, name, rng in self.graphs:
+                if name == "opt" and self.reducer is not None:
+                    self.reducer.wait()
+                g.replay()
+                if self.reducer is not None:
+                    self.reducer.reduce_range(rng)
         return self.plan.buf["loss"], self.plan.buf["ncorrect"]
 
     def _capture(self):
         # one warm-up run on a side stream (lazy module loads, workspace allocation), undone afterwards so
-        # it does not count as a training step; then capture the same launches into a graph
+        # it does not count as a training step; then capture the same launches
         f = self.opt._flat
         snap = (f["P"].clone(), f["M"].clone(), f["V"].clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._body()
+            stream = s.cuda_stream
+            for name, fn, rng in self._pieces():
+                fn(stream)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         f["P"].copy_(snap[0]); f["M"].copy_(snap[1]); f["V"].copy_(snap[2])
         self.model.refresh_shadow()
         # (the warm-up left prev_ids == ids, so the first real step re-zeroes exactly the embedding-gradient
         #  rows the warm-up wrote)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._body()
-        self._captured = True
+        pieces = self._pieces()
+        graphs = []
+        if self.reducer is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                stream = torch.cuda.current_stream().cuda_stream
+                for name, fn, rng in pieces:
+                    fn(stream)
+            graphs.append((g, "step", None))
+        else:
+            pool = None
+            for name, fn, rng in pieces:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn(torch.cuda.current_stream().cuda_stream)
+                pool = g.pool()
+                graphs.append((g, name, rng))
+        self.graphs = graphs
