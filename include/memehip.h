@@ -76,6 +76,11 @@ typedef struct MhGemmProblem {
 
 int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems, int a_kmajor,
                          int b_kmajor, mh_stream_t stream);
+/* kernel variant for A/B measurements in one process: 0 = 128x128 tile staged global->VGPR->LDS,
+ * 1 = 128x128 tile staged by LDS-DMA (buffer_load ... lds), 2 = 256x128 tile, 8 waves, 3-stage LDS-DMA
+ * ring with counted vmcnt, 3 = the same ring with the two wave groups in ping-pong R/C slots.
+ * Default 1 (or env MEMEHIP_GEMM_VARIANT at first launch). */
+int mh_gemm_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (D % 8 == 0, D <= 4096), one wavefront per row.

@@ -107,111 +107,129 @@ MH_DEV void store_rows_from_T(bf16* __restrict__ base, size_t pitch, int row0, i
 }
 
 // ----------------------------------------------------------------------------------------------
-// forward
+// forward.  NT_RES > 0: the head's whole K and V (NT_RES tiles of 64 keys) are staged into LDS once,
+// then every wave sweeps its 32-query tiles with no further barrier or global K/V load (S <= 64*NT_RES).
+// NT_RES == 0: streaming fallback for long sequences (one K/V tile resident at a time).
 // ----------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, int NT_RES>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16* __restrict__ qkv,
                                                            const int64_t* __restrict__ key_mask,
                                                            bf16* __restrict__ out, float* __restrict__ lse,
                                                            int B, int S, int H) {
     constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) char smem[2 * IMG + TILE * 4];
+    constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_img = smem;
-    char* v_img = smem + IMG;
-    float* kbias = (float*)(smem + 2 * IMG);
+    char* v_img = smem + NTL * IMG;
+    float* kbias = (float*)(smem + 2 * NTL * IMG);
+    int* kany = (int*)(kbias + NTL * TILE);   // per 32-key sub-tile: any key to attend to?
 
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
-    const int q0 = blockIdx.x * (NW * 32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
     const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
     const bf16* kb = qb + (size_t)H * HD;
     const bf16* vb = qb + (size_t)2 * H * HD;
-    const int wq0 = q0 + wave * 32;
-    const bool active = wq0 < S;
-
-    bf16x8 qf[4];
-    load_rows_frag(qb, pitch, wq0, S, lane, qf);
-
-    f32x16 o[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) o[i][g] = 0.f;
-    float m = NEG_BIG, l = 0.f;
     const float c = 0.125f * LOG2E;  // 1/sqrt(64) folded with log2(e)
+    const int ntiles = (S + TILE - 1) / TILE;
 
-    for (int k0 = 0; k0 < S; k0 += TILE) {
-        __syncthreads();
-        stage_tile<NT>(kb, pitch, k0, S, tid, k_img, nullptr);
-        stage_tile<NT>(vb, pitch, k0, S, tid, nullptr, v_img);
-        if (tid < TILE) {
-            const int key = k0 + tid;
+    auto stage = [&](int t, int slot) {
+        stage_tile<NT>(kb, pitch, t * TILE, S, tid, k_img + slot * IMG, nullptr);
+        stage_tile<NT>(vb, pitch, t * TILE, S, tid, nullptr, v_img + slot * IMG);
+        if (tid < TILE) {   // wave 0, all 64 lanes
+            const int key = t * TILE + tid;
             float bias = NEG_BIG;
             if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) bias = 0.f;
-            kbias[tid] = bias;
+            kbias[slot * TILE + tid] = bias;
+            const unsigned long long bal = __ballot(bias == 0.f);
+            if (tid == 0) {
+                kany[slot * 2] = (bal & 0xffffffffull) != 0;
+                kany[slot * 2 + 1] = (bal >> 32) != 0;
+            }
         }
+    };
+    if (NT_RES > 0) {
+        for (int t = 0; t < ntiles; ++t) stage(t, t);
         __syncthreads();
-        if (!active) continue;
+    }
 
-        f32x16 st[2];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) st[sub][g] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(k_img, sub * 32, s, lane), qf[s],
-                                                                  st[sub], 0, 0, 0);
-        }
-        float mx = NEG_BIG;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 kb4 = *(const f32x4*)(kbias + sub * 32 + 8 * g4 + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = st[sub][4 * g4 + e] * c + kb4[e];
-                    st[sub][4 * g4 + e] = v;
-                    mx = fmaxf(mx, v);
-                }
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        m = mn;
-        float ps = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float p = __builtin_amdgcn_exp2f(st[sub][g] - mn);
-                st[sub][g] = p;
-                ps += p;
-            }
-        l = l * alpha + ps;
+    for (int qt = blockIdx.x * NW + wave; (NT_RES > 0) ? (qt * 32 < S) : (qt == (int)blockIdx.x * NW + wave);
+         qt += NW * gridDim.x) {
+        const int wq0 = qt * 32;
+        const bool active = wq0 < S;
+        bf16x8 qf[4];
+        load_rows_frag(qb, pitch, wq0, S, lane, qf);
+        f32x16 o[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) o[i][g] *= alpha;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = acc_frag(st[sub], s);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(v_img, sub * 32, s, dt * 32, lane), pf,
-                                                                    o[dt], 0, 0, 0);
+            for (int g = 0; g < 16; ++g) o[i][g] = 0.f;
+        float m = NEG_BIG, l = 0.f;
+
+        for (int t = 0; t < ntiles; ++t) {
+            const int slot = NT_RES > 0 ? t : 0;
+            if (NT_RES == 0) {
+                __syncthreads();
+                stage(t, 0);
+                __syncthreads();
+                if (!active) continue;
             }
+            const char* ki = k_img + slot * IMG;
+            const char* vi = v_img + slot * IMG;
+            const float* kbt = kbias + slot * TILE;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                // a 32-key sub-tile with nothing to attend to (padding / past S) contributes exactly 0
+                if (!__builtin_amdgcn_readfirstlane(kany[slot * 2 + sub])) continue;
+                f32x16 st;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) st[g] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ki, sub * 32, s, lane), qf[s], st, 0, 0, 0);
+                float mx = NEG_BIG;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 kb4 = *(const f32x4*)(kbt + sub * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = st[4 * g4 + e] * c + kb4[e];
+                        st[4 * g4 + e] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mn = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                float ps = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float p = __builtin_amdgcn_exp2f(st[g] - mn);
+                    st[g] = p;
+                    ps += p;
+                }
+                l = l * alpha + ps;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) o[i][g] *= alpha;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 pf = acc_frag(st, s);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vi, sub * 32, s, dt * 32, lane), pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (!active) continue;
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        store_rows_from_T(out + (size_t)b * S * H * HD + hh * HD, (size_t)H * HD, wq0, S, lane, o, inv);
+        const int q = wq0 + (lane & 31);
+        if (h == 0 && q < S) lse[((size_t)b * H + hh) * S + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
     }
-    if (!active) return;
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    store_rows_from_T(out + (size_t)b * S * H * HD + hh * HD, (size_t)H * HD, wq0, S, lane, o, inv);
-    const int q = wq0 + (lane & 31);
-    if (h == 0 && q < S) lse[((size_t)b * H + hh) * S + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
 }
 
 // delta[b][h][s] = sum_d dout * out
@@ -236,9 +254,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 }
 
 // ----------------------------------------------------------------------------------------------
-// backward, dQ:  one wave = 32 queries, sweep key tiles
+// backward, dQ:  one wave = 32 queries at a time, sweep key tiles (resident K/V when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, int NT_RES>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv,
                                                               const int64_t* __restrict__ key_mask,
                                                               const bf16* __restrict__ dout,
@@ -246,89 +264,114 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __rest
                                                               const float* __restrict__ delta,
                                                               bf16* __restrict__ dqkv, int B, int S, int H) {
     constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) char smem[3 * IMG + TILE * 4];
+    constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_img = smem;
-    char* kt_img = smem + IMG;
-    char* v_img = smem + 2 * IMG;
-    float* kbias = (float*)(smem + 3 * IMG);
+    char* kt_img = smem + NTL * IMG;
+    char* v_img = smem + 2 * NTL * IMG;
+    float* kbias = (float*)(smem + 3 * NTL * IMG);
+    int* kany = (int*)(kbias + NTL * TILE);
 
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
-    const int q0 = blockIdx.x * (NW * 32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
     const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
     const bf16* kb = qb + (size_t)H * HD;
     const bf16* vb = qb + (size_t)2 * H * HD;
     const bf16* dob = dout + (size_t)b * S * H * HD + hh * HD;
-    const int wq0 = q0 + wave * 32;
-    const bool active = wq0 < S;
-    const int q = wq0 + (lane & 31);
-
-    bf16x8 qf[4], dof[4];
-    load_rows_frag(qb, pitch, wq0, S, lane, qf);
-    load_rows_frag(dob, (size_t)H * HD, wq0, S, lane, dof);
     const float c = 0.125f * LOG2E;
-    float lse2 = 0.f, dl = 0.f;
-    if (q < S) {
-        lse2 = lse[((size_t)b * H + hh) * S + q] * LOG2E;
-        dl = delta[((size_t)b * H + hh) * S + q];
-    }
-    f32x16 dq[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) dq[i][g] = 0.f;
+    const int ntiles = (S + TILE - 1) / TILE;
 
-    for (int k0 = 0; k0 < S; k0 += TILE) {
-        __syncthreads();
-        stage_tile<NT>(kb, pitch, k0, S, tid, k_img, kt_img);
-        stage_tile<NT>(vb, pitch, k0, S, tid, v_img, nullptr);
+    auto stage = [&](int t, int slot) {
+        stage_tile<NT>(kb, pitch, t * TILE, S, tid, k_img + slot * IMG, kt_img + slot * IMG);
+        stage_tile<NT>(vb, pitch, t * TILE, S, tid, v_img + slot * IMG, nullptr);
         if (tid < TILE) {
-            const int key = k0 + tid;
+            const int key = t * TILE + tid;
             float bias = NEG_BIG;
             if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) bias = 0.f;
-            kbias[tid] = bias;
-        }
-        __syncthreads();
-        if (!active) continue;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            f32x16 st, dp;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(k_img, sub * 32, s, lane), qf[s], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(v_img, sub * 32, s, lane), dof[s], dp, 0, 0, 0);
+            kbias[slot * TILE + tid] = bias;
+            const unsigned long long bal = __ballot(bias == 0.f);
+            if (tid == 0) {
+                kany[slot * 2] = (bal & 0xffffffffull) != 0;
+                kany[slot * 2 + 1] = (bal >> 32) != 0;
             }
+        }
+    };
+    if (NT_RES > 0) {
+        for (int t = 0; t < ntiles; ++t) stage(t, t);
+        __syncthreads();
+    }
+
+    for (int qt = blockIdx.x * NW + wave; (NT_RES > 0) ? (qt * 32 < S) : (qt == (int)blockIdx.x * NW + wave);
+         qt += NW * gridDim.x) {
+        const int wq0 = qt * 32;
+        const bool active = wq0 < S;
+        const int q = wq0 + (lane & 31);
+        bf16x8 qf[4], dof[4];
+        load_rows_frag(qb, pitch, wq0, S, lane, qf);
+        load_rows_frag(dob, (size_t)H * HD, wq0, S, lane, dof);
+        float lse2 = 0.f, dl = 0.f;
+        if (q < S) {
+            lse2 = lse[((size_t)b * H + hh) * S + q] * LOG2E;
+            dl = delta[((size_t)b * H + hh) * S + q];
+        }
+        f32x16 dq[2];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 kb4 = *(const f32x4*)(kbias + sub * 32 + 8 * g4 + 4 * h);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int g = 4 * g4 + e;
-                    const float p = __builtin_amdgcn_exp2f(st[g] * c + kb4[e] - lse2);
-                    st[g] = p * (dp[g] - dl);  // dS^T (unscaled)
+            for (int g = 0; g < 16; ++g) dq[i][g] = 0.f;
+
+        for (int t = 0; t < ntiles; ++t) {
+            const int slot = NT_RES > 0 ? t : 0;
+            if (NT_RES == 0) {
+                __syncthreads();
+                stage(t, 0);
+                __syncthreads();
+                if (!active) continue;
+            }
+            const char* ki = k_img + slot * IMG;
+            const char* kti = kt_img + slot * IMG;
+            const char* vi = v_img + slot * IMG;
+            const float* kbt = kbias + slot * TILE;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                if (!__builtin_amdgcn_readfirstlane(kany[slot * 2 + sub])) continue;   // P == 0 on the whole sub-tile
+                f32x16 st, dp;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ki, sub * 32, s, lane), qf[s], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vi, sub * 32, s, lane), dof[s], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 kb4 = *(const f32x4*)(kbt + sub * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int g = 4 * g4 + e;
+                        const float p = __builtin_amdgcn_exp2f(st[g] * c + kb4[e] - lse2);
+                        st[g] = p * (dp[g] - dl);  // dS^T (unscaled)
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 df = acc_frag(st, s);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kti, sub * 32, s, dt * 32, lane), df, dq[dt], 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 df = acc_frag(st, s);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kt_img, sub * 32, s, dt * 32, lane), df,
-                                                                     dq[dt], 0, 0, 0);
-            }
         }
+        if (!active) continue;
+        store_rows_from_T(dqkv + (size_t)b * S * pitch + hh * HD, pitch, wq0, S, lane, dq, 0.125f);
     }
-    if (!active) return;
-    store_rows_from_T(dqkv + (size_t)b * S * pitch + hh * HD, pitch, wq0, S, lane, dq, 0.125f);
 }
 
 // ----------------------------------------------------------------------------------------------
-// backward, dK / dV:  one wave = 32 keys, sweep query tiles
+// backward, dK / dV:  one wave = 32 keys at a time, sweep query tiles (resident Q/dO when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, int NT_RES>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv,
                                                                const int64_t* __restrict__ key_mask,
                                                                const bf16* __restrict__ dout,
@@ -336,93 +379,128 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16* __res
                                                                const float* __restrict__ delta,
                                                                bf16* __restrict__ dqkv, int B, int S, int H) {
     constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) char smem[4 * IMG + 2 * TILE * 4];
+    constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* q_img = smem;
-    char* qt_img = smem + IMG;
-    char* do_img = smem + 2 * IMG;
-    char* dot_img = smem + 3 * IMG;
-    float* lse_t = (float*)(smem + 4 * IMG);
-    float* dl_t = lse_t + TILE;
+    char* qt_img = smem + NTL * IMG;
+    char* do_img = smem + 2 * NTL * IMG;
+    char* dot_img = smem + 3 * NTL * IMG;
+    float* lse_t = (float*)(smem + 4 * NTL * IMG);
+    float* dl_t = lse_t + NTL * TILE;
 
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
-    const int kblk0 = blockIdx.x * (NW * 32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
     const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
     const bf16* kb = qb + (size_t)H * HD;
     const bf16* vb = qb + (size_t)2 * H * HD;
     const bf16* dob = dout + (size_t)b * S * H * HD + hh * HD;
-    const int wk0 = kblk0 + wave * 32;
-    const bool active = wk0 < S;
-    const int key = wk0 + (lane & 31);
-
-    bf16x8 kf[4], vf[4];
-    load_rows_frag(kb, pitch, wk0, S, lane, kf);
-    load_rows_frag(vb, pitch, wk0, S, lane, vf);
-    float kbias = NEG_BIG;
-    if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) kbias = 0.f;
     const float c = 0.125f * LOG2E;
+    const int ntiles = (S + TILE - 1) / TILE;
 
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) { dk[i][g] = 0.f; dv[i][g] = 0.f; }
-
-    for (int q0 = 0; q0 < S; q0 += TILE) {
-        __syncthreads();
-        stage_tile<NT>(qb, pitch, q0, S, tid, q_img, qt_img);
-        stage_tile<NT>(dob, (size_t)H * HD, q0, S, tid, do_img, dot_img);
-        if (tid < TILE) {
-            const int qq = q0 + tid;
+    auto stage = [&](int t, int slot) {
+        stage_tile<NT>(qb, pitch, t * TILE, S, tid, q_img + slot * IMG, qt_img + slot * IMG);
+        stage_tile<NT>(dob, (size_t)H * HD, t * TILE, S, tid, do_img + slot * IMG, dot_img + slot * IMG);
+        for (int i = tid; i < TILE; i += NT) {
+            const int qq = t * TILE + i;
             // rows past S: lse = +big makes P = exp2(-big) = 0, so they add nothing
-            lse_t[tid] = qq < S ? lse[((size_t)b * H + hh) * S + qq] * LOG2E : 1.0e30f;
-            dl_t[tid] = qq < S ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
+            lse_t[slot * TILE + i] = qq < S ? lse[((size_t)b * H + hh) * S + qq] * LOG2E : 1.0e30f;
+            dl_t[slot * TILE + i] = qq < S ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
         }
+    };
+    if (NT_RES > 0) {
+        for (int t = 0; t < ntiles; ++t) stage(t, t);
         __syncthreads();
-        if (!active) continue;
+    }
+
+    for (int kt = blockIdx.x * NW + wave; (NT_RES > 0) ? (kt * 32 < S) : (kt == (int)blockIdx.x * NW + wave);
+         kt += NW * gridDim.x) {
+        const int wk0 = kt * 32;
+        const bool active = wk0 < S;
+        const int key = wk0 + (lane & 31);
+        bf16x8 kf[4], vf[4];
+        load_rows_frag(kb, pitch, wk0, S, lane, kf);
+        load_rows_frag(vb, pitch, wk0, S, lane, vf);
+        float kbias = NEG_BIG;
+        if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) kbias = 0.f;
+        f32x16 dk[2], dv[2];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            f32x16 st, dp;  // rows = queries (register), cols = keys (lane)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(q_img, sub * 32, s, lane), kf[s], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(do_img, sub * 32, s, lane), vf[s], dp, 0, 0, 0);
+            for (int g = 0; g < 16; ++g) { dk[i][g] = 0.f; dv[i][g] = 0.f; }
+        // every key of this wave's tile masked: P == 0 for all queries, so dK = dV = 0 (resident mode has no
+        // barriers inside the sweep, so the wave may leave early)
+        const bool any_key = __ballot(kbias == 0.f) != 0ull;
+
+        for (int t = 0; t < ntiles; ++t) {
+            const int slot = NT_RES > 0 ? t : 0;
+            if (NT_RES == 0) {
+                __syncthreads();
+                stage(t, 0);
+                __syncthreads();
+                if (!active) continue;
             }
-            f32x16 pp;
+            if (!any_key) continue;
+            const char* qi = q_img + slot * IMG;
+            const char* qti = qt_img + slot * IMG;
+            const char* doi = do_img + slot * IMG;
+            const char* doti = dot_img + slot * IMG;
+            const float* lt = lse_t + slot * TILE;
+            const float* dt_ = dl_t + slot * TILE;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 l4 = *(const f32x4*)(lse_t + sub * 32 + 8 * g4 + 4 * h);
-                const f32x4 d4 = *(const f32x4*)(dl_t + sub * 32 + 8 * g4 + 4 * h);
+            for (int sub = 0; sub < 2; ++sub) {
+                if (t * TILE + sub * 32 >= S) continue;   // query rows past S
+                f32x16 st, dp;  // rows = queries (register), cols = keys (lane)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int g = 4 * g4 + e;
-                    const float p = __builtin_amdgcn_exp2f(st[g] * c + kbias - l4[e]);
-                    pp[g] = p;
-                    st[g] = p * (dp[g] - d4[e]);  // dS (unscaled)
+                for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qi, sub * 32, s, lane), kf[s], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(doi, sub * 32, s, lane), vf[s], dp, 0, 0, 0);
                 }
-            }
+                f32x16 pp;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = acc_frag(pp, s);
-                const bf16x8 df = acc_frag(st, s);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *(const f32x4*)(lt + sub * 32 + 8 * g4 + 4 * h);
+                    const f32x4 d4 = *(const f32x4*)(dt_ + sub * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dot_img, sub * 32, s, dt * 32, lane), pf,
-                                                                     dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qt_img, sub * 32, s, dt * 32, lane), df,
-                                                                     dk[dt], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        const int g = 4 * g4 + e;
+                        const float p = __builtin_amdgcn_exp2f(st[g] * c + kbias - l4[e]);
+                        pp[g] = p;
+                        st[g] = p * (dp[g] - d4[e]);  // dS (unscaled)
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 pf = acc_frag(pp, s);
+                    const bf16x8 df = acc_frag(st, s);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(doti, sub * 32, s, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qti, sub * 32, s, dt * 32, lane), df, dk[dt], 0, 0, 0);
+                    }
                 }
             }
         }
+        if (!active) continue;
+        bf16* dkb = dqkv + (size_t)b * S * pitch + (size_t)H * HD + hh * HD;
+        bf16* dvb = dqkv + (size_t)b * S * pitch + (size_t)2 * H * HD + hh * HD;
+        store_rows_from_T(dkb, pitch, wk0, S, lane, dk, 0.125f);
+        store_rows_from_T(dvb, pitch, wk0, S, lane, dv, 1.0f);
     }
-    if (!active) return;
-    bf16* dkb = dqkv + (size_t)b * S * pitch + (size_t)H * HD + hh * HD;
-    bf16* dvb = dqkv + (size_t)b * S * pitch + (size_t)2 * H * HD + hh * HD;
-    store_rows_from_T(dkb, pitch, wk0, S, lane, dk, 0.125f);
-    store_rows_from_T(dvb, pitch, wk0, S, lane, dv, 1.0f);
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------------
+// resident when S <= 256 (NT_RES = 2 for S <= 128, else 4); the 32-row tiles of a head are dealt to
+// `split` workgroups of 4 waves (split chosen so that every wave has work and the grid fills 256 CUs)
+template <typename K>
+void set_lds(K kern, int bytes) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+int split_for(int S) {
+    const int tiles32 = (S + 31) / 32;
+    return tiles32 > 4 ? 2 : 1;
 }
 
 }  // namespace
@@ -432,14 +510,20 @@ extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, 
     if (!qkv || !out || !lse) return MH_EINVAL;
     if (B < 1 || S < 1 || H < 1) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (S % 128 == 0 || S > 512) {
-        dim3 grid((S + 127) / 128, B * H);
-        hipLaunchKernelGGL((attn_fwd_kernel<4>), grid, dim3(256), 0, s, (const bf16*)qkv, key_mask, (bf16*)out,
-                           lse, B, S, H);
+    const bf16* q = (const bf16*)qkv;
+    if (S <= 128) {
+        constexpr int L = 2 * 2 * IMG + 2 * TILE * 4 + 64;
+        static bool once = (set_lds(attn_fwd_kernel<4, 2>, L), true);
+        (void)once;
+        hipLaunchKernelGGL((attn_fwd_kernel<4, 2>), dim3(split_for(S), B * H), dim3(256), L, s, q, key_mask, (bf16*)out, lse, B, S, H);
+    } else if (S <= 256) {
+        constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
+        static bool once = (set_lds(attn_fwd_kernel<4, 4>, L), true);
+        (void)once;
+        hipLaunchKernelGGL((attn_fwd_kernel<4, 4>), dim3(split_for(S), B * H), dim3(256), L, s, q, key_mask, (bf16*)out, lse, B, S, H);
     } else {
-        dim3 grid((S + 63) / 64, B * H);
-        hipLaunchKernelGGL((attn_fwd_kernel<2>), grid, dim3(128), 0, s, (const bf16*)qkv, key_mask, (bf16*)out,
-                           lse, B, S, H);
+        constexpr int L = 2 * IMG + TILE * 4 + 64;
+        hipLaunchKernelGGL((attn_fwd_kernel<4, 0>), dim3((S + 127) / 128, B * H), dim3(256), L, s, q, key_mask, (bf16*)out, lse, B, S, H);
     }
     return mh_launch_status();
 }
@@ -453,18 +537,28 @@ extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void*
     const int n = B * S * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16*)out,
                        (const bf16*)dout, delta, B, S, H);
-    if (S % 128 == 0 || S > 512) {
-        dim3 grid((S + 127) / 128, B * H);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<4>), grid, dim3(256), 0, s, (const bf16*)qkv, key_mask,
-                           (const bf16*)dout, lse, delta, (bf16*)dqkv, B, S, H);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4>), grid, dim3(256), 0, s, (const bf16*)qkv, key_mask,
-                           (const bf16*)dout, lse, delta, (bf16*)dqkv, B, S, H);
+    const bf16* q = (const bf16*)qkv;
+    const bf16* dO = (const bf16*)dout;
+    bf16* dq = (bf16*)dqkv;
+    if (S <= 128) {
+        constexpr int L1 = 3 * 2 * IMG + 2 * TILE * 4 + 64, L2 = 4 * 2 * IMG + 2 * 2 * TILE * 4;
+        static bool once = (set_lds(attn_bwd_dq_kernel<4, 2>, L1), set_lds(attn_bwd_dkv_kernel<4, 2>, L2), true);
+        (void)once;
+        dim3 grid(split_for(S), B * H);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2>), grid, dim3(256), L1, s, q, key_mask, dO, lse, delta, dq, B, S, H);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 2>), grid, dim3(256), L2, s, q, key_mask, dO, lse, delta, dq, B, S, H);
+    } else if (S <= 256) {
+        constexpr int L1 = 3 * 4 * IMG + 4 * TILE * 4 + 64, L2 = 4 * 4 * IMG + 2 * 4 * TILE * 4;
+        static bool once = (set_lds(attn_bwd_dq_kernel<4, 4>, L1), set_lds(attn_bwd_dkv_kernel<4, 4>, L2), true);
+        (void)once;
+        dim3 grid(split_for(S), B * H);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 4>), grid, dim3(256), L1, s, q, key_mask, dO, lse, delta, dq, B, S, H);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 4>), grid, dim3(256), L2, s, q, key_mask, dO, lse, delta, dq, B, S, H);
     } else {
-        dim3 grid((S + 63) / 64, B * H);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<2>), grid, dim3(128), 0, s, (const bf16*)qkv, key_mask,
-                           (const bf16*)dout, lse, delta, (bf16*)dqkv, B, S, H);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), grid, dim3(128), 0, s, (const bf16*)qkv, key_mask,
-                           (const bf16*)dout, lse, delta, (bf16*)dqkv, B, S, H);
+        constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
+        dim3 grid((S + 127) / 128, B * H);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 0>), grid, dim3(256), L1, s, q, key_mask, dO, lse, delta, dq, B, S, H);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 0>), grid, dim3(256), L2, s, q, key_mask, dO, lse, delta, dq, B, S, H);
     }
     return mh_launch_status();
 }

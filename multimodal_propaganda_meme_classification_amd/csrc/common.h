@@ -54,12 +54,32 @@ MH_DEV float wave_max(float v) {
     return v;
 }
 
-// exact (erf) GELU and its derivative, fp32
-MH_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU and its derivative in fp32.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below
+// the bf16 rounding of the result): one v_rcp, one v_exp, five FMAs instead of libm erff's ~40 ops,
+// and gelu' re-uses the same exponential (exp(-x^2/2) is both erf's tail and the Gaussian pdf).
+struct GeluParts {
+    float cdf;  // 0.5 (1 + erf(x / sqrt 2))
+    float pdf;  // exp(-x^2/2) / sqrt(2 pi)
+};
+MH_DEV GeluParts gelu_parts(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);  // exp(-x^2/2)
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float erf_abs = 1.0f - poly * t * e;
+    GeluParts r;
+    r.cdf = 0.5f + 0.5f * copysignf(erf_abs, x);
+    r.pdf = 0.39894228040143268f * e;
+    return r;
+}
+MH_DEV float gelu_f(float x) { return x * gelu_parts(x).cdf; }
 MH_DEV float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    const GeluParts g = gelu_parts(x);
+    return g.cdf + x * g.pdf;
 }
 
 static inline int mh_launch_status() {

@@ -13,6 +13,7 @@
 // blockIdx -> tile: XCD-aware (blocks b, b+8 share an L2): each XCD gets a contiguous run of
 // tiles, tiles ordered n-fastest so the run re-uses one A row panel and the whole of B.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -70,6 +71,29 @@ MH_DEV void store_tile(char* lds, int tid, const i32x4 (&v)[4]) {
     }
 }
 
+// ---- global -> LDS directly (LDS-DMA, buffer_load ... lds): no VGPR staging, no ds_write pass ---
+// One wave-instruction writes 1 KiB of LDS linearly (base + lane*16), so the swizzle is applied to
+// the per-lane SOURCE address (same involution as store_tile).  Wave w moves pieces 4w..4w+3.
+template <int KMAJOR>
+MH_DEV void dma_tile(__amdgpu_buffer_rsrc_t r, int ld, int r0, int k0, int wave, int lane, char* lds) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;
+        uint32_t off;
+        if (KMAJOR == 0) {
+            const int row = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            off = (uint32_t)((r0 + row) * ld + k0 + c * 8) * 2u;
+        } else {
+            const int kr = piece * 4 + (lane >> 4);
+            const int pos = lane & 15;
+            const int c = (((pos >> 1) ^ swz_kstrided(kr)) << 1) | (pos & 1);
+            off = (uint32_t)((k0 + kr) * ld + r0 + c * 8) * 2u;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, lds + piece * 1024), 16, off, 0, 0, 0);
+    }
+}
+
 // ---- LDS -> MFMA fragment: rows rb..rb+15, k = kk*32 .. kk*32+31 -------------------------------
 template <int KMAJOR>
 MH_DEV bf16x8 read_frag(const char* lds, int rb, int kk, int lane) {
@@ -100,122 +124,16 @@ MH_DEV bf16x8 read_frag(const char* lds, int rb, int kk, int lane) {
     }
 }
 
-template <int LA, int LB>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    // ---- which tile ----------------------------------------------------------------------------
-    const int nwg = g.total_tiles;
-    int t;
-    {
-        const int b = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, x = b & 7;
-        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
-        if (i < g.n && t >= g.d[i].tile_start) pi = i;
-    const MhGemmProblem& P = g.d[pi].p;
-    const int lt = t - g.d[pi].tile_start;
-    const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int M = P.M, N = P.N, K = P.K;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-
-    const uint32_t a_bytes = (LA == 0) ? (uint32_t)((M - 1) * P.lda + K) * 2u
-                                       : (uint32_t)((K - 1) * P.lda + M) * 2u;
-    const uint32_t b_bytes = (LB == 0) ? (uint32_t)((N - 1) * P.ldb + K) * 2u
-                                       : (uint32_t)((K - 1) * P.ldb + N) * 2u;
-    const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, a_bytes);
-    const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, b_bytes);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave & 1) == 0);
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-
-    const int nk = (K + BK - 1) / BK;
-    i32x4 va[4], vb[4];
-    load_tile<LA>(ra, P.lda, m0, 0, tid, va);
-    load_tile<LB>(rb, P.ldb, n0, 0, tid, vb);
-    store_tile<LA>(smem, tid, va);
-    store_tile<LB>(smem + BM * BK * 2, tid, vb);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * STAGE_BYTES;
-        char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            load_tile<LA>(ra, P.lda, m0, (kt + 1) * BK, tid, va);
-            load_tile<LB>(rb, P.ldb, n0, (kt + 1) * BK, tid, vb);
-        }
-        const char* la = cur;
-        const char* lb = cur + BM * BK * 2;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA>(la, wm0 + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            if (do_rowsum) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
-            }
-        }
-        if (more) {
-            store_tile<LA>(nxt, tid, va);
-            store_tile<LB>(nxt + BM * BK * 2, tid, vb);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue --------------------------------------------------------------------------------
-    if (do_rowsum && (lane & 15) == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
-                if (row < M) P.rowsum[row] = accb[i][r];
-            }
-    }
-    float* cs = (float*)smem;  // [128][128] f32, column index XOR-swizzled by row group
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
-                const int col = wn0 + j * 16 + (lane & 15);
-                cs[row * BN + col] = acc[i][j][r];
-            }
-    __syncthreads();
-
+// ---- epilogue: f32 tile in LDS -> bias / GELU / gelu' / residual -> 16-B coalesced stores ----------
+template <int TM>
+MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n0, int tid) {
+    const int M = P.M;
     const int flags = P.flags;
     const int ldc = P.ldc;
+    const int nthreads = TM * 2;  // 256 threads for TM = 128, 512 for TM = 256
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-        const int q = it * NTHREADS + tid;
+        const int q = it * nthreads + tid;
         const int row = q >> 4, cc = q & 15;
         const int gm = m0 + row, gn = n0 + cc * 8;
         if (gm >= M) continue;
@@ -273,16 +191,485 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
     }
 }
 
+template <int LA, int LB, int DMA>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- which tile ----------------------------------------------------------------------------
+    const int nwg = g.total_tiles;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
+        if (i < g.n && t >= g.d[i].tile_start) pi = i;
+    const MhGemmProblem& P = g.d[pi].p;
+    const int lt = t - g.d[pi].tile_start;
+    const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int M = P.M, N = P.N, K = P.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+
+    const uint32_t a_bytes = (LA == 0) ? (uint32_t)((M - 1) * P.lda + K) * 2u
+                                       : (uint32_t)((K - 1) * P.lda + M) * 2u;
+    const uint32_t b_bytes = (LB == 0) ? (uint32_t)((N - 1) * P.ldb + K) * 2u
+                                       : (uint32_t)((K - 1) * P.ldb + N) * 2u;
+    const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, b_bytes);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave & 1) == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+    const int nk = (K + BK - 1) / BK;
+    auto compute = [&](const char* cur) {
+        const char* la = cur;
+        const char* lb = cur + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA>(la, wm0 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+    };
+    if (DMA) {
+        dma_tile<LA>(ra, P.lda, m0, 0, wave, lane, smem);
+        dma_tile<LB>(rb, P.ldb, n0, 0, wave, lane, smem + BM * BK * 2);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE_BYTES;
+            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            if (kt + 1 < nk) {
+                dma_tile<LA>(ra, P.lda, m0, (kt + 1) * BK, wave, lane, nxt);
+                dma_tile<LB>(rb, P.ldb, n0, (kt + 1) * BK, wave, lane, nxt + BM * BK * 2);
+            }
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+        i32x4 va[4], vb[4];
+        load_tile<LA>(ra, P.lda, m0, 0, tid, va);
+        load_tile<LB>(rb, P.ldb, n0, 0, tid, vb);
+        store_tile<LA>(smem, tid, va);
+        store_tile<LB>(smem + BM * BK * 2, tid, vb);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE_BYTES;
+            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            const bool more = (kt + 1) < nk;
+            if (more) {
+                load_tile<LA>(ra, P.lda, m0, (kt + 1) * BK, tid, va);
+                load_tile<LB>(rb, P.ldb, n0, (kt + 1) * BK, tid, vb);
+            }
+            compute(cur);
+            if (more) {
+                store_tile<LA>(nxt, tid, va);
+                store_tile<LB>(nxt + BM * BK * 2, tid, vb);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    if (do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) P.rowsum[row] = accb[i][r];
+            }
+    }
+    float* cs = (float*)smem;  // [128][128] f32, column index XOR-swizzled by row group
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
+                const int col = wn0 + j * 16 + (lane & 15);
+                cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    epilogue_rows<BM>(P, cs, m0, n0, tid);
+}
+
+// one 1-KiB LDS-DMA piece of a 16-KiB panel ([128 rows][64 k] or [64 k][128 rows]), swizzle on the source
+template <int KMAJOR>
+MH_DEV void dma_piece(__amdgpu_buffer_rsrc_t r, int ld, int r0, int k0, int piece, int lane, char* panel) {
+    uint32_t off;
+    if (KMAJOR == 0) {
+        const int row = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        off = (uint32_t)((r0 + row) * ld + k0 + c * 8) * 2u;
+    } else {
+        const int kr = piece * 4 + (lane >> 4);
+        const int pos = lane & 15;
+        const int c = (((pos >> 1) ^ swz_kstrided(kr)) << 1) | (pos & 1);
+        off = (uint32_t)((k0 + kr) * ld + r0 + c * 8) * 2u;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, panel + piece * 1024), 16, off, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 256x128x64 tile, 8 waves (4M x 2N, 64x64 each), THREE-stage LDS-DMA ring (3 x 48 KiB), one workgroup
+// per CU.  Tile t+2 is issued right after the barrier of iteration t and waited for with a COUNTED
+// s_waitcnt vmcnt(6) two iterations later, so every load has two K tiles of MFMA time to land and no
+// barrier drains the queue (raw s_barrier; __syncthreads() would force vmcnt(0)).
+//   iteration t:  vmcnt(6|0) -> s_barrier -> issue tile t+2 into stage (t+2)%3 -> MFMA on stage t%3
+// RAW: a wave reads stage t%3 only after its own counted wait AND the barrier every wave reached after
+// its wait.  WAR: stage (t+2)%3 == (t-1)%3 is refilled only after the barrier that follows compute(t-1).
+// ---------------------------------------------------------------------------------------------------
+constexpr int R_BM = 256, R_THREADS = 512, R_PANEL = 16384, R_STAGE = 3 * R_PANEL, R_LDS = 3 * R_STAGE;
+
 template <int LA, int LB>
-int launch(const GemmGroup& g, hipStream_t s) {
+__global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.total_tiles;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
+        if (i < g.n && t >= g.d[i].tile_start) pi = i;
+    const MhGemmProblem& P = g.d[pi].p;
+    const int lt = t - g.d[pi].tile_start;
+    const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
+    const int m0 = tm * R_BM, n0 = tn * BN;
+    const int M = P.M, N = P.N, K = P.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int a_panel = wm >> 1, a_row0 = (wm & 1) * 64, wn0 = wn * 64;
+
+    const uint32_t a_bytes = (LA == 0) ? (uint32_t)((M - 1) * P.lda + K) * 2u : (uint32_t)((K - 1) * P.lda + M) * 2u;
+    const uint32_t b_bytes = (LB == 0) ? (uint32_t)((N - 1) * P.ldb + K) * 2u : (uint32_t)((K - 1) * P.ldb + N) * 2u;
+    const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, b_bytes);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && (wn == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+    const int nk = (K + BK - 1) / BK;
+    // wave w moves pieces 6w .. 6w+5 of the 48 pieces of a stage (panels: A rows 0-127, A rows 128-255, B)
+    auto issue = [&](int kt) {
+        char* st = smem + (kt % 3) * R_STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = wave * 6 + i;
+            const int panel = q >> 4, piece = q & 15;
+            if (panel < 2) dma_piece<LA>(ra, P.lda, m0 + panel * 128, k0, piece, lane, st + panel * R_PANEL);
+            else dma_piece<LB>(rb, P.ldb, n0, k0, piece, lane, st + 2 * R_PANEL);
+        }
+    };
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const char* st = smem + (kt % 3) * R_STAGE;
+        const char* la = st + a_panel * R_PANEL;
+        const char* lb = st + 2 * R_PANEL;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA>(la, a_row0 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // every wave is done reading the ring before it becomes the f32 output tile
+
+    const int wm0 = wm * 64;
+    if (do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) P.rowsum[row] = accb[i][r];
+            }
+    }
+    float* cs = (float*)smem;  // [256][128] f32 = 128 KiB
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
+                const int col = wn0 + j * 16 + (lane & 15);
+                cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    epilogue_rows<R_BM>(P, cs, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ping-pong variant of the ring kernel: same 256x128x64 tile, 3-stage LDS-DMA ring and wave->tile map,
+// but the two wave groups (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; waves w and w+4 share a
+// SIMD) are driven in opposite phases by a workgroup barrier per slot: while one group reads its MFMA
+// fragments from LDS (R slot), the other issues its 16 MFMAs (C slot) plus three LDS-DMA pieces, so
+// the matrix pipe of every SIMD always has one wave in a C slot.
+//   group 0:  R(t,0) | C(t,0) | R(t,1) | C(t,1) | R(t+1,0) ...          (global slots 4t .. 4t+3)
+//   group 1:         | R(t,0) | C(t,0) | R(t,1) | C(t,1)   ...          (one slot later)
+// Stage (t+2)%3 is last read in global slot 4t-1 (group 1's R(t-1,1)), so tile t+2 is issued from slot
+// 4t+1 on (three pieces per C slot).  Every wave retires its pieces of tile t+1 with a counted vmcnt at
+// the end of global slot 4t+3; the barrier that closes that slot publishes the tile to group 0's
+// R(t+1,0) in slot 4t+4.
+// ---------------------------------------------------------------------------------------------------
+#define MH_SLOT_BARRIER()                        \
+    do {                                         \
+        asm volatile("" ::: "memory");           \
+        __builtin_amdgcn_sched_barrier(0);       \
+        __builtin_amdgcn_s_barrier();            \
+        __builtin_amdgcn_sched_barrier(0);       \
+        asm volatile("" ::: "memory");           \
+    } while (0)
+
+template <int LA, int LB>
+__global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.total_tiles;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
+        if (i < g.n && t >= g.d[i].tile_start) pi = i;
+    const MhGemmProblem& P = g.d[pi].p;
+    const int lt = t - g.d[pi].tile_start;
+    const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
+    const int m0 = tm * R_BM, n0 = tn * BN;
+    const int M = P.M, N = P.N, K = P.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int a_row0 = ((wave >> 1) & 1) * 64, wn0 = (wave & 1) * 64;
+
+    const uint32_t a_bytes = (LA == 0) ? (uint32_t)((M - 1) * P.lda + K) * 2u : (uint32_t)((K - 1) * P.lda + M) * 2u;
+    const uint32_t b_bytes = (LB == 0) ? (uint32_t)((N - 1) * P.ldb + K) * 2u : (uint32_t)((K - 1) * P.ldb + N) * 2u;
+    const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, b_bytes);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave & 1) == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+    const int nk = (K + BK - 1) / BK;
+    // pieces 6w + 3h .. 6w + 3h + 2 of tile kt (h = which half)
+    auto issue_half = [&](int kt, int h) {
+        char* st = smem + (kt % 3) * R_STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = wave * 6 + h * 3 + i;
+            const int panel = q >> 4, piece = q & 15;
+            if (panel < 2) dma_piece<LA>(ra, P.lda, m0 + panel * 128, k0, piece, lane, st + panel * R_PANEL);
+            else dma_piece<LB>(rb, P.ldb, n0, k0, piece, lane, st + 2 * R_PANEL);
+        }
+    };
+    bf16x8 fa[4], fb[4];
+    auto read_frags = [&](int kt, int kk) {
+        const char* st = smem + (kt % 3) * R_STAGE;
+        const char* la = st + grp * R_PANEL;
+        const char* lb = st + 2 * R_PANEL;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA>(la, a_row0 + i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto mfma16 = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (do_rowsum) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    issue_half(0, 0);
+    issue_half(0, 1);
+    if (nk > 1) {
+        issue_half(1, 0);
+        issue_half(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    MH_SLOT_BARRIER();                 // tile 0 is in LDS for everyone
+    if (grp == 1) MH_SLOT_BARRIER();   // stagger: group 1 runs one slot behind
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more2 = kt + 2 < nk, more1 = kt + 1 < nk;
+        // ---- R(kt, 0)
+        read_frags(kt, 0);
+        MH_SLOT_BARRIER();
+        // ---- C(kt, 0)
+        if (more2) issue_half(kt + 2, 0);
+        mfma16();
+        MH_SLOT_BARRIER();
+        // ---- R(kt, 1)
+        read_frags(kt, 1);
+        if (grp == 1 && more1) {       // end of global slot 4kt+3 for group 1: tile kt+1 must have landed
+            if (more2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        MH_SLOT_BARRIER();
+        // ---- C(kt, 1)
+        if (more2) issue_half(kt + 2, 1);
+        mfma16();
+        if (grp == 0 && more1) {       // end of global slot 4kt+3 for group 0
+            if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        MH_SLOT_BARRIER();
+    }
+    if (grp == 0) MH_SLOT_BARRIER();   // group 0 issued one barrier fewer
+    __syncthreads();
+
+    const int wm0 = grp * 128 + a_row0;
+    if (do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) P.rowsum[row] = accb[i][r];
+            }
+    }
+    float* cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
+                const int col = wn0 + j * 16 + (lane & 15);
+                cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    epilogue_rows<R_BM>(P, cs, m0, n0, tid);
+}
+
+int g_variant = -1;  // -1: read MEMEHIP_GEMM_VARIANT once; 0 = register staging, 1 = LDS-DMA, 2 = 256x128 ring
+
+template <int LA, int LB, int DMA>
+int launch1(const GemmGroup& g, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<LA, LB>), dim3(g.total_tiles), dim3(NTHREADS), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_kernel<LA, LB, DMA>), dim3(g.total_tiles), dim3(NTHREADS), LDS_BYTES, s, g);
     return mh_launch_status();
+}
+template <int LA, int LB>
+int launch_ring(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_ring_kernel<LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  R_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_ring_kernel<LA, LB>), dim3(g.total_tiles), dim3(R_THREADS), R_LDS, s, g);
+    return mh_launch_status();
+}
+template <int LA, int LB>
+int launch_pp(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  R_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_pp_kernel<LA, LB>), dim3(g.total_tiles), dim3(R_THREADS), R_LDS, s, g);
+    return mh_launch_status();
+}
+template <int LA, int LB>
+int launch(const GemmGroup& g, hipStream_t s) {
+    if (g_variant == 0) return launch1<LA, LB, 0>(g, s);
+    if (g_variant == 1) return launch1<LA, LB, 1>(g, s);
+    if (g_variant == 2) return launch_ring<LA, LB>(g, s);
+    return launch_pp<LA, LB>(g, s);
 }
 
 }  // namespace
@@ -290,6 +677,12 @@ int launch(const GemmGroup& g, hipStream_t s) {
 extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problems, int a_kmajor,
                                     int b_kmajor, mh_stream_t stream) {
     if (!problems || n_problems < 1 || n_problems > MH_GEMM_MAX_GROUP) return MH_EINVAL;
+    if (g_variant < 0) {
+        const char* e = getenv("MEMEHIP_GEMM_VARIANT");
+        g_variant = e ? atoi(e) : 1;
+        if (g_variant < 0 || g_variant > 3) g_variant = 1;
+    }
+    const int tile_m = g_variant >= 2 ? R_BM : BM;
     GemmGroup g;
     g.n = n_problems;
     int total = 0;
@@ -307,7 +700,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         g.d[i].p = p;
         g.d[i].tiles_n = p.N / BN;
         g.d[i].tile_start = total;
-        total += ((p.M + BM - 1) / BM) * (p.N / BN);
+        total += ((p.M + tile_m - 1) / tile_m) * (p.N / BN);
     }
     g.total_tiles = total;
     hipStream_t s = (hipStream_t)stream;
@@ -315,4 +708,11 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     if (!a_kmajor && b_kmajor) return launch<0, 1>(g, s);
     if (a_kmajor && b_kmajor) return launch<1, 1>(g, s);
     return MH_EINVAL;  // (1,0) is not needed by the path
+}
+
+// experiment knob (A/B in one process): 0 = register-staged tiles, 1 = LDS-DMA staged tiles
+extern "C" int mh_gemm_set_variant(int v) {
+    if (v < 0 || v > 3) return MH_EINVAL;
+    g_variant = v;
+    return MH_OK;
 }

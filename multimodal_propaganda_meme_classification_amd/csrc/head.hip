@@ -29,11 +29,15 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         float acc[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        // rows past M re-read row M-1 (masked at the store): unconditional loads let the compiler keep
+        // all 32 row loads of a k step in flight instead of 32 dependent L2 round trips
         for (int k = lane; k < K; k += 64) {
             const float wk = w[k];
+            float xv[RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
-                if (m0 + r < M) acc[r] += wk * x[(size_t)(m0 + r) * ldx + k];
+            for (int r = 0; r < RB; ++r) xv[r] = x[(size_t)min(m0 + r, M - 1) * ldx + k];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] += wk * xv[r];
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {

@@ -1,0 +1,133 @@
+"""JSON loader + Dataset with the reference's surface (example_scripts/Multimodal_example_task2C.txt:28-104).
+
+``read_data`` and ``MultimodalDataset`` keep the reference's names, argument order and batch-dict
+keys (``id, text, text_mask, image[, label]``) so its DataLoader / train loop work unchanged.
+Differences forced by the offline environment, all opt-in via keyword arguments:
+  * tokenizer: the reference downloads ``AutoTokenizer.from_pretrained(...)``; pass any object with
+    ``encode_plus`` (a transformers tokenizer works), or leave None for ``HashTokenizer`` (a
+    deterministic whitespace/hash stand-in: [CLS]=2, [SEP]=3, [PAD]=0).
+  * images: torchvision is not installed; Resize(256) -> CenterCrop(224) -> ToTensor -> Normalize
+    is restated with PIL + numpy.  ``synthetic_images=True`` replaces missing files (the task's
+    image archive is not in the repository) by a deterministic pseudo-image per id.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+l2id = {"not_propaganda": 0, "propaganda": 1}          # ...task2C.txt:107
+id2l = {0: "not_propaganda", 1: "propaganda"}           # ...task2C.txt:277
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)                   # ...task2C.txt:40
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def read_data(fpath: str, is_test: bool = False):
+    """JSON list-of-dicts -> pandas DataFrame with columns id, text, image[, label] (...task2C.txt:88-104)."""
+    import pandas as pd
+    js_obj = json.load(open(fpath, encoding="utf-8"))
+    data = {"id": [], "text": [], "image": []}
+    if not is_test:
+        data["label"] = []
+    for obj in js_obj:
+        data["id"].append(obj["id"])
+        data["image"].append(obj["img_path"])
+        data["text"].append(obj["text"])
+        if not is_test:
+            data["label"].append(obj["class_label"])
+    return pd.DataFrame.from_dict(data)
+
+
+class HashTokenizer:
+    """Offline stand-in for a WordPiece tokenizer: whitespace tokens hashed into [5, vocab)."""
+
+    cls_token_id, sep_token_id, pad_token_id = 2, 3, 0
+
+    def __init__(self, vocab_size: int = 64000):
+        self.vocab_size = vocab_size
+
+    def _id(self, tok: str) -> int:
+        h = int.from_bytes(hashlib.blake2s(tok.encode("utf-8"), digest_size=8).digest(), "little")
+        return 5 + h % (self.vocab_size - 5)
+
+    def encode_plus(self, text, add_special_tokens=True, max_length=128, padding="max_length", truncation=True,
+                    return_attention_mask=True, return_tensors="pt", **_):
+        ids = [self._id(t) for t in str(text).split()]
+        room = max_length - (2 if add_special_tokens else 0)
+        ids = ids[:room]
+        if add_special_tokens:
+            ids = [self.cls_token_id] + ids + [self.sep_token_id]
+        mask = [1] * len(ids)
+        pad = max_length - len(ids)
+        ids += [self.pad_token_id] * pad
+        mask += [0] * pad
+        return {"input_ids": torch.tensor([ids], dtype=torch.long), "attention_mask": torch.tensor([mask], dtype=torch.long)}
+
+
+def load_image(path: str, image_size: int = 224, resize: int = 256) -> torch.Tensor:
+    """PIL restatement of Resize(256) -> CenterCrop(224) -> ToTensor -> Normalize(ImageNet)."""
+    from PIL import Image
+    img = Image.open(path).convert("RGB")
+    w, h = img.size
+    if w <= h:
+        nw, nh = resize, max(1, int(round(h * resize / w)))
+    else:
+        nw, nh = max(1, int(round(w * resize / h))), resize
+    img = img.resize((nw, nh), Image.BILINEAR)
+    left, top = (nw - image_size) // 2, (nh - image_size) // 2
+    img = img.crop((left, top, left + image_size, top + image_size))
+    x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
+    mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+    return (x - mean) / std
+
+
+def synthetic_image(key: str, image_size: int = 224) -> torch.Tensor:
+    seed = int.from_bytes(hashlib.blake2s(key.encode("utf-8"), digest_size=8).digest(), "little") % (2 ** 31)
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn((3, image_size, image_size), generator=g)
+
+
+class MultimodalDataset(Dataset):
+    """Same constructor order as the reference: (ids, text_data, image_data, labels, is_test=False)."""
+
+    def __init__(self, ids: Sequence, text_data: Sequence, image_data: Sequence, labels: Optional[Sequence],
+                 is_test: bool = False, tokenizer=None, max_seq_len: int = 128, image_size: int = 224,
+                 image_root: str = "", synthetic_images: bool = False, vocab_size: int = 64000):
+        self.ids = list(ids)
+        self.text_data = list(text_data)
+        self.image_data = list(image_data)
+        self.labels = None if labels is None else list(labels)
+        self.is_test = is_test
+        self.tokenizer = tokenizer if tokenizer is not None else HashTokenizer(vocab_size)
+        self.max_seq_len = max_seq_len
+        self.image_size = image_size
+        self.image_root = image_root
+        self.synthetic_images = synthetic_images
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, index):
+        id_ = self.ids[index]
+        enc = self.tokenizer.encode_plus(self.text_data[index], add_special_tokens=True, max_length=self.max_seq_len,
+                                         padding="max_length", truncation=True, return_attention_mask=True,
+                                         return_tensors="pt")
+        path = os.path.join(self.image_root, self.image_data[index])
+        if os.path.exists(path):
+            image = load_image(path, self.image_size)
+        elif self.synthetic_images:
+            image = synthetic_image(str(id_), self.image_size)
+        else:
+            raise FileNotFoundError(f"{path} (pass synthetic_images=True to run without the image archive)")
+        fdata = {"id": id_, "text": enc["input_ids"].squeeze(0), "text_mask": enc["attention_mask"].squeeze(0),
+                 "image": image}
+        if not self.is_test:
+            fdata["label"] = torch.tensor(self.labels[index], dtype=torch.long)
+        return fdata

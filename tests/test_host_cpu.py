@@ -1,0 +1,141 @@
+"""Host-side logic that needs no GPU: JSON loader / Dataset surface, TSV format, flat parameter
+layout, gradient-bucket cover, and the world_size-2 gloo all-reduce path of the DDP reducer."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import multimodal_propaganda_meme_classification_amd as pkg
+from multimodal_propaganda_meme_classification_amd import ddp
+from multimodal_propaganda_meme_classification_amd.config import Layout
+
+# the task's format checker regex, restated (format_checker/task2.py:20)
+LINE = re.compile(r'^([\w:]+\/.*?\.[\w:]+)\t(propaganda|not_propaganda)\t[\w-]+')
+
+
+def _tiny_cfg():
+    return pkg.ModelConfig(text=pkg.TextConfig(vocab_size=512, hidden=128, layers=2, heads=2, intermediate=256, max_position=64),
+                           image=pkg.ImageConfig(image_size=32, hidden=128, layers=2, heads=2, intermediate=256), proj=128)
+
+
+def test_read_data_and_dataset_surface(golden_dir):
+    df = pkg.read_data(os.path.join(golden_dir, "dev_sample12.json"))
+    assert list(df.columns) == ["id", "text", "image", "label"] and len(df) == 12
+    assert list(pkg.read_data(os.path.join(golden_dir, "dev_sample12.json"), is_test=True).columns) == ["id", "text", "image"]
+    labels = df["label"].map(pkg.l2id)
+    ds = pkg.MultimodalDataset(df["id"], df["text"], df["image"], labels, max_seq_len=32, image_size=32, synthetic_images=True,
+                               vocab_size=512)
+    assert len(ds) == 12
+    item = ds[3]
+    assert set(item) == {"id", "text", "text_mask", "image", "label"}
+    assert item["text"].dtype == torch.int64 and item["text"].shape == (32,)
+    assert item["text_mask"].dtype == torch.int64 and item["image"].shape == (3, 32, 32) and item["image"].dtype == torch.float32
+    n = int(item["text_mask"].sum())
+    assert item["text"][0] == 2 and item["text"][n - 1] == 3 and (item["text"][n:] == 0).all()      # [CLS] .. [SEP] PAD..
+    assert int(item["text"].max()) < 512
+    assert torch.equal(ds[3]["image"], item["image"])                                              # deterministic
+    assert "label" not in pkg.MultimodalDataset(df["id"], df["text"], df["image"], None, is_test=True, synthetic_images=True)[0]
+    with pytest.raises(FileNotFoundError):
+        pkg.MultimodalDataset(df["id"], df["text"], df["image"], labels)[0]
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=4)))
+    assert batch["text"].shape == (4, 32) and batch["image"].shape == (4, 3, 32, 32) and len(batch["id"]) == 4
+
+
+def test_tsv_lines_pass_the_task_format(tmp_path, golden_dir):
+    df = pkg.read_data(os.path.join(golden_dir, "dev_sample12.json"))
+    for id_ in df["id"]:
+        for lab in pkg.id2l.values():
+            assert LINE.match(f"{id_}\t{lab}\tViT-BERT-memehip")
+
+
+def test_image_transform_matches_definition(tmp_path):
+    from PIL import Image
+    from multimodal_propaganda_meme_classification_amd.data import load_image
+    arr = (np.arange(300 * 400 * 3) % 251).astype(np.uint8).reshape(300, 400, 3)
+    path = str(tmp_path / "x.png")
+    Image.fromarray(arr).save(path)
+    x = load_image(path)
+    assert x.shape == (3, 224, 224)
+    ref = Image.open(path).convert("RGB").resize((341, 256), Image.BILINEAR)            # shorter side -> 256
+    ref = np.asarray(ref.crop((58, 16, 58 + 224, 16 + 224)), dtype=np.float32) / 255.0
+    ref = (ref - np.array([0.485, 0.456, 0.406], dtype=np.float32)) / np.array([0.229, 0.224, 0.225], dtype=np.float32)
+    np.testing.assert_allclose(x.numpy(), ref.transpose(2, 0, 1), atol=1e-6)
+
+
+def test_layout_config3():
+    lay = Layout(pkg.ModelConfig())
+    real = sum(s.numel for s in lay.specs)
+    assert abs(real - 221.7e6) < 0.1e6
+    assert lay.n_total - real < 16                         # only alignment padding
+    for s in lay.specs:
+        assert s.offset % 4 == 0
+    q = lay.spec["bert.encoder.layer.3.attention.self.query.weight"]
+    k = lay.spec["bert.encoder.layer.3.attention.self.key.weight"]
+    v = lay.spec["bert.encoder.layer.3.attention.self.value.weight"]
+    assert k.offset == q.offset + q.numel and v.offset == k.offset + k.numel       # fused QKV operand is a slice
+    qb = lay.spec["image_model.encoder.layer.0.attention.attention.query.bias"]
+    kb = lay.spec["image_model.encoder.layer.0.attention.attention.key.bias"]
+    assert kb.offset == qb.offset + qb.numel
+    assert lay.n_shadow == 2 * 12 * (4 * 768 * 768 + 2 * 768 * 3072) + 768 * 768
+    # gradient buckets (one per layer pair, then everything else) tile the flat buffer exactly once
+    buckets = {f"bwd_layer_{l}": (a, b) for l, a, b in lay.layer_ranges}
+    buckets["bwd_embed"] = (lay.layer_ranges[-1][2], lay.n_total)
+    ddp.check_bucket_cover(buckets, lay.n_total)
+    with pytest.raises(AssertionError):
+        ddp.check_bucket_cover({"a": (0, 10), "b": (12, 20)}, 20)
+    names = lay.state_dict_order()
+    assert names[0] == "bert.embeddings.word_embeddings.weight" and names[-1] == "output_fc.bias"
+
+
+def test_module_protocol_on_cpu():
+    m = pkg.MultimodalClassifier.from_config(_tiny_cfg(), seed=3)
+    sd = m.state_dict()
+    assert list(sd) == m.layout.state_dict_order()
+    assert len(list(m.parameters())) == len(sd)
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in m.parameters())
+    m2 = pkg.MultimodalClassifier.from_config(_tiny_cfg(), init=False)
+    m2.load_state_dict({("resnet_fc" + k[8:] if k.startswith("image_fc") else k): v for k, v in sd.items()})   # alias
+    assert torch.equal(m2.flat_params, m.flat_params)
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict({"bert_fc.weight": sd["bert_fc.weight"]})
+    with pytest.raises(ValueError):
+        pkg.ModelConfig(pool="max").validate()                 # "Unsupported pooling type" like the reference
+    with pytest.raises(TypeError):
+        m.half()
+    with pytest.raises(pkg.MemehipError):
+        m(torch.zeros((1, 8), dtype=torch.long), torch.zeros((1, 3, 32, 32)), torch.ones((1, 8), dtype=torch.long))
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1000
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        red = ddp.GradientReducer(g, bucket_cap_elems=128)
+        for rng in ((0, 300), (300, 301), (301, 1000)):         # ragged buckets, issued in order
+            red.hook("seg", rng)
+        red.hook("none", None)
+        red.wait()
+        want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        ok = torch.equal(g, want) and red.grad_scale == 1.0 / world and red.reduced_elems == n
+        p = torch.full((16,), float(rank))
+        ddp.broadcast_parameters(p, src=0)
+        ok = ok and bool((p == 0).all())
+        out[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_reducer_gloo_world2():
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
