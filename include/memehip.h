@@ -5,6 +5,12 @@
  * entry point below names the reference call site whose implied kernel it replaces
  * (paths relative to /root/reference/example_scripts).  INTEGRATION.md shows the ctypes binding.
  *
+ * Two builds of the same sources export this ABI: libmemehip.so stores 16-bit tensors as bfloat16
+ * ("bf16" below), libmemehip_f16.so (-DMH_FP16) as IEEE half with the same MFMA rate.  Gradient
+ * streams of the 16-bit towers may carry a power-of-two scale (needed for half): it enters through
+ * mh_head_bwd(out_scale) and is removed where parameter gradients are produced (MhGemmProblem.alpha,
+ * the `scale` arguments below), so every f32 gradient buffer holds true gradients.
+ *
  * Conventions
  *   - every pointer is a DEVICE pointer unless marked "host"; no ownership transfer, no
  *     allocation, no synchronisation inside; work is enqueued on `stream` (a hipStream_t).
@@ -71,7 +77,7 @@ typedef struct MhGemmProblem {
     int32_t M, N, K;
     int32_t lda, ldb, ldc;
     int32_t flags;
-    int32_t reserved;
+    float alpha;          /* accumulator scale applied first (0 means 1): un-scales 16-bit gradient streams */
 } MhGemmProblem;
 
 int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems, int a_kmajor,
@@ -106,7 +112,7 @@ typedef struct MhColsumJob {
     float* out1;       /* [D] dbeta  */
 } MhColsumJob;
 int mh_colsum_partials_f32(const MhColsumJob* jobs /*host*/, int n_jobs, int n_part, int D,
-                           mh_stream_t stream);
+                           float scale, mh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-head attention (head dim 64), flash-style, bf16 in / f32 softmax.
@@ -137,7 +143,7 @@ int mh_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, c
                       float eps, mh_stream_t stream);
 int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre /*bf16 [T][D]*/, float* dword /*[V][D]*/,
                       float* dpos /*[P][D]*/, float* dtype0 /*[D] or NULL*/, int B, int S, int D,
-                      int vocab, int64_t pad_id, mh_stream_t stream);
+                      int vocab, int64_t pad_id, float scale, mh_stream_t stream);
 /* zero the rows of dword named by ids (cheap re-zero of the dense table after the optimizer step) */
 int mh_zero_rows_f32(const int64_t* ids, float* table, int n_ids, int D, int vocab, mh_stream_t stream);
 
@@ -152,7 +158,7 @@ int mh_patchify(const float* image, void* patches, int B, int C, int H, int W, i
 int mh_vit_assemble_fwd(const void* proj /*bf16 [B*Np][D]*/, const float* cls, const float* pos,
                         void* x /*bf16 [B][Np+1][D]*/, int B, int Np, int D, mh_stream_t stream);
 int mh_vit_assemble_bwd(const void* dx /*bf16 [B][Np+1][D]*/, void* dproj /*bf16 [B*Np][D]*/,
-                        float* dcls, float* dpos, int B, int Np, int D, mh_stream_t stream);
+                        float* dcls, float* dpos, int B, int Np, int D, float scale, mh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Late-fusion head + cross-entropy, fp32 (Multimodal_example_task2C.txt:178-195, :248, :214):
@@ -184,7 +190,7 @@ int mh_head_bwd(const MhHeadParams* p /*host*/, const MhHeadGrads* g /*host*/, c
                 const float* pooled, const float* feat, const float* fused, float* dfeat /*[B][2P]*/,
                 float* dfused /*[B][P]*/, void* d_text_hidden /*bf16 [B][S][Dt]*/,
                 void* d_image_hidden /*bf16 [B][Nt][Di]*/, int text_pool_index, int B, int S, int Nt,
-                int Dt, int Di, int P, int C, mh_stream_t stream);
+                int Dt, int Di, int P, int C, float out_scale, mh_stream_t stream);
 int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
                   int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream);
 

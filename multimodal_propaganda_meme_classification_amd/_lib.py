@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmemehip.so")
+LIB_PATH = os.path.join(_HERE, "libmemehip.so")            # bf16 storage
+LIB_PATH_F16 = os.path.join(_HERE, "libmemehip_f16.so")    # fp16 storage (same kernels, -DMH_FP16)
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": LIB_PATH_F16}
 
 MH_GEMM_MAX_GROUP = 8
 MH_GEMM_GELU = 1
@@ -26,7 +28,7 @@ class MhGemmProblem(C.Structure):
                 ("residual", c_void_p), ("aux", c_void_p), ("mul", c_void_p), ("rowsum", c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
-                ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("flags", C.c_int32), ("alpha", C.c_float)]
 
 
 class MhColsumJob(C.Structure):
@@ -47,17 +49,17 @@ _PROTOS = {
     "mh_gemm_set_variant": [c_int],
     "mh_layernorm_fwd": [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p],
     "mh_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p],
-    "mh_colsum_partials_f32": [C.POINTER(MhColsumJob), c_int, c_int, c_int, c_void_p],
+    "mh_colsum_partials_f32": [C.POINTER(MhColsumJob), c_int, c_int, c_int, c_float, c_void_p],
     "mh_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p],
     "mh_attn_bwd": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p],
     "mh_bert_embed_fwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_void_p],
-    "mh_bert_embed_bwd": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int64, c_void_p],
+    "mh_bert_embed_bwd": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p],
     "mh_zero_rows_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mh_patchify": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
     "mh_vit_assemble_fwd": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
-    "mh_vit_assemble_bwd": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
+    "mh_vit_assemble_bwd": [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p],
     "mh_head_fwd": [C.POINTER(MhHeadParams), c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p],
-    "mh_head_bwd": [C.POINTER(MhHeadParams), C.POINTER(MhHeadGrads)] + [c_void_p] * 8 + [c_int] * 8 + [c_void_p],
+    "mh_head_bwd": [C.POINTER(MhHeadParams), C.POINTER(MhHeadGrads)] + [c_void_p] * 8 + [c_int] * 8 + [c_float, c_void_p],
     "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     "mh_adam_step": [c_void_p] * 5 + [c_int64, c_int64, c_void_p, c_int, c_void_p, c_float, c_void_p],
@@ -70,29 +72,32 @@ _RESTYPES = {"mh_version": C.c_char_p, "mh_status_str": C.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
-_lib = None
+_libs = {}
 
 
 class MemehipError(RuntimeError):
     pass
 
 
-def load() -> C.CDLL:
-    """Load libmemehip.so (once).  Raises MemehipError when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(kind: str = "bf16") -> C.CDLL:
+    """Load libmemehip.so (kind="bf16") or libmemehip_f16.so (kind="fp16"), once each.
+    Raises MemehipError when it has not been built."""
+    if kind in _libs:
+        return _libs[kind]
+    if kind not in LIB_PATHS:
+        raise ValueError(f"compute dtype must be 'bf16' or 'fp16', got {kind!r}")
+    path = LIB_PATHS[kind]
+    if not os.path.exists(path):
         raise MemehipError(
-            f"{LIB_PATH} is missing: build the HIP extension first "
+            f"{path} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C "
             "multimodal_propaganda_meme_classification_amd/csrc). There is no CPU/PyTorch fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
-    _lib = lib
+    _libs[kind] = lib
     return lib
 
 

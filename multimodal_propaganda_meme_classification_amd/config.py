@@ -57,11 +57,23 @@ class ModelConfig:
     proj: int = 512
     num_classes: int = 2
     pool: str = "cls"   # "cls" (Multimodal_example_task2C.py:359) | "last" (...task2C.txt:178)
+    # 16-bit storage / MFMA operand type of the towers: "bf16" (libmemehip.so) or "fp16"
+    # (libmemehip_f16.so: 11-bit significand, needs the power-of-two gradient-stream scale below,
+    # the static counterpart of the GradScaler in Multimodal_example_task2C.py:60-64,712-717)
+    compute_dtype: str = "bf16"
+    grad_stream_scale: float = 0.0      # 0 = automatic: 1 for bf16, 8192 for fp16
 
     @staticmethod
     def from_dict(d: dict) -> "ModelConfig":
         return ModelConfig(text=TextConfig(**d["text"]), image=ImageConfig(**d["image"]), proj=d["proj"],
-                           num_classes=d["num_classes"], pool=d["pool"])
+                           num_classes=d["num_classes"], pool=d["pool"], compute_dtype=d.get("compute_dtype", "bf16"),
+                           grad_stream_scale=d.get("grad_stream_scale", 0.0))
+
+    @property
+    def stream_scale(self) -> float:
+        if self.grad_stream_scale:
+            return float(self.grad_stream_scale)
+        return 8192.0 if self.compute_dtype == "fp16" else 1.0
 
     def to_dict(self) -> dict:
         return asdict(self)
@@ -69,6 +81,8 @@ class ModelConfig:
     def validate(self):
         if self.pool not in ("cls", "last"):
             raise ValueError(f"Unsupported pooling type: {self.pool}")
+        if self.compute_dtype not in ("bf16", "fp16"):
+            raise ValueError(f"compute_dtype must be 'bf16' or 'fp16', got {self.compute_dtype!r}")
         for nm, c in (("text", self.text), ("image", self.image)):
             if c.hidden % 128 or c.intermediate % 128:
                 raise ValueError(f"{nm}: hidden and intermediate sizes must be multiples of 128 (GEMM tile)")

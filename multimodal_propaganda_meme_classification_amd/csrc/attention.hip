@@ -29,9 +29,9 @@ constexpr float LN2 = 0.6931471805599453f;
 MH_DEV int row_img_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 MH_DEV int tr_img_off(int row, int unit) { return row * 128 + ((unit ^ (((row >> 1) & 1) << 1)) << 5); }
 
-// stage one [64][64] bf16 tile (rows row0.., clipped at nrows -> zeros) into a row image and/or tr image
+// stage one [64][64] h16 tile (rows row0.., clipped at nrows -> zeros) into a row image and/or tr image
 template <int NT>
-MH_DEV void stage_tile(const bf16* __restrict__ base, size_t pitch, int row0, int nrows, int tid,
+MH_DEV void stage_tile(const h16* __restrict__ base, size_t pitch, int row0, int nrows, int tid,
                        char* row_img, char* tr_img) {
 #pragma unroll
     for (int q = tid; q < TILE * 8; q += NT) {
@@ -44,14 +44,14 @@ MH_DEV void stage_tile(const bf16* __restrict__ base, size_t pitch, int row0, in
 }
 
 // A/B fragment from a row image: rows rb..rb+31 (lane&31), d = 16 s + 8 h + j
-MH_DEV bf16x8 frag_rows(const char* img, int rb, int s, int lane) {
+MH_DEV h16x8 frag_rows(const char* img, int rb, int s, int lane) {
     Pack8 u;
     u.v = *(const i32x4*)(img + row_img_off(rb + (lane & 31), 2 * s + (lane >> 5)));
     return u.h;
 }
 // A fragment of the TRANSPOSED tile: result row = d (dbase + lane&31), k = tile rows in the
 // accumulator-operand order row(s,h,j) within the 32-row block starting at rb.
-MH_DEV bf16x8 frag_tr(const char* img, int rb, int s, int dbase, int lane) {
+MH_DEV h16x8 frag_tr(const char* img, int rb, int s, int dbase, int lane) {
     const int i = lane & 15, q = i >> 2, p = i & 3;
     const int chalf = (lane >> 4) & 1, h = lane >> 5;
     const int unit = (dbase >> 4) + chalf;
@@ -61,25 +61,25 @@ MH_DEV bf16x8 frag_tr(const char* img, int rb, int s, int dbase, int lane) {
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, img + tr_img_off(r1, unit) + 8 * p));
     union {
         struct { s16x4 lo, hi; } s;
-        bf16x8 h8;
+        h16x8 h8;
     } cv;
     cv.s.lo = lo;
     cv.s.hi = hi;
     return cv.h8;
 }
-// registers 8s..8s+7 of a 32x32 accumulator as a bf16 operand fragment
-MH_DEV bf16x8 acc_frag(const f32x16& x, int s) {
-    bf16x8 f;
+// registers 8s..8s+7 of a 32x32 accumulator as a h16 operand fragment
+MH_DEV h16x8 acc_frag(const f32x16& x, int s) {
+    h16x8 f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (bf16)x[8 * s + j];
+    for (int j = 0; j < 8; ++j) f[j] = (h16)x[8 * s + j];
     return f;
 }
 // row index inside a 32x32 accumulator of register g for lane half h
 MH_DEV int acc_row(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
 // 32 rows x 64 d fragment straight from global: row (lane&31), d = 16 s + 8 h + j ; zero when row >= nrows
-MH_DEV void load_rows_frag(const bf16* __restrict__ base, size_t pitch, int row0, int nrows, int lane,
-                           bf16x8 (&f)[4]) {
+MH_DEV void load_rows_frag(const h16* __restrict__ base, size_t pitch, int row0, int nrows, int lane,
+                           h16x8 (&f)[4]) {
     const int r = row0 + (lane & 31);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -91,7 +91,7 @@ MH_DEV void load_rows_frag(const bf16* __restrict__ base, size_t pitch, int row0
 }
 
 // store a transposed result X^T (two 32x32 accumulators = 64 d x 32 rows; lane = row, regs = d)
-MH_DEV void store_rows_from_T(bf16* __restrict__ base, size_t pitch, int row0, int nrows, int lane,
+MH_DEV void store_rows_from_T(h16* __restrict__ base, size_t pitch, int row0, int nrows, int lane,
                               const f32x16 (&acc)[2], float scale) {
     const int r = row0 + (lane & 31), h = lane >> 5;
     if (r >= nrows) return;
@@ -101,7 +101,7 @@ MH_DEV void store_rows_from_T(bf16* __restrict__ base, size_t pitch, int row0, i
         for (int g4 = 0; g4 < 4; ++g4) {
             Pack4 u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) u.e[e] = (bf16)(acc[dt][4 * g4 + e] * scale);
+            for (int e = 0; e < 4; ++e) u.e[e] = (h16)(acc[dt][4 * g4 + e] * scale);
             *(i32x2*)(base + (size_t)r * pitch + dt * 32 + 8 * g4 + 4 * h) = u.v;
         }
 }
@@ -112,9 +112,9 @@ MH_DEV void store_rows_from_T(bf16* __restrict__ base, size_t pitch, int row0, i
 // NT_RES == 0: streaming fallback for long sequences (one K/V tile resident at a time).
 // ----------------------------------------------------------------------------------------------
 template <int NW, int NT_RES>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict__ qkv,
                                                            const int64_t* __restrict__ key_mask,
-                                                           bf16* __restrict__ out, float* __restrict__ lse,
+                                                           h16* __restrict__ out, float* __restrict__ lse,
                                                            int B, int S, int H) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
@@ -127,9 +127,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16* __restric
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
-    const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
-    const bf16* kb = qb + (size_t)H * HD;
-    const bf16* vb = qb + (size_t)2 * H * HD;
+    const h16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    const h16* kb = qb + (size_t)H * HD;
+    const h16* vb = qb + (size_t)2 * H * HD;
     const float c = 0.125f * LOG2E;  // 1/sqrt(64) folded with log2(e)
     const int ntiles = (S + TILE - 1) / TILE;
 
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16* __restric
          qt += NW * gridDim.x) {
         const int wq0 = qt * 32;
         const bool active = wq0 < S;
-        bf16x8 qf[4];
+        h16x8 qf[4];
         load_rows_frag(qb, pitch, wq0, S, lane, qf);
         f32x16 o[2];
 #pragma unroll
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16* __restric
                 for (int g = 0; g < 16; ++g) st[g] = 0.f;
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ki, sub * 32, s, lane), qf[s], st, 0, 0, 0);
+                    st = MH_MFMA_32x32x16(frag_rows(ki, sub * 32, s, lane), qf[s], st, 0, 0, 0);
                 float mx = NEG_BIG;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -216,10 +216,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16* __restric
                     for (int g = 0; g < 16; ++g) o[i][g] *= alpha;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 pf = acc_frag(st, s);
+                    const h16x8 pf = acc_frag(st, s);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(vi, sub * 32, s, dt * 32, lane), pf, o[dt], 0, 0, 0);
+                        o[dt] = MH_MFMA_32x32x16(frag_tr(vi, sub * 32, s, dt * 32, lane), pf, o[dt], 0, 0, 0);
                 }
             }
         }
@@ -233,14 +233,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16* __restric
 }
 
 // delta[b][h][s] = sum_d dout * out
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ out,
-                                                         const bf16* __restrict__ dout,
+__global__ __launch_bounds__(256) void attn_delta_kernel(const h16* __restrict__ out,
+                                                         const h16* __restrict__ dout,
                                                          float* __restrict__ delta, int B, int S, int H) {
     const int idx = blockIdx.x * 256 + threadIdx.x;  // (b, s, h)
     if (idx >= B * S * H) return;
     const int hh = idx % H, bs = idx / H, s = bs % S, b = bs / S;
-    const bf16* o = out + (size_t)idx * HD;
-    const bf16* d = dout + (size_t)idx * HD;
+    const h16* o = out + (size_t)idx * HD;
+    const h16* d = dout + (size_t)idx * HD;
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -257,12 +257,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 // backward, dQ:  one wave = 32 queries at a time, sweep key tiles (resident K/V when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
 template <int NW, int NT_RES>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restrict__ qkv,
                                                               const int64_t* __restrict__ key_mask,
-                                                              const bf16* __restrict__ dout,
+                                                              const h16* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
-                                                              bf16* __restrict__ dqkv, int B, int S, int H) {
+                                                              h16* __restrict__ dqkv, int B, int S, int H) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,10 +275,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __rest
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
-    const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
-    const bf16* kb = qb + (size_t)H * HD;
-    const bf16* vb = qb + (size_t)2 * H * HD;
-    const bf16* dob = dout + (size_t)b * S * H * HD + hh * HD;
+    const h16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    const h16* kb = qb + (size_t)H * HD;
+    const h16* vb = qb + (size_t)2 * H * HD;
+    const h16* dob = dout + (size_t)b * S * H * HD + hh * HD;
     const float c = 0.125f * LOG2E;
     const int ntiles = (S + TILE - 1) / TILE;
 
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __rest
         const int wq0 = qt * 32;
         const bool active = wq0 < S;
         const int q = wq0 + (lane & 31);
-        bf16x8 qf[4], dof[4];
+        h16x8 qf[4], dof[4];
         load_rows_frag(qb, pitch, wq0, S, lane, qf);
         load_rows_frag(dob, (size_t)H * HD, wq0, S, lane, dof);
         float lse2 = 0.f, dl = 0.f;
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __rest
                 for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ki, sub * 32, s, lane), qf[s], st, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vi, sub * 32, s, lane), dof[s], dp, 0, 0, 0);
+                    st = MH_MFMA_32x32x16(frag_rows(ki, sub * 32, s, lane), qf[s], st, 0, 0, 0);
+                    dp = MH_MFMA_32x32x16(frag_rows(vi, sub * 32, s, lane), dof[s], dp, 0, 0, 0);
                 }
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -356,10 +356,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __rest
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 df = acc_frag(st, s);
+                    const h16x8 df = acc_frag(st, s);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
-                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(kti, sub * 32, s, dt * 32, lane), df, dq[dt], 0, 0, 0);
+                        dq[dt] = MH_MFMA_32x32x16(frag_tr(kti, sub * 32, s, dt * 32, lane), df, dq[dt], 0, 0, 0);
                 }
             }
         }
@@ -372,12 +372,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16* __rest
 // backward, dK / dV:  one wave = 32 keys at a time, sweep query tiles (resident Q/dO when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
 template <int NW, int NT_RES>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __restrict__ qkv,
                                                                const int64_t* __restrict__ key_mask,
-                                                               const bf16* __restrict__ dout,
+                                                               const h16* __restrict__ dout,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
-                                                               bf16* __restrict__ dqkv, int B, int S, int H) {
+                                                               h16* __restrict__ dqkv, int B, int S, int H) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16* __res
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
-    const bf16* qb = qkv + (size_t)b * S * pitch + hh * HD;
-    const bf16* kb = qb + (size_t)H * HD;
-    const bf16* vb = qb + (size_t)2 * H * HD;
-    const bf16* dob = dout + (size_t)b * S * H * HD + hh * HD;
+    const h16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    const h16* kb = qb + (size_t)H * HD;
+    const h16* vb = qb + (size_t)2 * H * HD;
+    const h16* dob = dout + (size_t)b * S * H * HD + hh * HD;
     const float c = 0.125f * LOG2E;
     const int ntiles = (S + TILE - 1) / TILE;
 
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16* __res
         const int wk0 = kt * 32;
         const bool active = wk0 < S;
         const int key = wk0 + (lane & 31);
-        bf16x8 kf[4], vf[4];
+        h16x8 kf[4], vf[4];
         load_rows_frag(kb, pitch, wk0, S, lane, kf);
         load_rows_frag(vb, pitch, wk0, S, lane, vf);
         float kbias = NEG_BIG;
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16* __res
                 for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qi, sub * 32, s, lane), kf[s], st, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(doi, sub * 32, s, lane), vf[s], dp, 0, 0, 0);
+                    st = MH_MFMA_32x32x16(frag_rows(qi, sub * 32, s, lane), kf[s], st, 0, 0, 0);
+                    dp = MH_MFMA_32x32x16(frag_rows(doi, sub * 32, s, lane), vf[s], dp, 0, 0, 0);
                 }
                 f32x16 pp;
 #pragma unroll
@@ -473,19 +473,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16* __res
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 pf = acc_frag(pp, s);
-                    const bf16x8 df = acc_frag(st, s);
+                    const h16x8 pf = acc_frag(pp, s);
+                    const h16x8 df = acc_frag(st, s);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(doti, sub * 32, s, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-                        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(qti, sub * 32, s, dt * 32, lane), df, dk[dt], 0, 0, 0);
+                        dv[dt] = MH_MFMA_32x32x16(frag_tr(doti, sub * 32, s, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                        dk[dt] = MH_MFMA_32x32x16(frag_tr(qti, sub * 32, s, dt * 32, lane), df, dk[dt], 0, 0, 0);
                     }
                 }
             }
         }
         if (!active) continue;
-        bf16* dkb = dqkv + (size_t)b * S * pitch + (size_t)H * HD + hh * HD;
-        bf16* dvb = dqkv + (size_t)b * S * pitch + (size_t)2 * H * HD + hh * HD;
+        h16* dkb = dqkv + (size_t)b * S * pitch + (size_t)H * HD + hh * HD;
+        h16* dvb = dqkv + (size_t)b * S * pitch + (size_t)2 * H * HD + hh * HD;
         store_rows_from_T(dkb, pitch, wk0, S, lane, dk, 0.125f);
         store_rows_from_T(dvb, pitch, wk0, S, lane, dv, 1.0f);
     }
@@ -510,20 +510,20 @@ extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, 
     if (!qkv || !out || !lse) return MH_EINVAL;
     if (B < 1 || S < 1 || H < 1) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const bf16* q = (const bf16*)qkv;
+    const h16* q = (const h16*)qkv;
     if (S <= 128) {
         constexpr int L = 2 * 2 * IMG + 2 * TILE * 4 + 64;
         static bool once = (set_lds(attn_fwd_kernel<4, 2>, L), true);
         (void)once;
-        hipLaunchKernelGGL((attn_fwd_kernel<4, 2>), dim3(split_for(S), B * H), dim3(256), L, s, q, key_mask, (bf16*)out, lse, B, S, H);
+        hipLaunchKernelGGL((attn_fwd_kernel<4, 2>), dim3(split_for(S), B * H), dim3(256), L, s, q, key_mask, (h16*)out, lse, B, S, H);
     } else if (S <= 256) {
         constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
         static bool once = (set_lds(attn_fwd_kernel<4, 4>, L), true);
         (void)once;
-        hipLaunchKernelGGL((attn_fwd_kernel<4, 4>), dim3(split_for(S), B * H), dim3(256), L, s, q, key_mask, (bf16*)out, lse, B, S, H);
+        hipLaunchKernelGGL((attn_fwd_kernel<4, 4>), dim3(split_for(S), B * H), dim3(256), L, s, q, key_mask, (h16*)out, lse, B, S, H);
     } else {
         constexpr int L = 2 * IMG + TILE * 4 + 64;
-        hipLaunchKernelGGL((attn_fwd_kernel<4, 0>), dim3((S + 127) / 128, B * H), dim3(256), L, s, q, key_mask, (bf16*)out, lse, B, S, H);
+        hipLaunchKernelGGL((attn_fwd_kernel<4, 0>), dim3((S + 127) / 128, B * H), dim3(256), L, s, q, key_mask, (h16*)out, lse, B, S, H);
     }
     return mh_launch_status();
 }
@@ -535,11 +535,11 @@ extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void*
     if (B < 1 || S < 1 || H < 1) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int n = B * S * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16*)out,
-                       (const bf16*)dout, delta, B, S, H);
-    const bf16* q = (const bf16*)qkv;
-    const bf16* dO = (const bf16*)dout;
-    bf16* dq = (bf16*)dqkv;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const h16*)out,
+                       (const h16*)dout, delta, B, S, H);
+    const h16* q = (const h16*)qkv;
+    const h16* dO = (const h16*)dout;
+    h16* dq = (h16*)dqkv;
     if (S <= 128) {
         constexpr int L1 = 3 * 2 * IMG + 2 * TILE * 4 + 64, L2 = 4 * 2 * IMG + 2 * 2 * TILE * 4;
         static bool once = (set_lds(attn_bwd_dq_kernel<4, 2>, L1), set_lds(attn_bwd_dkv_kernel<4, 2>, L2), true);

@@ -4,10 +4,22 @@
 #include <stdint.h>
 #include "../../include/memehip.h"
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The 16-bit storage / MFMA operand type.  Default build: bfloat16 (libmemehip.so).  -DMH_FP16 builds the
+// same kernels on IEEE half (libmemehip_f16.so): same MFMA rate, 11-bit significand instead of 8.
+#ifdef MH_FP16
+typedef _Float16 h16;
+#define MH_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#define MH_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#define MH_DTYPE_NAME "fp16"
+#else
+typedef __bf16 h16;
+#define MH_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#define MH_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#define MH_DTYPE_NAME "bf16"
+#endif
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,18 +41,18 @@ MH_DEV void mh_buf_store16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, i32x4 v)
     __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);
 }
 
-MH_DEV float mh_bf2f(bf16 x) { return (float)x; }
-MH_DEV bf16 mh_f2bf(float x) { return (bf16)x; }
+MH_DEV float mh_bf2f(h16 x) { return (float)x; }
+MH_DEV h16 mh_f2bf(float x) { return (h16)x; }
 
 union Pack8 {
     i32x4 v;
-    bf16x8 h;
-    bf16 e[8];
+    h16x8 h;
+    h16 e[8];
 };
 union Pack4 {
     i32x2 v;
-    bf16x4 h;
-    bf16 e[4];
+    h16x4 h;
+    h16 e[4];
 };
 
 MH_DEV float wave_sum(float v) {
@@ -55,7 +67,7 @@ MH_DEV float wave_max(float v) {
 }
 
 // erf-GELU and its derivative in fp32.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below
-// the bf16 rounding of the result): one v_rcp, one v_exp, five FMAs instead of libm erff's ~40 ops,
+// the h16 rounding of the result): one v_rcp, one v_exp, five FMAs instead of libm erff's ~40 ops,
 // and gelu' re-uses the same exponential (exp(-x^2/2) is both erf's tail and the Gaussian pdf).
 struct GeluParts {
     float cdf;  // 0.5 (1 + erf(x / sqrt 2))

@@ -10,7 +10,7 @@ template <int NCH>
 __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
     const float* __restrict__ type0, const float* __restrict__ gamma, const float* __restrict__ beta,
-    bf16* __restrict__ pre, bf16* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int T, int S,
+    h16* __restrict__ pre, h16* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int T, int S,
     int D, int vocab, float eps) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -77,9 +77,9 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(
 // duplicates in position order (bitwise reproducible, no atomics) -----------------------------------
 template <int NCH>
 __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const int64_t* __restrict__ ids,
-                                                                  const bf16* __restrict__ d_pre,
+                                                                  const h16* __restrict__ d_pre,
                                                                   float* __restrict__ dword, int T, int D,
-                                                                  int vocab, int64_t pad_id) {
+                                                                  int vocab, int64_t pad_id, float scale) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const int64_t*
         while (m) {
             const int bit = __builtin_ctzll(m);
             m &= m - 1;
-            const bf16* row = d_pre + (size_t)(c0 + bit) * D;
+            const h16* row = d_pre + (size_t)(c0 + bit) * D;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c = (lane + 64 * i) * 8;
@@ -121,16 +121,16 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const int64_t*
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
         if (c < D) {
-            *(f32x4*)(out + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-            *(f32x4*)(out + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+            *(f32x4*)(out + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]} * scale;
+            *(f32x4*)(out + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]} * scale;
         }
     }
 }
 
 // dpos[s] = sum_b d[b][s]  (rows: tokens per sample = S, B samples); one wave per s
 template <int NCH>
-__global__ __launch_bounds__(256) void sum_over_batch_kernel(const bf16* __restrict__ d, float* __restrict__ out,
-                                                             int B, int S, int D) {
+__global__ __launch_bounds__(256) void sum_over_batch_kernel(const h16* __restrict__ d, float* __restrict__ out,
+                                                             int B, int S, int D, float scale) {
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= S) return;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void sum_over_batch_kernel(const bf16* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
     for (int b = 0; b < B; ++b) {
-        const bf16* row = d + ((size_t)b * S + s) * D;
+        const h16* row = d + ((size_t)b * S + s) * D;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = (lane + 64 * i) * 8;
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void sum_over_batch_kernel(const bf16* __restr
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
         if (c < D) {
-            *(f32x4*)(o + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-            *(f32x4*)(o + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+            *(f32x4*)(o + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]} * scale;
+            *(f32x4*)(o + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]} * scale;
         }
     }
 }
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(const int64_t* __restric
     for (int c = lane * 4; c < D; c += 256) *(f32x4*)(row + c) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// ---- ViT: im2col gather (f32 image -> bf16 patch rows), 8 outputs per thread ---------------------
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B,
+// ---- ViT: im2col gather (f32 image -> h16 patch rows), 8 outputs per thread ---------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, h16* __restrict__ out, int B,
                                                        int C, int H, int W, int P) {
     const int gh = H / P, gw = W / P, Kp = C * P * P;
     const size_t total = (size_t)B * gh * gw * (Kp / 8);
@@ -204,9 +204,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     *(i32x4*)(out + row * Kp + col) = u.v;
 }
 
-__global__ __launch_bounds__(256) void vit_assemble_fwd_kernel(const bf16* __restrict__ proj,
+__global__ __launch_bounds__(256) void vit_assemble_fwd_kernel(const h16* __restrict__ proj,
                                                                const float* __restrict__ cls,
-                                                               const float* __restrict__ pos, bf16* __restrict__ x,
+                                                               const float* __restrict__ pos, h16* __restrict__ x,
                                                                int B, int Np, int D) {
     const int NT = Np + 1;
     const size_t total = (size_t)B * NT * (D / 8);
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256) void vit_assemble_fwd_kernel(const bf16* __res
     *(i32x4*)(x + tok * D + c) = o.v;
 }
 
-__global__ __launch_bounds__(256) void vit_assemble_bwd_copy_kernel(const bf16* __restrict__ dx,
-                                                                    bf16* __restrict__ dproj, int B, int Np,
+__global__ __launch_bounds__(256) void vit_assemble_bwd_copy_kernel(const h16* __restrict__ dx,
+                                                                    h16* __restrict__ dproj, int B, int Np,
                                                                     int D) {
     const size_t total = (size_t)B * Np * (D / 8);
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -262,19 +262,19 @@ extern "C" int mh_bert_embed_fwd(const int64_t* ids, const float* word, const fl
     const int T = B * S;
     hipStream_t s = (hipStream_t)stream;
     NCH_DISPATCH(bert_embed_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, word, pos, type0, gamma, beta,
-                 (bf16*)pre, (bf16*)y, mean, rstd, T, S, D, vocab, eps);
+                 (h16*)pre, (h16*)y, mean, rstd, T, S, D, vocab, eps);
     return mh_launch_status();
 }
 
 extern "C" int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre, float* dword, float* dpos, float* dtype0,
-                                 int B, int S, int D, int vocab, int64_t pad_id, mh_stream_t stream) {
+                                 int B, int S, int D, int vocab, int64_t pad_id, float scale, mh_stream_t stream) {
     if (!ids || !d_pre || !dword || !dpos) return MH_EINVAL;
     if (B < 1 || S < 1 || D < 8 || (D % 8) || D > 4096 || vocab < 1) return MH_ESHAPE;
     const int T = B * S;
     hipStream_t s = (hipStream_t)stream;
-    NCH_DISPATCH(bert_embed_bwd_word_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, (const bf16*)d_pre, dword, T,
-                 D, vocab, pad_id);
-    NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const bf16*)d_pre, dpos, B, S, D);
+    NCH_DISPATCH(bert_embed_bwd_word_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, (const h16*)d_pre, dword, T,
+                 D, vocab, pad_id, scale);
+    NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const h16*)d_pre, dpos, B, S, D, scale);
     if (dtype0)
         hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dpos, dtype0, S, D);
     return mh_launch_status();
@@ -294,7 +294,7 @@ extern "C" int mh_patchify(const float* image, void* patches, int B, int C, int 
     if (B < 1 || C < 1 || P < 8 || (P % 8) || (H % P) || (W % P) || (W % 4)) return MH_ESHAPE;
     const size_t total = (size_t)B * (H / P) * (W / P) * (C * P * P / 8);
     hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       image, (bf16*)patches, B, C, H, W, P);
+                       image, (h16*)patches, B, C, H, W, P);
     return mh_launch_status();
 }
 
@@ -304,20 +304,20 @@ extern "C" int mh_vit_assemble_fwd(const void* proj, const float* cls, const flo
     if (B < 1 || Np < 1 || D < 8 || (D % 8)) return MH_ESHAPE;
     const size_t total = (size_t)B * (Np + 1) * (D / 8);
     hipLaunchKernelGGL(vit_assemble_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16*)proj, cls, pos, (bf16*)x, B, Np, D);
+                       (hipStream_t)stream, (const h16*)proj, cls, pos, (h16*)x, B, Np, D);
     return mh_launch_status();
 }
 
 extern "C" int mh_vit_assemble_bwd(const void* dx, void* dproj, float* dcls, float* dpos, int B, int Np, int D,
-                                   mh_stream_t stream) {
+                                   float scale, mh_stream_t stream) {
     if (!dx || !dproj || !dcls || !dpos) return MH_EINVAL;
     if (B < 1 || Np < 1 || D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const size_t total = (size_t)B * Np * (D / 8);
     hipLaunchKernelGGL(vit_assemble_bwd_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       (const bf16*)dx, (bf16*)dproj, B, Np, D);
+                       (const h16*)dx, (h16*)dproj, B, Np, D);
     const int S = Np + 1;
-    NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const bf16*)dx, dpos, B, S, D);
+    NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const h16*)dx, dpos, B, S, D, scale);
     // d cls = sum_b dx[b][0] = dpos row 0
     hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dpos, dcls, 1, D);
     return mh_launch_status();

@@ -1,4 +1,4 @@
-// Grouped bf16 MFMA GEMM with fused epilogue for gfx950 (see include/memehip.h).
+// Grouped h16 MFMA GEMM with fused epilogue for gfx950 (see include/memehip.h).
 //
 // Tile 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 tiles of
 // v_mfma_f32_16x16x32_bf16).  Operands are staged global -> VGPR -> LDS (buffer loads: rows past
@@ -96,7 +96,7 @@ MH_DEV void dma_tile(__amdgpu_buffer_rsrc_t r, int ld, int r0, int k0, int wave,
 
 // ---- LDS -> MFMA fragment: rows rb..rb+15, k = kk*32 .. kk*32+31 -------------------------------
 template <int KMAJOR>
-MH_DEV bf16x8 read_frag(const char* lds, int rb, int kk, int lane) {
+MH_DEV h16x8 read_frag(const char* lds, int rb, int kk, int lane) {
     if (KMAJOR == 0) {
         const int row = rb + (lane & 15);
         const int c = kk * 4 + (lane >> 4);
@@ -116,7 +116,7 @@ MH_DEV bf16x8 read_frag(const char* lds, int rb, int kk, int lane) {
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + a1));
         union {
             struct { s16x4 lo, hi; } s;
-            bf16x8 h;
+            h16x8 h;
         } cv;
         cv.s.lo = lo;
         cv.s.hi = hi;
@@ -130,6 +130,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
     const int M = P.M;
     const int flags = P.flags;
     const int ldc = P.ldc;
+    const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
     const int nthreads = TM * 2;  // 256 threads for TM = 128, 512 for TM = 256
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -142,7 +143,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
             const f32x4 x0 = *(const f32x4*)(cs + row * BN + cc * 8);
             const f32x4 x1 = *(const f32x4*)(cs + row * BN + cc * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+            for (int e = 0; e < 4; ++e) { v[e] = x0[e] * alpha; v[4 + e] = x1[e] * alpha; }
         }
         if (P.bias) {
             const f32x4 b0 = *(const f32x4*)(P.bias + gn);
@@ -155,7 +156,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
             Pack8 u;
 #pragma unroll
             for (int e = 0; e < 8; ++e) u.e[e] = mh_f2bf(v[e]);
-            *(i32x4*)((bf16*)P.aux + o) = u.v;
+            *(i32x4*)((h16*)P.aux + o) = u.v;
         }
         if (flags & MH_GEMM_GELU) {
 #pragma unroll
@@ -163,13 +164,13 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
         }
         if (P.mul) {
             Pack8 u;
-            u.v = *(const i32x4*)((const bf16*)P.mul + o);
+            u.v = *(const i32x4*)((const h16*)P.mul + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(mh_bf2f(u.e[e]));
         }
         if (P.residual) {
             Pack8 u;
-            u.v = *(const i32x4*)((const bf16*)P.residual + o);
+            u.v = *(const i32x4*)((const h16*)P.residual + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += mh_bf2f(u.e[e]);
         }
@@ -186,7 +187,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
             Pack8 u;
 #pragma unroll
             for (int e = 0; e < 8; ++e) u.e[e] = mh_f2bf(v[e]);
-            *(i32x4*)((bf16*)P.C + o) = u.v;
+            *(i32x4*)((h16*)P.C + o) = u.v;
         }
     }
 }
@@ -232,9 +233,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave & 1) == 0);
-    bf16x8 ones;
+    h16x8 ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    for (int j = 0; j < 8; ++j) ones[j] = (h16)1.0f;
 
     const int nk = (K + BK - 1) / BK;
     auto compute = [&](const char* cur) {
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
         const char* lb = cur + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[4], fb[4];
+            h16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA>(la, wm0 + i * 16, kk, lane);
 #pragma unroll
@@ -251,11 +252,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MH_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (do_rowsum) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+                    accb[i] = MH_MFMA_16x16x32(fa[i], ones, accb[i], 0, 0, 0);
             }
         }
     };
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
-                if (row < M) P.rowsum[row] = accb[i][r];
+                if (row < M) P.rowsum[row] = accb[i][r] * (P.alpha == 0.f ? 1.0f : P.alpha);
             }
     }
     float* cs = (float*)smem;  // [128][128] f32, column index XOR-swizzled by row group
@@ -389,9 +390,9 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && (wn == 0);
-    bf16x8 ones;
+    h16x8 ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    for (int j = 0; j < 8; ++j) ones[j] = (h16)1.0f;
 
     const int nk = (K + BK - 1) / BK;
     // wave w moves pieces 6w .. 6w+5 of the 48 pieces of a stage (panels: A rows 0-127, A rows 128-255, B)
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
         const char* lb = st + 2 * R_PANEL;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[4], fb[4];
+            h16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA>(la, a_row0 + i * 16, kk, lane);
 #pragma unroll
@@ -427,11 +428,11 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MH_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (do_rowsum) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+                    accb[i] = MH_MFMA_16x16x32(fa[i], ones, accb[i], 0, 0, 0);
             }
         }
     }
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
-                if (row < M) P.rowsum[row] = accb[i][r];
+                if (row < M) P.rowsum[row] = accb[i][r] * (P.alpha == 0.f ? 1.0f : P.alpha);
             }
     }
     float* cs = (float*)smem;  // [256][128] f32 = 128 KiB
@@ -522,9 +523,9 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave & 1) == 0);
-    bf16x8 ones;
+    h16x8 ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    for (int j = 0; j < 8; ++j) ones[j] = (h16)1.0f;
 
     const int nk = (K + BK - 1) / BK;
     // pieces 6w + 3h .. 6w + 3h + 2 of tile kt (h = which half)
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
             else dma_piece<LB>(rb, P.ldb, n0, k0, piece, lane, st + 2 * R_PANEL);
         }
     };
-    bf16x8 fa[4], fb[4];
+    h16x8 fa[4], fb[4];
     auto read_frags = [&](int kt, int kk) {
         const char* st = smem + (kt % 3) * R_STAGE;
         const char* la = st + grp * R_PANEL;
@@ -556,11 +557,11 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = MH_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         if (do_rowsum) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
+                accb[i] = MH_MFMA_16x16x32(fa[i], ones, accb[i], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
-                if (row < M) P.rowsum[row] = accb[i][r];
+                if (row < M) P.rowsum[row] = accb[i][r] * (P.alpha == 0.f ? 1.0f : P.alpha);
             }
     }
     float* cs = (float*)smem;

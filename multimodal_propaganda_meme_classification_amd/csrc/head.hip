@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, int ldy,
                                                         const float* __restrict__ W, void* __restrict__ dx,
-                                                        size_t ldx, int M, int N, int K) {
+                                                        size_t ldx, int M, int N, int K, float scale) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int m = blockIdx.y;
     if (k >= K) return;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
     float acc = 0.f;
 #pragma unroll 8
     for (int n = 0; n < N; ++n) acc += d[n] * W[(size_t)n * K + k];
-    if (OUT_BF16) ((bf16*)dx)[(size_t)m * ldx + k] = mh_f2bf(acc);
+    if (OUT_BF16) ((h16*)dx)[(size_t)m * ldx + k] = mh_f2bf(acc * scale);
     else ((float*)dx)[(size_t)m * ldx + k] = acc;
 }
 
@@ -150,7 +150,7 @@ extern "C" int mh_head_fwd(const MhHeadParams* p, const float* text_hidden, cons
 extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const float* dlogits, const float* pooled,
                            const float* feat, const float* fused, float* dfeat, float* dfused, void* d_text_hidden,
                            void* d_image_hidden, int text_pool_index, int B, int S, int Nt, int Dt, int Di, int P,
-                           int C, mh_stream_t stream) {
+                           int C, float out_scale, mh_stream_t stream) {
     if (!p || !g || !dlogits || !pooled || !feat || !fused || !dfeat || !dfused || !d_text_hidden ||
         !d_image_hidden)
         return MH_EINVAL;
@@ -163,12 +163,12 @@ extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const fl
     hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(P), C), dim3(256), 0, s, dlogits, C, fused, P, g->Wo, g->bo, B,
                        C, P);
     hipLaunchKernelGGL((linear_dx_kernel<false>), dim3(blocks(P), B), dim3(256), 0, s, dlogits, C, p->Wo,
-                       (void*)dfused, (size_t)P, B, C, P);
+                       (void*)dfused, (size_t)P, B, C, P, 1.0f);
     // fusion_fc
     hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(2 * P), P), dim3(256), 0, s, dfused, P, feat, 2 * P, g->Wf,
                        g->bf_, B, P, 2 * P);
     hipLaunchKernelGGL((linear_dx_kernel<false>), dim3(blocks(2 * P), B), dim3(256), 0, s, dfused, P, p->Wf,
-                       (void*)dfeat, (size_t)(2 * P), B, P, 2 * P);
+                       (void*)dfeat, (size_t)(2 * P), B, P, 2 * P, 1.0f);
     // bert_fc / image_fc
     hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(Dt), P), dim3(256), 0, s, dfeat, 2 * P, pooled, Dp, g->Wt,
                        g->bt, B, P, Dt);
@@ -176,9 +176,9 @@ extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const fl
                        g->Wi, g->bi, B, P, Di);
     // gradients of the pooled rows go straight into the [B][S][D] hidden-state gradient buffers
     hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Dt), B), dim3(256), 0, s, dfeat, 2 * P, p->Wt,
-                       (void*)((bf16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt, B, P, Dt);
+                       (void*)((h16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt, B, P, Dt, out_scale);
     hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Di), B), dim3(256), 0, s, dfeat + P, 2 * P, p->Wi,
-                       d_image_hidden, (size_t)Nt * Di, B, P, Di);
+                       d_image_hidden, (size_t)Nt * Di, B, P, Di, out_scale);
     return mh_launch_status();
 }
 

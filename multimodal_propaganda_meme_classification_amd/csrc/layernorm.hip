@@ -1,11 +1,11 @@
-// LayerNorm forward / backward, one 64-lane wavefront per row, 16-B bf16 loads (HBM-bound).
+// LayerNorm forward / backward, one 64-lane wavefront per row, 16-B h16 loads (HBM-bound).
 // See include/memehip.h.  Rows of D <= 4096 live in registers (NCH chunks of 8 per lane).
 #include "common.h"
 
 namespace {
 
 template <int NCH>
-MH_DEV void load_row(const bf16* __restrict__ p, int D, int lane, float (&v)[NCH][8]) {
+MH_DEV void load_row(const h16* __restrict__ p, int D, int lane, float (&v)[NCH][8]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
@@ -36,7 +36,7 @@ MH_DEV void load_row_f32(const float* __restrict__ p, int D, int lane, float (&v
     }
 }
 template <int NCH>
-MH_DEV void store_row(bf16* __restrict__ p, int D, int lane, const float (&v)[NCH][8]) {
+MH_DEV void store_row(h16* __restrict__ p, int D, int lane, const float (&v)[NCH][8]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
@@ -50,8 +50,8 @@ MH_DEV void store_row(bf16* __restrict__ p, int D, int lane, const float (&v)[NC
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, bf16* __restrict__ y,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const h16* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, h16* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
@@ -100,11 +100,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const h16* __restrict__ dy, const h16* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
-                                                     const bf16* __restrict__ dx_add, bf16* __restrict__ dx,
+                                                     const h16* __restrict__ dx_add, h16* __restrict__ dx,
                                                      float* __restrict__ part, int n_part, int rows, int D) {
     __shared__ float red[4][64 * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -186,7 +186,7 @@ struct ColsumJobs {
 };
 
 // grid (ceil(D/64), 2, n_jobs), block 256: 4 waves split the partial rows, lane = column
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs jobs, int n_part, int D) {
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs jobs, int n_part, int D, float scale) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs j
         for (int i = wave; i < n_part; i += 4) s += p[(size_t)i * D + col];
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && col < D) out[col] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (wave == 0 && col < D) out[col] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * scale;
 }
 
 }  // namespace
@@ -218,7 +218,7 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
     if (!x || !gamma || !beta || !y) return MH_EINVAL;
     if (rows < 1 || D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    LN_DISPATCH(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, y_f32,
+    LN_DISPATCH(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const h16*)x, gamma, beta, (h16*)y, y_f32,
                 mean, rstd, rows, D, eps);
     return mh_launch_status();
 }
@@ -229,12 +229,13 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !part) return MH_EINVAL;
     if (rows < 1 || n_part < 1 || D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    LN_DISPATCH(ln_bwd_kernel, dim3(n_part), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd,
-                (const bf16*)dx_add, (bf16*)dx, part, n_part, rows, D);
+    LN_DISPATCH(ln_bwd_kernel, dim3(n_part), dim3(256), 0, s, (const h16*)dy, (const h16*)x, gamma, mean, rstd,
+                (const h16*)dx_add, (h16*)dx, part, n_part, rows, D);
     return mh_launch_status();
 }
 
-extern "C" int mh_colsum_partials_f32(const MhColsumJob* jobs, int n_jobs, int n_part, int D, mh_stream_t stream) {
+extern "C" int mh_colsum_partials_f32(const MhColsumJob* jobs, int n_jobs, int n_part, int D, float scale,
+                                      mh_stream_t stream) {
     if (!jobs || n_jobs < 1 || n_jobs > MH_COLSUM_MAX_JOBS) return MH_EINVAL;
     if (n_part < 1 || D < 1) return MH_ESHAPE;
     ColsumJobs j;
@@ -246,6 +247,6 @@ extern "C" int mh_colsum_partials_f32(const MhColsumJob* jobs, int n_jobs, int n
         j.out1[i] = jobs[i].out1;
     }
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64, 2, n_jobs), dim3(256), 0, (hipStream_t)stream, j,
-                       n_part, D);
+                       n_part, D, scale);
     return mh_launch_status();
 }

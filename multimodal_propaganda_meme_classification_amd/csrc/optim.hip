@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
 // hyper (device, f32[8]): lr, beta1, beta2, eps, weight_decay, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ g,
-                                                   bf16* __restrict__ shadow, int64_t n, int64_t n_shadow,
+                                                   h16* __restrict__ shadow, int64_t n, int64_t n_shadow,
                                                    const float* __restrict__ hyper, int decoupled,
                                                    const float* __restrict__ gnorm_sq, float max_norm) {
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
-__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, h16* __restrict__ dst,
                                                             int64_t n) {
     const int64_t n8 = n >> 3;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[8 * n8 + threadIdx.x] = mh_f2bf(src[8 * n8 + threadIdx.x]);
 }
-__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16* __restrict__ src, float* __restrict__ dst,
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const h16* __restrict__ src, float* __restrict__ dst,
                                                             int64_t n) {
     const int64_t n8 = n >> 3;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -128,7 +128,7 @@ extern "C" int mh_adam_step(float* p, float* m, float* v, const float* g, void* 
     if (n < 4 || (n & 3) || (n_shadow & 3) || n_shadow > n) return MH_ESHAPE;
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
-                       (bf16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm);
+                       (h16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm);
     return mh_launch_status();
 }
 
@@ -136,18 +136,18 @@ extern "C" int mh_cast_f32_bf16(const float* src, void* dst, int64_t n, mh_strea
     if (!src || !dst) return MH_EINVAL;
     if (n < 1 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MH_ESHAPE;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src,
-                       (bf16*)dst, n);
+                       (h16*)dst, n);
     return mh_launch_status();
 }
 extern "C" int mh_cast_bf16_f32(const void* src, float* dst, int64_t n, mh_stream_t stream) {
     if (!src || !dst) return MH_EINVAL;
     if (n < 1 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MH_ESHAPE;
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)src, dst, n);
+                       (const h16*)src, dst, n);
     return mh_launch_status();
 }
 
-extern "C" const char* mh_version(void) { return "memehip 0.1 (gfx950)"; }
+extern "C" const char* mh_version(void) { return "memehip 0.1 (gfx950, " MH_DTYPE_NAME ")"; }
 extern "C" const char* mh_status_str(int status) {
     switch (status) {
         case MH_OK: return "ok";

@@ -32,12 +32,13 @@ LN_PARTS = 512
 class Segment:
     """An ordered list of prepared launches."""
 
-    def __init__(self, name: str):
+    def __init__(self, name: str, lib=None):
         self.name = name
+        self.lib = lib if lib is not None else _lib.load()
         self.calls: List[Tuple] = []
 
     def c(self, fn_name: str, *args, tag: Optional[str] = None, work: float = 0.0):
-        self.calls.append((getattr(_lib.load(), fn_name), args, fn_name, tag or fn_name, work))
+        self.calls.append((getattr(self.lib, fn_name), args, fn_name, tag or fn_name, work))
 
     def py(self, fn: Callable[[], None]):
         self.calls.append((None, fn, "py", "py", 0.0))
@@ -78,12 +79,13 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class Plan:
-    def __init__(self, B: int, S: int):
+    def __init__(self, B: int, S: int, lib=None):
         self.B, self.S = B, S
+        self.lib = lib
         self.buf: Dict[str, torch.Tensor] = {}
         self.keep: list = []                  # ctypes arrays referenced by prepared calls
-        self.fwd = Segment("fwd")
-        self.loss = Segment("loss")
+        self.fwd = Segment("fwd", lib)
+        self.loss = Segment("loss", lib)
         self.bwd: List[Segment] = []          # backward segments in execution order
         self.bucket_after: Dict[str, Tuple[int, int]] = {}   # segment name -> flat grad range complete after it
         self.n_launches = 0
@@ -96,6 +98,11 @@ class Engine:
         self.P, self.G, self.SH = P, G, SH
         self.dev = P.device
         assert P.is_cuda and G.is_cuda and SH.is_cuda, "memehip needs HIP device buffers (no CPU fallback)"
+        self.kind = cfg.compute_dtype
+        self.T16 = torch.float16 if self.kind == "fp16" else torch.bfloat16
+        assert SH.dtype == self.T16
+        self.lib = _lib.load(self.kind)
+        self.gscale = cfg.stream_scale          # scale carried by the 16-bit gradient streams
         self.plans: Dict[Tuple[int, int], Plan] = {}
 
     # ---- parameter / gradient views -----------------------------------------------------------------
@@ -125,12 +132,12 @@ class Engine:
             A, Bm, Cm = d["A"], d["B"], d["C"]
             M, N, K = d["M"], d["N"], d["K"]
             lda, ldb, ldc = d["lda"], d["ldb"], d["ldc"]
-            assert A.dtype == BF16 and Bm.dtype == BF16 and Cm.dtype in (BF16, F32)
+            assert A.dtype == self.T16 and Bm.dtype == self.T16 and Cm.dtype in (self.T16, F32)
             a_need = (K - 1) * lda + M if a_k else (M - 1) * lda + K
             b_need = (K - 1) * ldb + N if b_k else (N - 1) * ldb + K
             assert A.numel() >= a_need and Bm.numel() >= b_need and Cm.numel() >= (M - 1) * ldc + N, (M, N, K)
-            for key, dt, need in (("bias", F32, N), ("residual", BF16, (M - 1) * ldc + N), ("aux", BF16, (M - 1) * ldc + N),
-                                  ("mul", BF16, (M - 1) * ldc + N), ("rowsum", F32, M)):
+            for key, dt, need in (("bias", F32, N), ("residual", self.T16, (M - 1) * ldc + N), ("aux", self.T16, (M - 1) * ldc + N),
+                                  ("mul", self.T16, (M - 1) * ldc + N), ("rowsum", F32, M)):
                 t = d.get(key)
                 assert t is None or (t.dtype == dt and t.numel() >= need), key
             e = arr[i]
@@ -140,6 +147,7 @@ class Engine:
             e.M, e.N, e.K, e.lda, e.ldb, e.ldc = M, N, K, lda, ldb, ldc
             e.flags = (MH_GEMM_GELU if d.get("gelu") else 0) | (MH_GEMM_OUT_F32 if Cm.dtype == F32 else 0) | \
                       (MH_GEMM_ACCUM if d.get("accum") else 0)
+            e.alpha = float(d.get("alpha", 1.0))
         plan.keep.append(arr)
         flops = float(sum(2.0 * d["M"] * d["N"] * d["K"] for d in probs))
         plan.gemm_flops += flops
@@ -154,10 +162,10 @@ class Engine:
         # out[T, K_in] = dy[T, N_out] @ w[N_out, K_in]
         return dict(A=dy, B=w, C=out, M=T, N=K_in, K=N_out, lda=N_out, ldb=K_in, ldc=K_in, **kw)
 
-    @staticmethod
-    def _wgrad_prob(dy, x, dw, db, T, N_out, K_in):
-        # dw[N_out, K_in] = dy[T, N_out]^T @ x[T, K_in]
-        return dict(A=dy, B=x, C=dw, M=N_out, N=K_in, K=T, lda=N_out, ldb=K_in, ldc=K_in, rowsum=db)
+    def _wgrad_prob(self, dy, x, dw, db, T, N_out, K_in):
+        # dw[N_out, K_in] = dy[T, N_out]^T @ x[T, K_in]   (dy carries the gradient-stream scale: alpha removes it)
+        return dict(A=dy, B=x, C=dw, M=N_out, N=K_in, K=T, lda=N_out, ldb=K_in, ldc=K_in, rowsum=db,
+                    alpha=1.0 / self.gscale)
 
     def _ln_fwd(self, seg, x, gname, bname, y, mean, rstd, rows, D, eps, y32=None):
         seg.c("mh_layernorm_fwd", _ptr(x), _ptr(self.p(gname)), _ptr(self.p(bname)), _ptr(y), _ptr(y32), _ptr(mean),
@@ -183,8 +191,9 @@ class Engine:
             raise ValueError(f"sequence length {S} > max_position {t.max_position}")
         if B > 1024:
             raise ValueError("batch > 1024 not supported by the loss kernel")
-        pl = Plan(B, S)
+        pl = Plan(B, S, self.lib)
         pl._ln_jobs = {}
+        BF16 = self.T16          # every 16-bit buffer below uses the configured storage type
         dev = self.dev
         Dt, It, Ht, Lt = t.hidden, t.intermediate, t.heads, t.layers
         Di, Ii, Hi, Li = v.hidden, v.intermediate, v.heads, v.layers
@@ -332,7 +341,7 @@ class Engine:
 
         # ------------------------------------------------------------------ backward -----------------
         def seg(name):
-            s = Segment(name)
+            s = Segment(name, self.lib)
             pl.bwd.append(s)
             return s
 
@@ -344,7 +353,7 @@ class Engine:
         s.py(dXt[0].zero_)
         s.py(dXf.zero_)
         s.c("mh_head_bwd", C.byref(hp), C.byref(hg), _ptr(dlogits), _ptr(pooled), _ptr(feat), _ptr(fused), _ptr(dfeat),
-            _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn)
+            _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale))
         self._ln_bwd(pl, s, dXf, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", mf, rf, dXi[0], Ti, Di)
 
         # shared backward temporaries
@@ -443,11 +452,11 @@ class Engine:
         s.c("mh_zero_rows_f32", _ptr(prev_ids), _ptr(gword), Tt, Dt, t.vocab_size)
         gtype0 = self.g(TXT + "embeddings.token_type_embeddings.weight")[:Dt] if t.type_vocab > 0 else None
         s.c("mh_bert_embed_bwd", _ptr(ids), _ptr(t_dpre), _ptr(gword), _ptr(self.g(TXT + "embeddings.position_embeddings.weight")),
-            _ptr(gtype0), B, S, Dt, t.vocab_size, int(t.pad_token_id))
+            _ptr(gtype0), B, S, Dt, t.vocab_size, int(t.pad_token_id), 1.0 / self.gscale)
         s.py(lambda: prev_ids.copy_(ids))
         i_dproj = alloc("i.dproj", (B * Np, Di))
         s.c("mh_vit_assemble_bwd", _ptr(dXi[ci]), _ptr(i_dproj), _ptr(self.g(IMG + "embeddings.cls_token")),
-            _ptr(self.g(IMG + "embeddings.position_embeddings")), B, Np, Di)
+            _ptr(self.g(IMG + "embeddings.position_embeddings")), B, Np, Di, 1.0 / self.gscale)
         self._gemm(pl, s, [self._wgrad_prob(i_dproj, patches, self.g(IMG + "embeddings.patch_embeddings.projection.weight"),
                                             self.g(IMG + "embeddings.patch_embeddings.projection.bias"), B * Np, Di, Kp)],
                    True, True)
@@ -459,7 +468,7 @@ class Engine:
                 for j, (part, o0, o1) in enumerate(chunk):
                     arr[j].part, arr[j].out0, arr[j].out1 = _ptr(part), _ptr(o0), _ptr(o1)
                 pl.keep.append(arr)
-                s.c("mh_colsum_partials_f32", arr, len(chunk), LN_PARTS, D)
+                s.c("mh_colsum_partials_f32", arr, len(chunk), LN_PARTS, D, 1.0 / self.gscale)
         pl.bucket_after[s.name] = (self.layout.layer_ranges[-1][2], self.layout.n_total)
         pl.n_launches = len(pl.fwd) + len(pl.loss) + sum(len(x) for x in pl.bwd)
         return pl

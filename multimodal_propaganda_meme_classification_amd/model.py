@@ -121,7 +121,8 @@ class MultimodalClassifier(nn.Module):
         n = self.layout.n_total
         self._P = torch.zeros(n, dtype=F32, device=device)
         self._G = torch.zeros(n, dtype=F32, device=device)
-        self._SH = torch.zeros(self.layout.n_shadow, dtype=BF16, device=device)
+        self._T16 = torch.float16 if cfg.compute_dtype == "fp16" else BF16
+        self._SH = torch.zeros(self.layout.n_shadow, dtype=self._T16, device=device)
         self._names = self.layout.state_dict_order()
         self._params: Dict[str, nn.Parameter] = {}
         for name in self._names:
@@ -173,7 +174,7 @@ class MultimodalClassifier(nn.Module):
         if new_p.device != self._P.device or new_p.data_ptr() != self._P.data_ptr():
             self._P = new_p
             self._G = fn(self._G)
-            self._SH = torch.zeros(self.layout.n_shadow, dtype=BF16, device=new_p.device)
+            self._SH = torch.zeros(self.layout.n_shadow, dtype=self._T16, device=new_p.device)
             for name, prm in self._params.items():
                 s = self.layout.spec[name]
                 prm.data = self._P[s.offset:s.offset + s.numel].view(s.shape)

@@ -15,7 +15,8 @@ from . import _lib
 from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhColsumJob, MhGemmProblem, MhHeadGrads,
                    MhHeadParams, check)
 
-BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
+BF16, F16, F32, I64 = torch.bfloat16, torch.float16, torch.float32, torch.int64
+H16 = (BF16, F16)          # the two 16-bit storage types; the tensor dtype selects the library build
 
 
 def _stream() -> int:
@@ -26,12 +27,23 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _kind(t: torch.Tensor) -> str:
+    return "fp16" if t.dtype == F16 else "bf16"
+
+
+def _L(t: torch.Tensor):
+    return _lib.load(_kind(t))
+
+
 def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
     if not t.is_cuda:
         raise _lib.MemehipError(f"{name}: memehip kernels need a HIP device tensor (got {t.device}); no CPU fallback")
-    if t.dtype != dtype:
+    if dtype is BF16:                      # "the 16-bit storage type": bf16 or fp16
+        if t.dtype not in H16:
+            raise TypeError(f"{name}: expected bfloat16/float16, got {t.dtype}")
+    elif t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if contiguous and not t.is_contiguous():
         raise ValueError(f"{name}: must be contiguous")
@@ -46,10 +58,11 @@ class Gemm:
     """One problem of a grouped launch (see MhGemmProblem in include/memehip.h)."""
 
     __slots__ = ("A", "B", "C", "bias", "residual", "aux", "mul", "rowsum", "M", "N", "K", "lda", "ldb", "ldc",
-                 "flags")
+                 "flags", "alpha")
 
     def __init__(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, residual=None, aux=None, mul=None,
-                 rowsum=None, gelu=False, accum=False):
+                 rowsum=None, gelu=False, accum=False, alpha=1.0):
+        self.alpha = alpha
         self.A, self.B, self.C = A, B, C
         self.bias, self.residual, self.aux, self.mul, self.rowsum = bias, residual, aux, mul, rowsum
         self.M, self.N, self.K, self.lda, self.ldb, self.ldc = M, N, K, lda, ldb, ldc
@@ -66,8 +79,10 @@ def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
     arr = (MhGemmProblem * n)()
     for i, g in enumerate(problems):
         _chk(g.A, BF16, "A", False), _chk(g.B, BF16, "B", False)
-        if g.C.dtype not in (BF16, F32) or not g.C.is_cuda:
-            raise TypeError("C must be a bf16 or f32 device tensor")
+        if g.C.dtype not in (BF16, F16, F32) or not g.C.is_cuda:
+            raise TypeError("C must be a 16-bit or f32 device tensor")
+        if g.A.dtype != g.B.dtype or (g.C.dtype != F32 and g.C.dtype != g.A.dtype):
+            raise TypeError("A, B (and a 16-bit C) must share one 16-bit dtype")
         # extents the kernel will touch
         a_need = _min_elems(g.K, g.lda, g.M) if a_kmajor else _min_elems(g.M, g.lda, g.K)
         b_need = _min_elems(g.K, g.ldb, g.N) if b_kmajor else _min_elems(g.N, g.ldb, g.K)
@@ -84,8 +99,8 @@ def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
         a = arr[i]
         a.A, a.B, a.C = _p(g.A), _p(g.B), _p(g.C)
         a.bias, a.residual, a.aux, a.mul, a.rowsum = _p(g.bias), _p(g.residual), _p(g.aux), _p(g.mul), _p(g.rowsum)
-        a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.flags = g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.flags
-    check(_lib.load().mh_gemm_bf16_grouped(arr, n, int(a_kmajor), int(b_kmajor), _stream()), "mh_gemm_bf16_grouped")
+        a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.flags, a.alpha = g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.flags, g.alpha
+    check(_L(problems[0].A).mh_gemm_bf16_grouped(arr, n, int(a_kmajor), int(b_kmajor), _stream()), "mh_gemm_bf16_grouped")
 
 
 def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False):
@@ -93,7 +108,7 @@ def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False):
     T, K = x.shape
     N = w.shape[0]
     if out is None:
-        out = torch.empty((T, N), dtype=BF16, device=x.device)
+        out = torch.empty((T, N), dtype=x.dtype, device=x.device)
     gemm_grouped([Gemm(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual,
                        aux=aux, gelu=gelu)], False, False)
     return out
@@ -104,17 +119,17 @@ def linear_dgrad(dy, w, out=None, mul=None, residual=None):
     T, N = dy.shape
     K = w.shape[1]
     if out is None:
-        out = torch.empty((T, K), dtype=BF16, device=dy.device)
+        out = torch.empty((T, K), dtype=dy.dtype, device=dy.device)
     gemm_grouped([Gemm(dy, w, out, T, K, N, dy.stride(0), w.stride(0), out.stride(0), mul=mul, residual=residual)],
                  False, True)
     return out
 
 
-def linear_wgrad(dy, x, dw, dbias=None, accum=False):
+def linear_wgrad(dy, x, dw, dbias=None, accum=False, alpha=1.0):
     """dw[N,K] (f32) = dy[T,N]^T @ x[T,K] ; dbias[N] = colsum(dy)"""
     T, N = dy.shape
     K = x.shape[1]
-    gemm_grouped([Gemm(dy, x, dw, N, K, T, dy.stride(0), x.stride(0), dw.stride(0), rowsum=dbias, accum=accum)],
+    gemm_grouped([Gemm(dy, x, dw, N, K, T, dy.stride(0), x.stride(0), dw.stride(0), rowsum=dbias, accum=accum, alpha=alpha)],
                  True, True)
     return dw
 
@@ -132,7 +147,7 @@ def layernorm_fwd(x, gamma, beta, eps, y=None, mean=None, rstd=None, y_f32=None)
     if y_f32 is not None:
         _chk(y_f32, F32, "y_f32")
         assert y_f32.numel() >= rows * D
-    check(_lib.load().mh_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(y_f32), _p(mean), _p(rstd), rows, D,
+    check(_L(x).mh_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(y_f32), _p(mean), _p(rstd), rows, D,
                                        float(eps), _stream()), "mh_layernorm_fwd")
     return y, mean, rstd
 
@@ -143,12 +158,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, part, dx=None, dx_add=None):
     n_part = part.shape[1]
     assert part.shape == (2, n_part, D) and mean.numel() >= rows and rstd.numel() >= rows
     dx = torch.empty_like(x) if dx is None else _chk(dx, BF16, "dx")
-    check(_lib.load().mh_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(part),
+    check(_L(x).mh_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(part),
                                        n_part, rows, D, _stream()), "mh_layernorm_bwd")
     return dx
 
 
-def colsum_partials(jobs, n_part: int, D: int):
+def colsum_partials(jobs, n_part: int, D: int, scale: float = 1.0):
     """jobs: list of (part[2,n_part,D], out0 or None, out1 or None)"""
     for i in range(0, len(jobs), _lib.MH_COLSUM_MAX_JOBS):
         chunk = jobs[i:i + _lib.MH_COLSUM_MAX_JOBS]
@@ -161,7 +176,7 @@ def colsum_partials(jobs, n_part: int, D: int):
                     _chk(o, F32, "out", False)
                     assert o.numel() >= D
             arr[j].part, arr[j].out0, arr[j].out1 = _p(part), _p(o0), _p(o1)
-        check(_lib.load().mh_colsum_partials_f32(arr, len(chunk), n_part, D, _stream()), "mh_colsum_partials_f32")
+        check(_lib.load().mh_colsum_partials_f32(arr, len(chunk), n_part, D, float(scale), _stream()), "mh_colsum_partials_f32")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -174,10 +189,10 @@ def attn_fwd(qkv, key_mask, B, S, H, out=None, lse=None):
     if key_mask is not None:
         _chk(key_mask, I64, "key_mask")
         assert key_mask.numel() == B * S
-    out = torch.empty((B * S, H * 64), dtype=BF16, device=qkv.device) if out is None else _chk(out, BF16, "out")
+    out = torch.empty((B * S, H * 64), dtype=qkv.dtype, device=qkv.device) if out is None else _chk(out, BF16, "out")
     lse = torch.empty((B, H, S), dtype=F32, device=qkv.device) if lse is None else _chk(lse, F32, "lse")
     assert out.numel() == B * S * H * 64 and lse.numel() == B * H * S
-    check(_lib.load().mh_attn_fwd(_p(qkv), _p(key_mask), _p(out), _p(lse), B, S, H, _stream()), "mh_attn_fwd")
+    check(_L(qkv).mh_attn_fwd(_p(qkv), _p(key_mask), _p(out), _p(lse), B, S, H, _stream()), "mh_attn_fwd")
     return out, lse
 
 
@@ -188,7 +203,7 @@ def attn_bwd(qkv, key_mask, out, dout, lse, B, S, H, dqkv=None, delta=None):
     dqkv = torch.empty_like(qkv) if dqkv is None else _chk(dqkv, BF16, "dqkv")
     delta = torch.empty((B, H, S), dtype=F32, device=qkv.device) if delta is None else _chk(delta, F32, "delta")
     assert dqkv.numel() == qkv.numel() and delta.numel() == B * H * S
-    check(_lib.load().mh_attn_bwd(_p(qkv), _p(key_mask), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, S, H,
+    check(_L(qkv).mh_attn_bwd(_p(qkv), _p(key_mask), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, S, H,
                                   _stream()), "mh_attn_bwd")
     return dqkv
 
@@ -203,18 +218,18 @@ def bert_embed_fwd(ids, word, pos, type0, gamma, beta, eps, pre, y, mean, rstd):
     V, D = word.shape
     assert pos.shape[0] >= S and pos.shape[1] == D
     assert pre.numel() >= B * S * D and y.numel() >= B * S * D and mean.numel() >= B * S and rstd.numel() >= B * S
-    check(_lib.load().mh_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta),
+    check(_L(pre).mh_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta),
                                         _p(_chk(pre, BF16, "pre")), _p(_chk(y, BF16, "y")), _p(mean), _p(rstd), B, S,
                                         D, V, float(eps), _stream()), "mh_bert_embed_fwd")
 
 
-def bert_embed_bwd(ids, d_pre, dword, dpos, dtype0, pad_id: int):
+def bert_embed_bwd(ids, d_pre, dword, dpos, dtype0, pad_id: int, scale: float = 1.0):
     _chk(ids, I64, "ids"), _chk(d_pre, BF16, "d_pre"), _chk(dword, F32, "dword"), _chk(dpos, F32, "dpos")
     B, S = ids.shape
     V, D = dword.shape
     assert d_pre.numel() >= B * S * D and dpos.shape[0] >= S
-    check(_lib.load().mh_bert_embed_bwd(_p(ids), _p(d_pre), _p(dword), _p(dpos), _p(dtype0), B, S, D, V, int(pad_id),
-                                        _stream()), "mh_bert_embed_bwd")
+    check(_L(d_pre).mh_bert_embed_bwd(_p(ids), _p(d_pre), _p(dword), _p(dpos), _p(dtype0), B, S, D, V, int(pad_id),
+                                      float(scale), _stream()), "mh_bert_embed_bwd")
 
 
 def zero_rows(ids, table):
@@ -223,26 +238,26 @@ def zero_rows(ids, table):
     check(_lib.load().mh_zero_rows_f32(_p(ids), _p(table), ids.numel(), D, V, _stream()), "mh_zero_rows_f32")
 
 
-def patchify(image, patch: int, out=None):
+def patchify(image, patch: int, out=None, dtype=BF16):
     _chk(image, F32, "image")
     B, Cc, H, W = image.shape
     rows, K = B * (H // patch) * (W // patch), Cc * patch * patch
-    out = torch.empty((rows, K), dtype=BF16, device=image.device) if out is None else _chk(out, BF16, "patches")
+    out = torch.empty((rows, K), dtype=dtype, device=image.device) if out is None else _chk(out, BF16, "patches")
     assert out.numel() >= rows * K
-    check(_lib.load().mh_patchify(_p(image), _p(out), B, Cc, H, W, patch, _stream()), "mh_patchify")
+    check(_L(out).mh_patchify(_p(image), _p(out), B, Cc, H, W, patch, _stream()), "mh_patchify")
     return out
 
 
 def vit_assemble_fwd(proj, cls, pos, x, B, Np, D):
     _chk(proj, BF16, "proj"), _chk(cls, F32, "cls"), _chk(pos, F32, "pos"), _chk(x, BF16, "x")
     assert proj.numel() >= B * Np * D and cls.numel() >= D and pos.numel() >= (Np + 1) * D and x.numel() >= B * (Np + 1) * D
-    check(_lib.load().mh_vit_assemble_fwd(_p(proj), _p(cls), _p(pos), _p(x), B, Np, D, _stream()), "mh_vit_assemble_fwd")
+    check(_L(x).mh_vit_assemble_fwd(_p(proj), _p(cls), _p(pos), _p(x), B, Np, D, _stream()), "mh_vit_assemble_fwd")
 
 
-def vit_assemble_bwd(dx, dproj, dcls, dpos, B, Np, D):
+def vit_assemble_bwd(dx, dproj, dcls, dpos, B, Np, D, scale: float = 1.0):
     _chk(dx, BF16, "dx"), _chk(dproj, BF16, "dproj"), _chk(dcls, F32, "dcls"), _chk(dpos, F32, "dpos")
     assert dx.numel() >= B * (Np + 1) * D and dproj.numel() >= B * Np * D and dcls.numel() >= D and dpos.numel() >= (Np + 1) * D
-    check(_lib.load().mh_vit_assemble_bwd(_p(dx), _p(dproj), _p(dcls), _p(dpos), B, Np, D, _stream()), "mh_vit_assemble_bwd")
+    check(_L(dx).mh_vit_assemble_bwd(_p(dx), _p(dproj), _p(dcls), _p(dpos), B, Np, D, float(scale), _stream()), "mh_vit_assemble_bwd")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -268,7 +283,7 @@ def head_fwd(params, text_hidden, image_hidden, pool_index, pooled, feat, fused,
 
 
 def head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, d_text_hidden, d_image_hidden, pool_index,
-             B, S, Nt, Dt, Di, P, Cn):
+             B, S, Nt, Dt, Di, P, Cn, out_scale: float = 1.0):
     hp = _head_struct(MhHeadParams, params)
     hg = _head_struct(MhHeadGrads, grads)
     for a, b in zip(params, grads):
@@ -276,9 +291,9 @@ def head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, d_text_
     _chk(d_text_hidden, BF16, "d_text_hidden"), _chk(d_image_hidden, BF16, "d_image_hidden")
     assert d_text_hidden.numel() >= B * S * Dt and d_image_hidden.numel() >= B * Nt * Di
     assert dfeat.numel() >= B * 2 * P and dfused.numel() >= B * P and dlogits.numel() >= B * Cn
-    check(_lib.load().mh_head_bwd(C.byref(hp), C.byref(hg), _p(dlogits), _p(pooled), _p(feat), _p(fused), _p(dfeat),
-                                  _p(dfused), _p(d_text_hidden), _p(d_image_hidden), pool_index, B, S, Nt, Dt, Di, P,
-                                  Cn, _stream()), "mh_head_bwd")
+    check(_L(d_text_hidden).mh_head_bwd(C.byref(hp), C.byref(hg), _p(dlogits), _p(pooled), _p(feat), _p(fused), _p(dfeat),
+                                        _p(dfused), _p(d_text_hidden), _p(d_image_hidden), pool_index, B, S, Nt, Dt, Di, P,
+                                        Cn, float(out_scale), _stream()), "mh_head_bwd")
 
 
 def ce_fwd_bwd(logits, labels, loss, dlogits, n_correct=None, grad_scale: float = 1.0):
@@ -305,11 +320,11 @@ def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=Non
     if shadow is not None:
         _chk(shadow, BF16, "shadow")
         assert shadow.numel() >= n_shadow
-    check(_lib.load().mh_adam_step(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, n_shadow if shadow is not None else 0,
+    check(_L(shadow if shadow is not None else p).mh_adam_step(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, n_shadow if shadow is not None else 0,
                                    _p(hyper), int(decoupled), _p(gnorm_sq), float(max_norm), _stream()), "mh_adam_step")
 
 
 def cast_f32_bf16(src, dst):
     _chk(src, F32, "src"), _chk(dst, BF16, "dst")
     assert dst.numel() >= src.numel()
-    check(_lib.load().mh_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "mh_cast_f32_bf16")
+    check(_L(dst).mh_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "mh_cast_f32_bf16")

@@ -28,15 +28,17 @@ def lib():
 def test_header_symbols_exported(lib):
     names = _declared()
     assert len(names) >= 20
-    cdll = ctypes.CDLL(lib.LIB_PATH)
-    for n in names:
-        assert hasattr(cdll, n), f"{n} declared in include/memehip.h but not exported"
+    for path in (lib.LIB_PATH, lib.LIB_PATH_F16):           # the bf16 and the fp16 build export the same ABI
+        cdll = ctypes.CDLL(path)
+        for n in names:
+            assert hasattr(cdll, n), f"{n} declared in include/memehip.h but not exported by {path}"
 
 
 def test_binding_covers_header(lib):
     assert sorted(lib.EXPORTED_SYMBOLS) == _declared()
     handle = lib.load()
-    assert handle.mh_version().startswith(b"memehip")
+    assert handle.mh_version().startswith(b"memehip") and b"bf16" in handle.mh_version()
+    assert b"fp16" in lib.load("fp16").mh_version()
     assert b"shape" in handle.mh_status_str(2)
 
 

@@ -29,9 +29,12 @@ def rnd(*shape, scale=1.0, dtype=BF16, seed=0):
     return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
 
 
-def ints(*shape, lo=-2, hi=3, seed=0):
+def ints(*shape, lo=-2, hi=3, seed=0, dtype=BF16):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    return torch.randint(lo, hi, shape, generator=g).to(BF16).to(dev())
+    return torch.randint(lo, hi, shape, generator=g).to(dtype).to(dev())
+
+
+BOTH = pytest.mark.parametrize("T16", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 
 
 def close(a, b, rtol, atol, what=""):
@@ -46,12 +49,13 @@ def close(a, b, rtol, atol, what=""):
 # GEMM
 # ------------------------------------------------------------------------------------------------
 
+@BOTH
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (394, 256, 192), (64, 128, 128), (1000, 384, 768)])
-def test_gemm_exact_integer_all_layouts(ops, M, N, K):
+def test_gemm_exact_integer_all_layouts(ops, M, N, K, T16):
     """Small-integer operands: every product and sum is exact, so the three layouts must be
     bit-exact against fp32 matmul (catches any fragment / transpose / swizzle mix-up)."""
-    A = ints(M, K, seed=1)            # asymmetric random integers
-    Bw = ints(N, K, seed=2)
+    A = ints(M, K, seed=1, dtype=T16)            # asymmetric random integers
+    Bw = ints(N, K, seed=2, dtype=T16)
     ref = A.float() @ Bw.float().t()
     out = torch.empty((M, N), dtype=F32, device=dev())
     ops.gemm_grouped([ops.Gemm(A, Bw, out, M, N, K, K, K, N)], False, False)
@@ -63,13 +67,13 @@ def test_gemm_exact_integer_all_layouts(ops, M, N, K):
     assert torch.equal(out, ref), "dgrad layout (0,1)"
     # wgrad layout: both stored K-major; M must be a multiple of 128 there
     M2 = ((M + 127) // 128) * 128
-    A2 = ints(K, M2, seed=3)
+    A2 = ints(K, M2, seed=3, dtype=T16)
     ref2 = A2.float().t() @ Bk.float()
     out2 = torch.empty((M2, N), dtype=F32, device=dev())
     rows = torch.empty(M2, dtype=F32, device=dev())
-    ops.gemm_grouped([ops.Gemm(A2, Bk, out2, M2, N, K, M2, N, N, rowsum=rows)], True, True)
-    assert torch.equal(out2, ref2), "wgrad layout (1,1)"
-    assert torch.equal(rows, A2.float().sum(0)), "wgrad rowsum (bias gradient)"
+    ops.gemm_grouped([ops.Gemm(A2, Bk, out2, M2, N, K, M2, N, N, rowsum=rows, alpha=0.25)], True, True)
+    assert torch.equal(out2, 0.25 * ref2), "wgrad layout (1,1) with alpha"
+    assert torch.equal(rows, 0.25 * A2.float().sum(0)), "wgrad rowsum (bias gradient)"
 
 
 def test_gemm_wgrad_ragged_contraction(ops):
@@ -128,9 +132,10 @@ def test_gemm_rejects_bad_shapes(ops):
 # LayerNorm
 # ------------------------------------------------------------------------------------------------
 
+@BOTH
 @pytest.mark.parametrize("rows,D,eps", [(37, 128, 1e-12), (394, 768, 1e-6), (130, 1024, 1e-12)])
-def test_layernorm_fwd_bwd(ops, rows, D, eps):
-    x = rnd(rows, D, seed=1)
+def test_layernorm_fwd_bwd(ops, rows, D, eps, T16):
+    x = rnd(rows, D, seed=1, dtype=T16)
     g = (1 + 0.1 * torch.randn(D)).to(dev())
     b = (0.1 * torch.randn(D)).to(dev())
     y32 = torch.empty((rows, D), device=dev())
@@ -141,8 +146,8 @@ def test_layernorm_fwd_bwd(ops, rows, D, eps):
     close(y, ref, 8e-3, 8e-3, "ln fwd")
     close(y32, ref, 1e-5, 1e-5, "ln fwd (unrounded copy)")
     close(mean, xf.mean(1), 1e-5, 1e-5, "ln mean")
-    dy = rnd(rows, D, seed=2)
-    add = rnd(rows, D, seed=3)
+    dy = rnd(rows, D, seed=2, dtype=T16)
+    add = rnd(rows, D, seed=3, dtype=T16)
     ref.backward(dy.float())
     n_part = 16
     part = torch.zeros((2, n_part, D), dtype=F32, device=dev())
@@ -151,9 +156,9 @@ def test_layernorm_fwd_bwd(ops, rows, D, eps):
     dx2 = ops.layernorm_bwd(dy, x, g, mean, rstd, part, dx_add=add)
     close(dx2, xf.grad + add.float(), 1e-2, 1.5e-2, "ln dx + add")
     dg, db = torch.empty(D, device=dev()), torch.empty(D, device=dev())
-    ops.colsum_partials([(part, dg, db)], n_part, D)
-    close(dg, gf.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln dgamma")
-    close(db, bf.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln dbeta")
+    ops.colsum_partials([(part, dg, db)], n_part, D, scale=0.5)
+    close(dg, 0.5 * gf.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln dgamma")
+    close(db, 0.5 * bf.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln dbeta")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -171,10 +176,11 @@ def _attn_ref(qkv, mask, B, S, H):
     return o, lse
 
 
+@BOTH
 @pytest.mark.parametrize("B,S,H,masked", [(2, 128, 2, True), (2, 197, 3, False), (3, 16, 2, True), (2, 5, 2, False),
                                            (1, 256, 1, True), (1, 577, 1, False)])
-def test_attention_fwd_bwd(ops, B, S, H, masked):
-    qkv = rnd(B * S, 3 * H * 64, seed=S)
+def test_attention_fwd_bwd(ops, B, S, H, masked, T16):
+    qkv = rnd(B * S, 3 * H * 64, seed=S, dtype=T16)
     mask = None
     if masked:
         lens = torch.randint(max(1, S // 8), S + 1, (B,), generator=torch.Generator().manual_seed(S))
@@ -184,7 +190,7 @@ def test_attention_fwd_bwd(ops, B, S, H, masked):
     ref, lse_ref = _attn_ref(qf, mask, B, S, H)
     close(out, ref, 1e-2, 6e-3, "attention out")
     close(lse, lse_ref, 1e-3, 2e-3, "attention lse")
-    dout = rnd(B * S, H * 64, seed=S + 1)
+    dout = rnd(B * S, H * 64, seed=S + 1, dtype=T16)
     ref.backward(dout.float())
     dqkv = ops.attn_bwd(qkv, mask, out, dout, lse, B, S, H)
     scale = float(qf.grad.abs().max())
@@ -235,6 +241,8 @@ def test_bert_embed_fwd_bwd(ops):
     dword = torch.zeros((V, D), device=dev())
     dpos = torch.zeros((P, D), device=dev())
     dtyp = torch.zeros(D, device=dev())
+    ops.bert_embed_bwd(ids, d_pre, dword, dpos, dtyp, 0, scale=0.5)
+    close(2 * dword, wf.grad, 1e-6, 1e-5, "dword with scale")
     ops.bert_embed_bwd(ids, d_pre, dword, dpos, dtyp, 0)
     close(dword, wf.grad, 1e-6, 1e-5, "dword (dups summed, PAD row zero)")
     assert float(dword[0].abs().max()) == 0.0
@@ -308,7 +316,9 @@ def test_head_ce_fwd_bwd(ops, B, pool):
     dth = torch.zeros((B * S, Dt), dtype=BF16, device=dev())
     dih = torch.zeros((B * Nt, Di), dtype=BF16, device=dev())
     dfeat, dfused = torch.empty_like(feat), torch.empty_like(fused)
-    ops.head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, dth, dih, pool, B, S, Nt, Dt, Di, P, Cn)
+    ops.head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, dth, dih, pool, B, S, Nt, Dt, Di, P, Cn,
+                 out_scale=4.0)
+    dth, dih = (dth.float() / 4).to(BF16), (dih.float() / 4).to(BF16)
     for gr, p, nm in zip(grads, pr, ("Wt", "bt", "Wi", "bi", "Wf", "bf", "Wo", "bo")):
         close(gr, p.grad, 1e-4, 1e-6, "grad " + nm)
     close(dth.view(B, S, Dt), thf.grad, 8e-3, 1e-6, "d text hidden")

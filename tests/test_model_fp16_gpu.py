@@ -1,0 +1,100 @@
+"""The north_star tolerance itself -- logits within 1e-3 of the CPU reference -- held by the fp16 build
+(libmemehip_f16.so: the same kernels compiled with IEEE-half storage, 11-bit significand, same MFMA
+rate; 16-bit gradient streams carry a static power-of-two scale).  GPU box only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LR = 2e-5
+LOGIT_TOL = 1e-3          # BASELINE.json north_star: "within 1e-3 logits tolerance"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import multimodal_propaganda_meme_classification_amd as m
+    return m
+
+
+def _make(pkg, O, cfg, seed):
+    params = O.init_params(cfg, seed)
+    d = cfg.to_dict()
+    d["compute_dtype"] = "fp16"
+    model = pkg.MultimodalClassifier.from_config(pkg.ModelConfig.from_dict(d), init=False)
+    model.load_state_dict(params)
+    model.to("cuda")
+    return model, params
+
+
+def _grad_rel(model, grads):
+    worst = ("", 0.0)
+    for name, p in model.named_parameters():
+        if ".key.bias" in name:
+            continue
+        ref = grads[name]
+        r = float((p.grad.detach().float().cpu() - ref).norm()) / (float(ref.norm()) + 1e-12)
+        if r > worst[1]:
+            worst = (name, r)
+    return worst
+
+
+@pytest.mark.parametrize("pool,fixture", [("cls", "tiny_cls"), ("last", "tiny_last")])
+def test_tiny_three_steps_within_1e3(pkg, golden_dir, pool, fixture):
+    from oracle import meme_oracle as O
+    z = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    cfg = O.tiny_config(pool)
+    model, params = _make(pkg, O, cfg, int(z["seed"]))
+    text, image, mask, labels = (torch.from_numpy(z[k]) for k in ("text", "image", "mask", "labels"))
+    opt = pkg.Adam(model.parameters(), lr=LR)
+    crit = pkg.CrossEntropyLoss()
+    st = O.AdamState()
+    p_ref = params
+    model.train()
+    for step in range(3):
+        opt.zero_grad()
+        output = model(text.cuda(), image.cuda(), mask.cuda())
+        loss = crit(output, labels.cuda())
+        loss.backward()
+        p_next, ref_logits, ref_loss, ref_grads = O.train_step(p_ref, st, text, image, mask, labels, cfg, lr=LR)
+        got = output.detach().float().cpu()
+        assert float((got - ref_logits).abs().max()) <= LOGIT_TOL, (step, got, ref_logits)
+        assert abs(float(loss.detach()) - float(ref_loss)) <= LOGIT_TOL
+        if step == 0:
+            assert float((got - torch.from_numpy(z["logits"])).abs().max()) <= LOGIT_TOL     # transformers golden
+        name, worst = _grad_rel(model, ref_grads)
+        assert worst <= 1e-2, (name, worst)
+        opt.step()
+        p_ref = p_next
+        sd = model.state_dict()
+        for k, ref in p_ref.items():
+            d = (sd[k].detach().float().cpu() - ref).abs()
+            assert float(d.max()) <= 2.05 * (step + 1) * LR, (k, float(d.max()))
+
+
+@pytest.mark.slow
+def test_config3_within_1e3(pkg, golden_dir):
+    """ViT-B/16 + BERT-base(V=64000), 224x224 + S=128 (BASELINE config 3), B=2."""
+    from oracle import meme_oracle as O
+    z = np.load(os.path.join(golden_dir, "config3_b2.npz"))
+    cfg = O.config3("cls")
+    model, params = _make(pkg, O, cfg, int(z["seed"]))
+    text, image, mask = (torch.from_numpy(z[k]) for k in ("text", "image", "mask"))
+    model.eval()
+    with torch.no_grad():
+        got = model(text.cuda(), image.cuda(), mask.cuda()).float().cpu()
+    err = float((got - torch.from_numpy(z["logits"])).abs().max())
+    print("config3 fp16 logits err", err)
+    assert err <= LOGIT_TOL, err
+    labels = torch.tensor([0, 1])
+    _, _, ref_grads = O.loss_and_grads(params, text, image, mask, labels, cfg)
+    model.train()
+    model.forward_backward(text.cuda(), image.cuda(), mask.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    name, worst = _grad_rel(model, ref_grads)
+    print("config3 fp16 worst relative grad error", name, worst)
+    assert worst <= 2e-2, (name, worst)
