@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--tiny", action="store_true", help="tiny model (debug only; not a bench line)")
+    ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
+                    help="16-bit storage / MFMA operand type of the towers (same kernels, same MFMA peak)")
     return ap.parse_args()
 
 
@@ -106,6 +108,7 @@ def main():
                               image=pkg.ImageConfig(image_size=32, hidden=128, layers=2, heads=2, intermediate=256), proj=128)
     else:
         cfg = pkg.ModelConfig()            # config 3
+    cfg.compute_dtype = args.dtype
     model = pkg.MultimodalClassifier.from_config(cfg, device=device, seed=0)
     model.train()
     reducer = None
@@ -161,12 +164,22 @@ def main():
         dom = max(per_tag, key=lambda k: per_tag[k]["total_ms"])
         d = per_tag[dom]
         achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel: from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # tools/traffic_from_pmc.py); PMC counters cannot be read from inside the process
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+            key = f"gemm_kernel<{dom[5]}, {dom[7]}, 1>"
+            if key in tj and not args.tiny and args.batch == 32:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         flop_per_meme = FLOP_PER_MEME if not args.tiny else plan.gemm_flops / args.batch
         out = {
             "metric": "memes/sec (fine-tune step) ViT-B/16+BERT-base bs=32, 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "memes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "Subtask-2C fine-tune step: ViT-B/16 (224x224, 197 tokens) + BERT-base (V=64000, "
                                    f"S={args.seq}) late-fusion, fwd+CE+bwd+Adam, batch {args.batch}/GPU, random-init weights"
                                    + (" [TINY DEBUG MODEL]" if args.tiny else ""),
@@ -174,9 +187,9 @@ def main():
                        "params": model.layout.n_total, "parallelism": f"dp{world}",
                        "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph per backward segment + RCCL all-reduce"),
                        "kernel_launches_per_step": plan.n_launches, "final_loss": round(final_loss, 5)},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_kernel{dom[4:]} (grouped bf16 MFMA GEMM)",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_kernel{dom[4:]} (grouped {args.dtype} MFMA GEMM)",
                          "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": d["launches"], "avg_launch_us": round(d["total_ms"] / d["launches"] * 1e3, 2),
                          "flops_per_launch": round(d["flops"] / d["launches"]),
                          "all_gemm_kernels": {k: {"ms_per_step": round(v["total_ms"], 3),

@@ -6,9 +6,11 @@ import multimodal_propaganda_meme_classification_amd as pkg
 from oracle import meme_oracle as O
 
 
-def run(name, cfg, B, S, seed):
+def run(name, cfg, B, S, seed, dtype="bf16"):
+    name = f"{name}/{dtype}"
     params = O.init_params(cfg, seed)
-    model = pkg.MultimodalClassifier.from_config(pkg.ModelConfig.from_dict(cfg.to_dict()), init=False)
+    d = cfg.to_dict(); d["compute_dtype"] = dtype
+    model = pkg.MultimodalClassifier.from_config(pkg.ModelConfig.from_dict(d), init=False)
     model.load_state_dict(params)
     model.to("cuda")
     text, image, mask, labels = O.synthetic_batch(cfg, B, S, seed=seed + 100)
@@ -38,8 +40,9 @@ def run(name, cfg, B, S, seed):
 
 if __name__ == "__main__":
     torch.set_num_threads(16)
-    run("tiny", O.tiny_config("cls"), 4, 16, 1)
-    run("tiny-last", O.tiny_config("last"), 4, 16, 2)
-    if "--full" in sys.argv:
-        run("config3", O.config3("cls"), 2, 128, 3)
-        run("config3-b4", O.config3("cls"), 4, 128, 4)
+    for dt in ("bf16", "fp16"):
+        run("tiny", O.tiny_config("cls"), 4, 16, 1, dt)
+        run("tiny-last", O.tiny_config("last"), 4, 16, 2, dt)
+        if "--full" in sys.argv:
+            run("config3", O.config3("cls"), 2, 128, 3, dt)
+            run("config3-b4", O.config3("cls"), 4, 128, 4, dt)
