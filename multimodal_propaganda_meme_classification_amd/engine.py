@@ -37,27 +37,92 @@ class Segment:
         self.lib = lib if lib is not None else _lib.load()
         self.calls: List[Tuple] = []
 
-    def c(self, fn_name: str, *args, tag: Optional[str] = None, work: float = 0.0):
-        self.calls.append((getattr(self.lib, fn_name), args, fn_name, tag or fn_name, work))
+    def c(self, fn_name: str, *args, tag: Optional[str] = None, work: float = 0.0, lane: int = 0):
+        self.calls.append((getattr(self.lib, fn_name), args, fn_name, tag or fn_name, work, lane))
 
     def py(self, fn: Callable[[], None]):
-        self.calls.append((None, fn, "py", "py", 0.0))
+        self.calls.append((None, fn, "py", "py", 0.0, 0))
+
+    def wait(self, key: str):
+        """On a multi-stream run: the main stream waits for the lane-1 work of segment `key`."""
+        self.calls.append((None, key, "wait", "wait", 0.0, 0))
+
+    def fork(self):
+        """Marks the point on the main stream that the next lane-2 calls depend on."""
+        self.calls.append((None, None, "fork", "fork", 0.0, 0))
+
+    def join(self):
+        """The main stream waits for every lane-2 call issued since the last join."""
+        self.calls.append((None, None, "join", "join", 0.0, 0))
 
     def run(self, stream: int):
-        for fn, args, name, _, _ in self.calls:
+        for fn, args, name, _, _, _ in self.calls:
             if fn is None:
-                args()
+                if name == "py":
+                    args()
             else:
                 st = fn(*args, stream)
                 if st != 0:
                     _lib.check(st, name)
 
+    def run2(self, main: "torch.cuda.Stream", side: "torch.cuda.Stream", events: Dict[str, "torch.cuda.Event"],
+             aux: Optional["torch.cuda.Stream"] = None):
+        """Multi-stream replay (single GPU).  lane 1 = the weight-gradient GEMMs, which nothing later in the
+        backward chain reads: they go to `side`, forked behind everything issued so far on `main`, and their
+        completion event is stored under this segment's name for a later wait().  lane 2 = the image tower's
+        small kernels (LayerNorm, attention), which run on `aux` beside the text tower's between fork()
+        and join()."""
+        mp, sp = main.cuda_stream, side.cuda_stream
+        ap = aux.cuda_stream if aux is not None else mp
+        forked1 = False
+        fork_ev = None
+        aux_dirty = False
+        for fn, args, name, _, _, lane in self.calls:
+            if fn is None:
+                if name == "py":
+                    args()
+                elif name == "wait":
+                    if args in events:
+                        main.wait_event(events.pop(args))
+                elif name == "fork" and aux is not None:
+                    fork_ev = torch.cuda.Event()
+                    fork_ev.record(main)
+                elif name == "join" and aux is not None and aux_dirty:
+                    d = torch.cuda.Event()
+                    d.record(aux)
+                    main.wait_event(d)
+                    aux_dirty = False
+                continue
+            if lane == 1:
+                if not forked1:
+                    e = torch.cuda.Event()
+                    e.record(main)
+                    side.wait_event(e)
+                    forked1 = True
+                st = fn(*args, sp)
+            elif lane == 2 and aux is not None:
+                if fork_ev is not None:
+                    aux.wait_event(fork_ev)
+                    fork_ev = None
+                aux_dirty = True
+                st = fn(*args, ap)
+            else:
+                st = fn(*args, mp)
+            if st != 0:
+                _lib.check(st, name)
+        assert not aux_dirty, f"segment {self.name}: lane-2 work without a closing join()"
+        if forked1:
+            d = torch.cuda.Event()
+            d.record(side)
+            events[self.name] = d
+
     def run_timed(self, stream: int, tag: str, out: list):
         """Eager replay that brackets every launch tagged `tag` with events on the launch stream;
         appends (start_event, end_event, work) to `out`."""
-        for fn, args, name, t, work in self.calls:
+        for fn, args, name, t, work, _ in self.calls:
             if fn is None:
-                args()
+                if name == "py":
+                    args()
                 continue
             if t == tag:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -122,7 +187,7 @@ class Engine:
         return self.SH[s.offset:s.offset + s.numel * count]
 
     # ---- call builders ---------------------------------------------------------------------------------
-    def _gemm(self, plan: Plan, seg: Segment, probs: List[dict], a_k: bool, b_k: bool):
+    def _gemm(self, plan: Plan, seg: Segment, probs: List[dict], a_k: bool, b_k: bool, lane: int = 0):
         if not probs:
             return
         n = len(probs)
@@ -151,7 +216,7 @@ class Engine:
         plan.keep.append(arr)
         flops = float(sum(2.0 * d["M"] * d["N"] * d["K"] for d in probs))
         plan.gemm_flops += flops
-        seg.c("mh_gemm_bf16_grouped", arr, n, int(a_k), int(b_k), tag=f"gemm<{int(a_k)},{int(b_k)}>", work=flops)
+        seg.c("mh_gemm_bf16_grouped", arr, n, int(a_k), int(b_k), tag=f"gemm<{int(a_k)},{int(b_k)}>", work=flops, lane=lane)
 
     @staticmethod
     def _fwd_prob(x, w, out, T, N, K, **kw):
@@ -167,15 +232,15 @@ class Engine:
         return dict(A=dy, B=x, C=dw, M=N_out, N=K_in, K=T, lda=N_out, ldb=K_in, ldc=K_in, rowsum=db,
                     alpha=1.0 / self.gscale)
 
-    def _ln_fwd(self, seg, x, gname, bname, y, mean, rstd, rows, D, eps, y32=None):
+    def _ln_fwd(self, seg, x, gname, bname, y, mean, rstd, rows, D, eps, y32=None, lane=0):
         seg.c("mh_layernorm_fwd", _ptr(x), _ptr(self.p(gname)), _ptr(self.p(bname)), _ptr(y), _ptr(y32), _ptr(mean),
-              _ptr(rstd), rows, D, float(eps))
+              _ptr(rstd), rows, D, float(eps), lane=lane)
 
-    def _ln_bwd(self, plan, seg, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None):
+    def _ln_bwd(self, plan, seg, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None, lane=0):
         part = torch.empty((2, LN_PARTS, D), dtype=F32, device=self.dev)
         plan.buf[f"lnpart.{gname}"] = part
         seg.c("mh_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(self.p(gname)), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
-              _ptr(part), LN_PARTS, rows, D)
+              _ptr(part), LN_PARTS, rows, D, lane=lane)
         plan._ln_jobs.setdefault(D, []).append((part, self.g(gname), self.g(bname)))
 
     # ---- plan ----------------------------------------------------------------------------------------------
@@ -260,8 +325,12 @@ class Engine:
                           h=alloc(f"i{l}.h", (Ti, Ii)), g=alloc(f"i{l}.g", (Ti, Ii)))
                 il.append(b_)
                 xi.append(alloc(f"i.x{l + 1}", (Ti, Di)))
+                # (forked before the previous layer's closing text LayerNorm, see the end of the loop body)
+                if l == 0:
+                    f.fork()
                 self._ln_fwd(f, xi[l], LI + "layernorm_before.weight", LI + "layernorm_before.bias", b_["u"], b_["m1"],
-                             b_["r1"], Ti, Di, v.ln_eps)
+                             b_["r1"], Ti, Di, v.ln_eps, lane=2)
+            f.join()
             # QKV
             pr = []
             if has_t:
@@ -271,10 +340,12 @@ class Engine:
                 pr.append(self._fwd_prob(b_["u"], self.w(LI + "attention.attention.query.weight", 3), b_["qkv"], Ti,
                                          3 * Di, Di, bias=self.p(LI + "attention.attention.query.bias", 3)))
             self._gemm(pl, f, pr, False, False)
+            f.fork()
+            if has_i:
+                f.c("mh_attn_fwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(b_["lse"]), B, Nt, Hi, lane=2)
             if has_t:
                 f.c("mh_attn_fwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(a["lse"]), B, S, Ht)
-            if has_i:
-                f.c("mh_attn_fwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(b_["lse"]), B, Nt, Hi)
+            f.join()
             # attention output projection + residual
             pr = []
             if has_t:
@@ -284,12 +355,14 @@ class Engine:
                 pr.append(self._fwd_prob(b_["ctx"], self.w(LI + "attention.output.dense.weight"), b_["xp"], Ti, Di, Di,
                                          bias=self.p(LI + "attention.output.dense.bias"), residual=xi[l]))
             self._gemm(pl, f, pr, False, False)
+            f.fork()
+            if has_i:
+                self._ln_fwd(f, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["w"], b_["m2"],
+                             b_["r2"], Ti, Di, v.ln_eps, lane=2)
             if has_t:
                 self._ln_fwd(f, a["a"], LT + "attention.output.LayerNorm.weight", LT + "attention.output.LayerNorm.bias",
                              a["y"], a["m1"], a["r1"], Tt, Dt, t.ln_eps)
-            if has_i:
-                self._ln_fwd(f, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["w"], b_["m2"],
-                             b_["r2"], Ti, Di, v.ln_eps)
+            f.join()
             # FFN up + GELU (pre-activation kept for the backward)
             pr = []
             if has_t:
@@ -308,13 +381,16 @@ class Engine:
                 pr.append(self._fwd_prob(b_["g"], self.w(LI + "output.dense.weight"), xi[l + 1], Ti, Di, Ii,
                                          bias=self.p(LI + "output.dense.bias"), residual=b_["xp"]))
             self._gemm(pl, f, pr, False, False)
+            f.fork()      # the next layer's image LayerNorm (lane 2) runs beside this text LayerNorm
             if has_t:
                 self._ln_fwd(f, a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", xt[l + 1], a["m2"],
                              a["r2"], Tt, Dt, t.ln_eps, y32=xt_last32 if l == Lt - 1 else None)
         # final ViT LayerNorm
         xf = alloc("i.xf", (Ti, Di))
         mf, rf = alloc("i.mf", (Ti,), F32), alloc("i.rf", (Ti,), F32)
-        self._ln_fwd(f, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", xf, mf, rf, Ti, Di, v.ln_eps, y32=xf32)
+        self._ln_fwd(f, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", xf, mf, rf, Ti, Di, v.ln_eps, y32=xf32,
+                     lane=2)
+        f.join()
 
         # head
         pool_index = 0 if cfg.pool == "cls" else S - 1
@@ -346,8 +422,11 @@ class Engine:
             return s
 
         s = seg("bwd_head")
-        dXt = [alloc("t.dX0", (Tt, Dt)), alloc("t.dX1", (Tt, Dt))]
-        dXi = [alloc("i.dX0", (Ti, Di)), alloc("i.dX1", (Ti, Di))]
+        # the weight-gradient GEMMs of layer l may run on a side stream while the chain of layers l-1 and
+        # l-2 proceeds: everything they read is double-buffered by layer parity (dX: rotation of three),
+        # and layer l-2 waits for them before it overwrites those buffers
+        dXt = [alloc(f"t.dX{i}", (Tt, Dt)) for i in range(3)]
+        dXi = [alloc(f"i.dX{i}", (Ti, Di)) for i in range(3)]
         dXf = alloc("i.dXf", (Ti, Di))
         dfeat, dfused = alloc("h.dfeat", (B, 2 * P_), F32), alloc("h.dfused", (B, P_), F32)
         s.py(dXt[0].zero_)
@@ -356,12 +435,14 @@ class Engine:
             _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale))
         self._ln_bwd(pl, s, dXf, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", mf, rf, dXi[0], Ti, Di)
 
-        # shared backward temporaries
-        t_df, t_dh, t_dy = alloc("t.df", (Tt, Dt)), alloc("t.dh", (Tt, It)), alloc("t.dy", (Tt, Dt))
-        t_da, t_dctx, t_dqkv = alloc("t.da", (Tt, Dt)), alloc("t.dctx", (Tt, Dt)), alloc("t.dqkv", (Tt, 3 * Dt))
+        # backward temporaries, one set per layer parity
+        T_ = [dict(df=alloc(f"t.df{i}", (Tt, Dt)), dh=alloc(f"t.dh{i}", (Tt, It)), da=alloc(f"t.da{i}", (Tt, Dt)),
+                   dqkv=alloc(f"t.dqkv{i}", (Tt, 3 * Dt))) for i in range(2)]
+        I_ = [dict(dh=alloc(f"i.dh{i}", (Ti, Ii)), dxp=alloc(f"i.dxp{i}", (Ti, Di)),
+                   dqkv=alloc(f"i.dqkv{i}", (Ti, 3 * Di))) for i in range(2)]
+        t_dy, t_dctx = alloc("t.dy", (Tt, Dt)), alloc("t.dctx", (Tt, Dt))
         t_delta = alloc("t.delta", (B, Ht, S), F32)
-        i_dh, i_dw, i_dxp = alloc("i.dh", (Ti, Ii)), alloc("i.dw", (Ti, Di)), alloc("i.dxp", (Ti, Di))
-        i_dctx, i_dqkv, i_du = alloc("i.dctx", (Ti, Di)), alloc("i.dqkv", (Ti, 3 * Di)), alloc("i.du", (Ti, Di))
+        i_dw, i_dctx, i_du = alloc("i.dw", (Ti, Di)), alloc("i.dctx", (Ti, Di)), alloc("i.du", (Ti, Di))
         i_delta = alloc("i.delta", (B, Hi, Nt), F32)
 
         ct, ci = 0, 0   # current ping-pong index of the incoming gradient
@@ -369,8 +450,11 @@ class Engine:
             has_t, has_i = l < Lt, l < Li
             LT, LI = f"{TXT}encoder.layer.{l}.", f"{IMG}encoder.layer.{l}."
             s = seg(f"bwd_layer_{l}")
+            s.wait(f"bwd_layer_{l + 2}")
             a = tl[l] if has_t else None
             b_ = il[l] if has_i else None
+            t_df, t_dh, t_da, t_dqkv = (T_[l & 1][k] for k in ("df", "dh", "da", "dqkv"))
+            i_dh, i_dxp, i_dqkv = (I_[l & 1][k] for k in ("dh", "dxp", "dqkv"))
             if has_t:   # through the output LayerNorm
                 self._ln_bwd(pl, s, dXt[ct], a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", a["m2"],
                              a["r2"], t_df, Tt, Dt)
@@ -388,12 +472,14 @@ class Engine:
             if has_i:
                 pr.append(self._dgrad_prob(i_dh, self.w(LI + "intermediate.dense.weight"), i_dw, Ti, Ii, Di))
             self._gemm(pl, s, pr, False, True)
+            s.fork()
+            if has_i:
+                self._ln_bwd(pl, s, i_dw, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["m2"],
+                             b_["r2"], i_dxp, Ti, Di, dx_add=dXi[ci], lane=2)
             if has_t:
                 self._ln_bwd(pl, s, t_dy, a["a"], LT + "attention.output.LayerNorm.weight",
                              LT + "attention.output.LayerNorm.bias", a["m1"], a["r1"], t_da, Tt, Dt)
-            if has_i:
-                self._ln_bwd(pl, s, i_dw, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["m2"],
-                             b_["r2"], i_dxp, Ti, Di, dx_add=dXi[ci])
+            s.join()
             # through the attention output projection
             pr = []
             if has_t:
@@ -401,23 +487,25 @@ class Engine:
             if has_i:
                 pr.append(self._dgrad_prob(i_dxp, self.w(LI + "attention.output.dense.weight"), i_dctx, Ti, Di, Di))
             self._gemm(pl, s, pr, False, True)
+            s.fork()
+            if has_i:
+                s.c("mh_attn_bwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(i_dctx), _ptr(b_["lse"]), _ptr(i_delta),
+                    _ptr(i_dqkv), B, Nt, Hi, lane=2)
             if has_t:
                 s.c("mh_attn_bwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(t_dctx), _ptr(a["lse"]), _ptr(t_delta),
                     _ptr(t_dqkv), B, S, Ht)
-            if has_i:
-                s.c("mh_attn_bwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(i_dctx), _ptr(b_["lse"]), _ptr(i_delta),
-                    _ptr(i_dqkv), B, Nt, Hi)
+            s.join()
             # through the QKV projection
             pr = []
             if has_t:
-                pr.append(self._dgrad_prob(t_dqkv, self.w(LT + "attention.self.query.weight", 3), dXt[ct ^ 1], Tt, 3 * Dt, Dt,
+                pr.append(self._dgrad_prob(t_dqkv, self.w(LT + "attention.self.query.weight", 3), dXt[(ct + 1) % 3], Tt, 3 * Dt, Dt,
                                            residual=t_da))
             if has_i:
                 pr.append(self._dgrad_prob(i_dqkv, self.w(LI + "attention.attention.query.weight", 3), i_du, Ti, 3 * Di, Di))
             self._gemm(pl, s, pr, False, True)
             if has_i:
                 self._ln_bwd(pl, s, i_du, xi[l], LI + "layernorm_before.weight", LI + "layernorm_before.bias", b_["m1"],
-                             b_["r1"], dXi[ci ^ 1], Ti, Di, dx_add=i_dxp)
+                             b_["r1"], dXi[(ci + 1) % 3], Ti, Di, dx_add=i_dxp)
             # weight gradients (+ bias gradients as row sums): one grouped launch per tower.  Measured on
             # MI355X: the 4+4 problems in ONE launch (864 tiles = 1.7 waves of 512 resident workgroups)
             # take 254 us, the two 432-tile launches back to back 215 us.
@@ -427,18 +515,18 @@ class Engine:
                     self._wgrad_prob(t_dh, a["y"], self.g(LT + "intermediate.dense.weight"), self.g(LT + "intermediate.dense.bias"), Tt, It, Dt),
                     self._wgrad_prob(t_da, a["ctx"], self.g(LT + "attention.output.dense.weight"), self.g(LT + "attention.output.dense.bias"), Tt, Dt, Dt),
                     self._wgrad_prob(t_dqkv, xt[l], self.g(LT + "attention.self.query.weight", 3), self.g(LT + "attention.self.query.bias", 3), Tt, 3 * Dt, Dt)],
-                    True, True)
+                    True, True, lane=1)
             if has_i:
                 self._gemm(pl, s, [
                     self._wgrad_prob(dXi[ci], b_["g"], self.g(LI + "output.dense.weight"), self.g(LI + "output.dense.bias"), Ti, Di, Ii),
                     self._wgrad_prob(i_dh, b_["w"], self.g(LI + "intermediate.dense.weight"), self.g(LI + "intermediate.dense.bias"), Ti, Ii, Di),
                     self._wgrad_prob(i_dxp, b_["ctx"], self.g(LI + "attention.output.dense.weight"), self.g(LI + "attention.output.dense.bias"), Ti, Di, Di),
                     self._wgrad_prob(i_dqkv, b_["u"], self.g(LI + "attention.attention.query.weight", 3), self.g(LI + "attention.attention.query.bias", 3), Ti, 3 * Di, Di)],
-                    True, True)
+                    True, True, lane=1)
             if has_t:
-                ct ^= 1
+                ct = (ct + 1) % 3
             if has_i:
-                ci ^= 1
+                ci = (ci + 1) % 3
             rng = [r for r in self.layout.layer_ranges if r[0] == l][0]
             pl.bucket_after[s.name] = (rng[1], rng[2])
 
@@ -470,5 +558,5 @@ class Engine:
                 pl.keep.append(arr)
                 s.c("mh_colsum_partials_f32", arr, len(chunk), LN_PARTS, D, 1.0 / self.gscale)
         pl.bucket_after[s.name] = (self.layout.layer_ranges[-1][2], self.layout.n_total)
-        pl.n_launches = len(pl.fwd) + len(pl.loss) + sum(len(x) for x in pl.bwd)
+        pl.n_launches = sum(1 for sg in [pl.fwd, pl.loss] + pl.bwd for c in sg.calls if c[0] is not None)
         return pl
