@@ -82,10 +82,12 @@ typedef struct MhGemmProblem {
 
 int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems, int a_kmajor,
                          int b_kmajor, mh_stream_t stream);
-/* kernel variant for A/B measurements in one process: 0 = 128x128 tile staged global->VGPR->LDS,
- * 1 = 128x128 tile staged by LDS-DMA (buffer_load ... lds), 2 = 256x128 tile, 8 waves, 3-stage LDS-DMA
- * ring with counted vmcnt, 3 = the same ring with the two wave groups in ping-pong R/C slots.
- * Default 1 (or env MEMEHIP_GEMM_VARIANT at first launch). */
+/* kernel variant for A/B measurements in one process (all 128x128x64 tiles unless noted):
+ * 0 = 4 waves, tiles staged global->VGPR->LDS; 1 = 4 waves, LDS-DMA (buffer_load ... lds);
+ * 2 = 256x128 tile, 8 waves, 3-stage LDS-DMA ring with counted vmcnt; 3 = that ring with the two wave
+ * groups in ping-pong read/MFMA slots; 4 = LDS-DMA, 8 waves of 64x32 (default: 4 waves/SIMD hide the
+ * barrier + LDS latency best on this path's shapes); 5 = LDS-DMA, 16 waves of 32x32.
+ * Default 4 (or env MEMEHIP_GEMM_VARIANT at first launch). */
 int mh_gemm_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------

@@ -74,11 +74,11 @@ MH_DEV void store_tile(char* lds, int tid, const i32x4 (&v)[4]) {
 // ---- global -> LDS directly (LDS-DMA, buffer_load ... lds): no VGPR staging, no ds_write pass ---
 // One wave-instruction writes 1 KiB of LDS linearly (base + lane*16), so the swizzle is applied to
 // the per-lane SOURCE address (same involution as store_tile).  Wave w moves pieces 4w..4w+3.
-template <int KMAJOR>
+template <int KMAJOR, int PPW = 4>
 MH_DEV void dma_tile(__amdgpu_buffer_rsrc_t r, int ld, int r0, int k0, int wave, int lane, char* lds) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave * PPW + i;
         uint32_t off;
         if (KMAJOR == 0) {
             const int row = piece * 8 + (lane >> 3);
@@ -125,15 +125,16 @@ MH_DEV h16x8 read_frag(const char* lds, int rb, int kk, int lane) {
 }
 
 // ---- epilogue: f32 tile in LDS -> bias / GELU / gelu' / residual -> 16-B coalesced stores ----------
-template <int TM>
+template <int TM, int NTHR = TM * 2>
 MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n0, int tid) {
     const int M = P.M;
     const int flags = P.flags;
     const int ldc = P.ldc;
     const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
-    const int nthreads = TM * 2;  // 256 threads for TM = 128, 512 for TM = 256
+    constexpr int nthreads = NTHR;
+    constexpr int iters = TM * 16 / NTHR;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < iters; ++it) {
         const int q = it * nthreads + tid;
         const int row = q >> 4, cc = q & 15;
         const int gm = m0 + row, gn = n0 + cc * 8;
@@ -192,8 +193,16 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
     }
 }
 
-template <int LA, int LB, int DMA>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
+// NW = 4: four waves, 64x64 each (2 workgroups/CU = 2 waves/SIMD).  NW = 8 / 16 (LDS-DMA staging only): eight
+// waves of 64x32 / sixteen of 32x32 on the same tile and LDS (4 / 8 waves per SIMD): more waves to cover barrier
+// and LDS latency, at 1.5x / 2x the fragment reads per MFMA.
+template <int LA, int LB, int DMA, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g) {
+    static_assert(NW == 4 || DMA == 1, "register staging is written for 256 threads");
+    constexpr int NWM = NW == 16 ? 4 : 2;      // waves along M
+    constexpr int NWN = NW / NWM;              // waves along N
+    constexpr int NI = BM / NWM / 16;          // 16-row A fragments per wave
+    constexpr int NJ = BN / NWN / 16;          // 16-column B fragments per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- which tile ----------------------------------------------------------------------------
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
 
     const int M = P.M, N = P.N, K = P.K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave / NWN) * (NI * 16), wn0 = (wave % NWN) * (NJ * 16);
 
     const uint32_t a_bytes = (LA == 0) ? (uint32_t)((M - 1) * P.lda + K) * 2u
                                        : (uint32_t)((K - 1) * P.lda + M) * 2u;
@@ -224,15 +233,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
     const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, a_bytes);
     const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, b_bytes);
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accb[4];
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave & 1) == 0);
+    for (int i = 0; i < NI; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave % NWN) == 0);
     h16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (h16)1.0f;
@@ -243,33 +252,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
         const char* lb = cur + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            h16x8 fa[4], fb[4];
+            h16x8 fa[NI], fb[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA>(la, wm0 + i * 16, kk, lane);
+            for (int i = 0; i < NI; ++i) fa[i] = read_frag<LA>(la, wm0 + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
+            for (int j = 0; j < NJ; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = MH_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (do_rowsum) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
                     accb[i] = MH_MFMA_16x16x32(fa[i], ones, accb[i], 0, 0, 0);
             }
         }
     };
     if (DMA) {
-        dma_tile<LA>(ra, P.lda, m0, 0, wave, lane, smem);
-        dma_tile<LB>(rb, P.ldb, n0, 0, wave, lane, smem + BM * BK * 2);
+        dma_tile<LA, 16 / NW>(ra, P.lda, m0, 0, wave, lane, smem);
+        dma_tile<LB, 16 / NW>(rb, P.ldb, n0, 0, wave, lane, smem + BM * BK * 2);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             char* cur = smem + (kt & 1) * STAGE_BYTES;
             char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
             if (kt + 1 < nk) {
-                dma_tile<LA>(ra, P.lda, m0, (kt + 1) * BK, wave, lane, nxt);
-                dma_tile<LB>(rb, P.ldb, n0, (kt + 1) * BK, wave, lane, nxt + BM * BK * 2);
+                dma_tile<LA, 16 / NW>(ra, P.lda, m0, (kt + 1) * BK, wave, lane, nxt);
+                dma_tile<LB, 16 / NW>(rb, P.ldb, n0, (kt + 1) * BK, wave, lane, nxt + BM * BK * 2);
             }
             compute(cur);
             __syncthreads();
@@ -301,18 +310,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
     // ---- epilogue --------------------------------------------------------------------------------
     if (do_rowsum && (lane & 15) == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
                 if (row < M) P.rowsum[row] = accb[i][r] * (P.alpha == 0.f ? 1.0f : P.alpha);
             }
     }
-    float* cs = (float*)smem;  // [128][128] f32, column index XOR-swizzled by row group
+    float* cs = (float*)smem;  // [128][128] f32
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmGroup g) {
             }
     __syncthreads();
 
-    epilogue_rows<BM>(P, cs, m0, n0, tid);
+    epilogue_rows<BM, NW * 64>(P, cs, m0, n0, tid);
 }
 
 // one 1-KiB LDS-DMA piece of a 16-KiB panel ([128 rows][64 k] or [64 k][128 rows]), swizzle on the source
@@ -630,7 +639,8 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
     epilogue_rows<R_BM>(P, cs, m0, n0, tid);
 }
 
-int g_variant = -1;  // -1: read MEMEHIP_GEMM_VARIANT once; 0 = register staging, 1 = LDS-DMA, 2 = 256x128 ring
+int g_variant = -1;  // -1: read MEMEHIP_GEMM_VARIANT once; 0 = register staging, 1 = LDS-DMA 4 waves, 2 = 256x128 ring,
+                     // 3 = ping-pong ring, 4 = LDS-DMA 8 waves (default), 5 = LDS-DMA 16 waves
 
 template <int LA, int LB, int DMA>
 int launch1(const GemmGroup& g, hipStream_t s) {
@@ -641,6 +651,17 @@ int launch1(const GemmGroup& g, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_kernel<LA, LB, DMA>), dim3(g.total_tiles), dim3(NTHREADS), LDS_BYTES, s, g);
+    return mh_launch_status();
+}
+template <int LA, int LB, int NW>
+int launch_nw(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<LA, LB, 1, NW>), dim3(g.total_tiles), dim3(NW * 64), LDS_BYTES, s, g);
     return mh_launch_status();
 }
 template <int LA, int LB>
@@ -670,6 +691,8 @@ int launch(const GemmGroup& g, hipStream_t s) {
     if (g_variant == 0) return launch1<LA, LB, 0>(g, s);
     if (g_variant == 1) return launch1<LA, LB, 1>(g, s);
     if (g_variant == 2) return launch_ring<LA, LB>(g, s);
+    if (g_variant == 4) return launch_nw<LA, LB, 8>(g, s);
+    if (g_variant == 5) return launch_nw<LA, LB, 16>(g, s);
     return launch_pp<LA, LB>(g, s);
 }
 
@@ -680,10 +703,10 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     if (!problems || n_problems < 1 || n_problems > MH_GEMM_MAX_GROUP) return MH_EINVAL;
     if (g_variant < 0) {
         const char* e = getenv("MEMEHIP_GEMM_VARIANT");
-        g_variant = e ? atoi(e) : 1;
-        if (g_variant < 0 || g_variant > 3) g_variant = 1;
+        g_variant = e ? atoi(e) : 4;
+        if (g_variant < 0 || g_variant > 5) g_variant = 4;
     }
-    const int tile_m = g_variant >= 2 ? R_BM : BM;
+    const int tile_m = (g_variant == 2 || g_variant == 3) ? R_BM : BM;
     GemmGroup g;
     g.n = n_problems;
     int total = 0;
@@ -713,7 +736,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
 
 // experiment knob (A/B in one process): 0 = register-staged tiles, 1 = LDS-DMA staged tiles
 extern "C" int mh_gemm_set_variant(int v) {
-    if (v < 0 || v > 3) return MH_EINVAL;
+    if (v < 0 || v > 5) return MH_EINVAL;
     g_variant = v;
     return MH_OK;
 }
