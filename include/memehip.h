@@ -91,7 +91,7 @@ int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems,
 int mh_gemm_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------
- * LayerNorm over the last dim (D % 8 == 0, D <= 4096), one wavefront per row.
+ * LayerNorm over the last dim (D % 8 == 0, D <= 4096 forward, <= 2048 backward), one wavefront per row.
  * replaces nn.LayerNorm inside BertModel (eps 1e-12, post-LN) and timm ViT (eps 1e-6, pre-LN).
  *   fwd:  y = (x - mean) * rstd * gamma + beta ; saves mean[rows], rstd[rows] (f32)
  *   bwd:  dx (bf16; added to dx_add when non-NULL), partial dgamma/dbeta in
