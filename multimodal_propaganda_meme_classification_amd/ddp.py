@@ -27,7 +27,7 @@ class GradientReducer:
 
     def reduce_range(self, rng: Optional[Tuple[int, int]]):
         """Start the all-reduce (SUM) of G[start:end]; returns immediately."""
-        if rng is None or self.world == 1:
+        if rng is None or not dist.is_initialized():
             return
         a, b = rng
         while a < b:
