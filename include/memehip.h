@@ -52,7 +52,7 @@ const char* mh_status_str(int status);
  *   dgrad    dx = dy W      : (0,1)  A=dy[T][N']    B=W[N'][K']   (contracts over N')
  *   wgrad    dW = dy^T x    : (1,1)  A=dy[T][N']    B=x[T][K']    (contracts over T)
  *
- * Epilogue order:  v = acc (+ bias[n]);  if aux: aux[m,n] = bf16(v);  if GELU: v = gelu_erf(v);
+ * Epilogue order:  v = alpha * acc (+ bias[n]);  if drop_rng: v = dropout(v);  if aux: aux[m,n] = bf16(v);  if GELU: v = gelu_erf(v);
  *                  if mul_dgelu: v *= gelu'(mul[m,n]);  if residual: v += residual[m,n];
  *                  C[m,n] = v  (bf16, or f32 when MH_GEMM_OUT_F32; += when MH_GEMM_ACCUM with f32).
  * rowsum (wgrad only, a_kmajor==1): rowsum[m] = sum_k A(m,k)  -- the bias gradient.
@@ -78,6 +78,9 @@ typedef struct MhGemmProblem {
     int32_t lda, ldb, ldc;
     int32_t flags;
     float alpha;          /* accumulator scale applied first (0 means 1): un-scales 16-bit gradient streams */
+    const uint32_t* drop_rng; /* device u32[4] {seed_lo, seed_hi, step, -} or NULL: nn.Dropout on (acc + bias) */
+    float drop_p;
+    uint32_t drop_stream;     /* id of this dropout site (mask = f(rng, site, m * N + n)) */
 } MhGemmProblem;
 
 int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems, int a_kmajor,
@@ -104,7 +107,8 @@ int mh_layernorm_fwd(const void* x /*bf16*/, const float* gamma, const float* be
 int mh_layernorm_bwd(const void* dy /*bf16*/, const void* x /*bf16*/, const float* gamma,
                      const float* mean, const float* rstd, const void* dx_add /*bf16 or NULL*/,
                      void* dx /*bf16*/, float* part /*[2][n_part][D]*/, int n_part, int rows, int D,
-                     mh_stream_t stream);
+                     void* dx_drop /*bf16 or NULL: dx * dropout-mask/(1-p) of the Linear output that fed this LN*/,
+                     const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream);
 /* batched finish of the partial column sums: for every job, out0[d] = sum_i part[0][i][d] and
  * out1[d] = sum_i part[1][i][d] (fixed order => bitwise reproducible); NULL outputs are skipped. */
 #define MH_COLSUM_MAX_JOBS 64
@@ -124,11 +128,14 @@ int mh_colsum_partials_f32(const MhColsumJob* jobs /*host*/, int n_jobs, int n_p
  *   out : bf16 [B][S][H][64] ; lse : f32 [B][H][S]  (log-sum-exp of the scaled scores)
  *   bwd : dqkv bf16 [B][S][3][H][64] from dout, recomputing P from lse; delta = rowsum(dout*out)
  *         is computed inside (workspace delta f32 [B][H][S]).
+ *   rng != NULL, drop_p > 0: dropout on the probabilities (attention_probs_dropout_prob); mask element index
+ *         ((b*H + h)*S + q)*S + k; the backward regenerates the same mask.
  * ------------------------------------------------------------------------------------------ */
 int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int B, int S, int H,
-                mh_stream_t stream);
+                const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream);
 int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
-                const float* lse, float* delta, void* dqkv, int B, int S, int H, mh_stream_t stream);
+                const float* lse, float* delta, void* dqkv, int B, int S, int H, const uint32_t* rng,
+                float drop_p, uint32_t drop_stream, mh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * BERT embeddings: x = LN(word[ids] + pos[s] + type[0]) (BertEmbeddings; ids are the Dataset's
@@ -142,10 +149,16 @@ int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void* out, const
 int mh_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
                       const float* gamma, const float* beta, void* pre /*bf16 [T][D]*/,
                       void* y /*bf16 [T][D]*/, float* mean, float* rstd, int B, int S, int D, int vocab,
-                      float eps, mh_stream_t stream);
+                      float eps, const uint32_t* rng, float drop_p, uint32_t drop_stream /*dropout on y*/,
+                      mh_stream_t stream);
 int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre /*bf16 [T][D]*/, float* dword /*[V][D]*/,
                       float* dpos /*[P][D]*/, float* dtype0 /*[D] or NULL*/, int B, int S, int D,
                       int vocab, int64_t pad_id, float scale, mh_stream_t stream);
+/* Dropout helpers.  mh_dropout_apply: x[i] *= mask(i)/(1-p) in place (16-bit), e.g. the gradient arriving at a
+ * dropped activation.  mh_dropout_mask_u8: the 0/1 mask a site would use for element indices 0..n-1 (tests). */
+int mh_dropout_apply(void* x, int64_t n, const uint32_t* rng, float p, uint32_t stream_id, mh_stream_t stream);
+int mh_dropout_mask_u8(uint8_t* out, int64_t n, const uint32_t* rng, float p, uint32_t stream_id,
+                       mh_stream_t stream);
 /* zero the rows of dword named by ids (cheap re-zero of the dense table after the optimizer step) */
 int mh_zero_rows_f32(const int64_t* ids, float* table, int n_ids, int D, int vocab, mh_stream_t stream);
 
@@ -187,12 +200,14 @@ int mh_head_fwd(const MhHeadParams* p /*host*/, const float* text_hidden /*f32 [
                 const float* image_hidden /*f32 [B][Nt][Di]*/, int text_pool_index, float* pooled
                 /*[B][Dt+Di] f32*/, float* feat /*[B][2P]*/, float* fused /*[B][P]*/,
                 float* logits /*[B][C]*/, int B, int S, int Nt, int Dt, int Di, int P, int C,
-                mh_stream_t stream);
+                const uint32_t* rng, float drop_p, uint32_t drop_stream /*nn.Dropout(0.3) on the pooled text row,
+                Multimodal_example_task2C.txt:160,178; mask index b*Dt + d*/, mh_stream_t stream);
 int mh_head_bwd(const MhHeadParams* p /*host*/, const MhHeadGrads* g /*host*/, const float* dlogits,
                 const float* pooled, const float* feat, const float* fused, float* dfeat /*[B][2P]*/,
                 float* dfused /*[B][P]*/, void* d_text_hidden /*bf16 [B][S][Dt]*/,
                 void* d_image_hidden /*bf16 [B][Nt][Di]*/, int text_pool_index, int B, int S, int Nt,
-                int Dt, int Di, int P, int C, float out_scale, mh_stream_t stream);
+                int Dt, int Di, int P, int C, float out_scale, const uint32_t* rng, float drop_p,
+                uint32_t drop_stream, mh_stream_t stream);
 int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
                   int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream);
 

@@ -28,7 +28,8 @@ class MhGemmProblem(C.Structure):
                 ("residual", c_void_p), ("aux", c_void_p), ("mul", c_void_p), ("rowsum", c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
-                ("flags", C.c_int32), ("alpha", C.c_float)]
+                ("flags", C.c_int32), ("alpha", C.c_float),
+                ("drop_rng", c_void_p), ("drop_p", C.c_float), ("drop_stream", C.c_uint32)]
 
 
 class MhColsumJob(C.Structure):
@@ -48,18 +49,20 @@ _PROTOS = {
     "mh_gemm_bf16_grouped": [C.POINTER(MhGemmProblem), c_int, c_int, c_int, c_void_p],
     "mh_gemm_set_variant": [c_int],
     "mh_layernorm_fwd": [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p],
-    "mh_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p],
+    "mh_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_colsum_partials_f32": [C.POINTER(MhColsumJob), c_int, c_int, c_int, c_float, c_void_p],
-    "mh_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p],
-    "mh_attn_bwd": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p],
-    "mh_bert_embed_fwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "mh_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_attn_bwd": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_bert_embed_fwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_dropout_apply": [c_void_p, c_int64, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_dropout_mask_u8": [c_void_p, c_int64, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_bert_embed_bwd": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p],
     "mh_zero_rows_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mh_patchify": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
     "mh_vit_assemble_fwd": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
     "mh_vit_assemble_bwd": [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p],
-    "mh_head_fwd": [C.POINTER(MhHeadParams), c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p],
-    "mh_head_bwd": [C.POINTER(MhHeadParams), C.POINTER(MhHeadGrads)] + [c_void_p] * 8 + [c_int] * 8 + [c_float, c_void_p],
+    "mh_head_fwd": [C.POINTER(MhHeadParams), c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_head_bwd": [C.POINTER(MhHeadParams), C.POINTER(MhHeadGrads)] + [c_void_p] * 8 + [c_int] * 8 + [c_float, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     "mh_adam_step": [c_void_p] * 5 + [c_int64, c_int64, c_void_p, c_int, c_void_p, c_float, c_void_p],

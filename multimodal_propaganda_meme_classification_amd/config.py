@@ -28,6 +28,8 @@ class TextConfig:
     type_vocab: int = 2
     pad_token_id: int = 0
     ln_eps: float = 1e-12
+    hidden_dropout: float = 0.0        # BertConfig.hidden_dropout_prob (0.1 in the reference's checkpoints)
+    attention_dropout: float = 0.0     # BertConfig.attention_probs_dropout_prob (0.1)
 
 
 @dataclass
@@ -62,12 +64,19 @@ class ModelConfig:
     # the static counterpart of the GradScaler in Multimodal_example_task2C.py:60-64,712-717)
     compute_dtype: str = "bf16"
     grad_stream_scale: float = 0.0      # 0 = automatic: 1 for bf16, 8192 for fp16
+    head_dropout: float = 0.0           # nn.Dropout(0.3) on the pooled text features (...task2C.txt:160); the
+                                        # parity / measurement plan runs every dropout at p = 0
+
+    def with_reference_dropout(self) -> "ModelConfig":
+        """The reference's training-mode dropout: 0.1 hidden / 0.1 attention (BERT), 0.3 head; timm ViT has none."""
+        self.text.hidden_dropout, self.text.attention_dropout, self.head_dropout = 0.1, 0.1, 0.3
+        return self
 
     @staticmethod
     def from_dict(d: dict) -> "ModelConfig":
         return ModelConfig(text=TextConfig(**d["text"]), image=ImageConfig(**d["image"]), proj=d["proj"],
                            num_classes=d["num_classes"], pool=d["pool"], compute_dtype=d.get("compute_dtype", "bf16"),
-                           grad_stream_scale=d.get("grad_stream_scale", 0.0))
+                           grad_stream_scale=d.get("grad_stream_scale", 0.0), head_dropout=d.get("head_dropout", 0.0))
 
     @property
     def stream_scale(self) -> float:
@@ -83,6 +92,9 @@ class ModelConfig:
             raise ValueError(f"Unsupported pooling type: {self.pool}")
         if self.compute_dtype not in ("bf16", "fp16"):
             raise ValueError(f"compute_dtype must be 'bf16' or 'fp16', got {self.compute_dtype!r}")
+        for pr in (self.text.hidden_dropout, self.text.attention_dropout, self.head_dropout):
+            if not 0.0 <= pr < 1.0:
+                raise ValueError(f"dropout probability has to be in [0, 1), got {pr}")
         for nm, c in (("text", self.text), ("image", self.image)):
             if c.hidden % 128 or c.intermediate % 128:
                 raise ValueError(f"{nm}: hidden and intermediate sizes must be multiples of 128 (GEMM tile)")

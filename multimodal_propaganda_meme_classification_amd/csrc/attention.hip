@@ -111,14 +111,16 @@ MH_DEV void store_rows_from_T(h16* __restrict__ base, size_t pitch, int row0, in
 // then every wave sweeps its 32-query tiles with no further barrier or global K/V load (S <= 64*NT_RES).
 // NT_RES == 0: streaming fallback for long sequences (one K/V tile resident at a time).
 // ----------------------------------------------------------------------------------------------
-template <int NW, int NT_RES>
+template <int NW, int NT_RES, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict__ qkv,
                                                            const int64_t* __restrict__ key_mask,
                                                            h16* __restrict__ out, float* __restrict__ lse,
-                                                           int B, int S, int H) {
+                                                           int B, int S, int H, const uint32_t* __restrict__ rng,
+                                                           float drop_p, uint32_t drop_stream) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DropCtx drop = mh_drop_ctx(DROP ? rng : nullptr, drop_p, drop_stream);   // dropout on the probabilities
     char* k_img = smem;
     char* v_img = smem + NTL * IMG;
     float* kbias = (float*)(smem + 2 * NTL * IMG);
@@ -210,6 +212,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
                     ps += p;
                 }
                 l = l * alpha + ps;
+                if (DROP && drop.on) {   // O = drop(P) V: the normaliser l keeps every key, only the PV operand is masked
+                    const uint64_t rowbase = (((uint64_t)bh * S) + (uint64_t)(wq0 + (lane & 31))) * (uint64_t)S;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+                        st[g] *= mh_drop_mul(drop, rowbase + (uint64_t)(t * TILE + sub * 32 + acc_row(g, h)));
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -256,16 +264,19 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const h16* __restrict__
 // ----------------------------------------------------------------------------------------------
 // backward, dQ:  one wave = 32 queries at a time, sweep key tiles (resident K/V when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
-template <int NW, int NT_RES>
+template <int NW, int NT_RES, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restrict__ qkv,
                                                               const int64_t* __restrict__ key_mask,
                                                               const h16* __restrict__ dout,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
-                                                              h16* __restrict__ dqkv, int B, int S, int H) {
+                                                              h16* __restrict__ dqkv, int B, int S, int H,
+                                                              const uint32_t* __restrict__ rng, float drop_p,
+                                                              uint32_t drop_stream) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DropCtx drop = mh_drop_ctx(DROP ? rng : nullptr, drop_p, drop_stream);
     char* k_img = smem;
     char* kt_img = smem + NTL * IMG;
     char* v_img = smem + 2 * NTL * IMG;
@@ -351,7 +362,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
                     for (int e = 0; e < 4; ++e) {
                         const int g = 4 * g4 + e;
                         const float p = __builtin_amdgcn_exp2f(st[g] * c + kb4[e] - lse2);
-                        st[g] = p * (dp[g] - dl);  // dS^T (unscaled)
+                        float dpg = dp[g];
+                        if (DROP && drop.on)   // dP = dP_drop * mask / (1 - p)
+                            dpg *= mh_drop_mul(drop, ((uint64_t)bh * S + (uint64_t)q) * (uint64_t)S +
+                                                         (uint64_t)(t * TILE + sub * 32 + acc_row(g, h)));
+                        st[g] = p * (dpg - dl);  // dS^T (unscaled)
                     }
                 }
 #pragma unroll
@@ -371,16 +386,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
 // ----------------------------------------------------------------------------------------------
 // backward, dK / dV:  one wave = 32 keys at a time, sweep query tiles (resident Q/dO when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
-template <int NW, int NT_RES>
+template <int NW, int NT_RES, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __restrict__ qkv,
                                                                const int64_t* __restrict__ key_mask,
                                                                const h16* __restrict__ dout,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
-                                                               h16* __restrict__ dqkv, int B, int S, int H) {
+                                                               h16* __restrict__ dqkv, int B, int S, int H,
+                                                               const uint32_t* __restrict__ rng, float drop_p,
+                                                               uint32_t drop_stream) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DropCtx drop = mh_drop_ctx(DROP ? rng : nullptr, drop_p, drop_stream);
     char* q_img = smem;
     char* qt_img = smem + NTL * IMG;
     char* do_img = smem + 2 * NTL * IMG;
@@ -467,8 +485,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
                     for (int e = 0; e < 4; ++e) {
                         const int g = 4 * g4 + e;
                         const float p = __builtin_amdgcn_exp2f(st[g] * c + kbias - l4[e]);
-                        pp[g] = p;
-                        st[g] = p * (dp[g] - d4[e]);  // dS (unscaled)
+                        float mul = 1.f;
+                        if (DROP && drop.on)
+                            mul = mh_drop_mul(drop, ((uint64_t)bh * S + (uint64_t)(t * TILE + sub * 32 + 8 * g4 + 4 * h + e)) *
+                                                            (uint64_t)S + (uint64_t)key);
+                        pp[g] = p * mul;                     // drop(P): what multiplied V in the forward
+                        st[g] = p * (dp[g] * mul - d4[e]);   // dS (unscaled)
                     }
                 }
 #pragma unroll
@@ -505,34 +527,44 @@ int split_for(int S) {
 
 }  // namespace
 
+#define ATTN_LAUNCH(KERN, NW_, NT_, GRID, LDS, ...)                                                         \
+    do {                                                                                                 \
+        if (dr) {                                                                                        \
+            static bool once_t = (set_lds(KERN<NW_, NT_, true>, LDS), true);                             \
+            (void)once_t;                                                                                \
+            hipLaunchKernelGGL((KERN<NW_, NT_, true>), GRID, dim3(NW_ * 64), LDS, s, __VA_ARGS__);       \
+        } else {                                                                                         \
+            static bool once_f = (set_lds(KERN<NW_, NT_, false>, LDS), true);                            \
+            (void)once_f;                                                                                \
+            hipLaunchKernelGGL((KERN<NW_, NT_, false>), GRID, dim3(NW_ * 64), LDS, s, __VA_ARGS__);      \
+        }                                                                                                \
+    } while (0)
+
 extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int B, int S,
-                           int H, mh_stream_t stream) {
+                           int H, const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream) {
     if (!qkv || !out || !lse) return MH_EINVAL;
-    if (B < 1 || S < 1 || H < 1) return MH_ESHAPE;
+    if (B < 1 || S < 1 || H < 1 || drop_p < 0.f || drop_p >= 1.f) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const h16* q = (const h16*)qkv;
+    const bool dr = rng && drop_p > 0.f;
     if (S <= 128) {
         constexpr int L = 2 * 2 * IMG + 2 * TILE * 4 + 64;
-        static bool once = (set_lds(attn_fwd_kernel<4, 2>, L), true);
-        (void)once;
-        hipLaunchKernelGGL((attn_fwd_kernel<4, 2>), dim3(split_for(S), B * H), dim3(256), L, s, q, key_mask, (h16*)out, lse, B, S, H);
+        ATTN_LAUNCH(attn_fwd_kernel, 4, 2, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
     } else if (S <= 256) {
         constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
-        static bool once = (set_lds(attn_fwd_kernel<4, 4>, L), true);
-        (void)once;
-        hipLaunchKernelGGL((attn_fwd_kernel<4, 4>), dim3(split_for(S), B * H), dim3(256), L, s, q, key_mask, (h16*)out, lse, B, S, H);
+        ATTN_LAUNCH(attn_fwd_kernel, 4, 4, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
     } else {
         constexpr int L = 2 * IMG + TILE * 4 + 64;
-        hipLaunchKernelGGL((attn_fwd_kernel<4, 0>), dim3((S + 127) / 128, B * H), dim3(256), L, s, q, key_mask, (h16*)out, lse, B, S, H);
+        ATTN_LAUNCH(attn_fwd_kernel, 4, 0, dim3((S + 127) / 128, B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
     }
     return mh_launch_status();
 }
 
 extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
-                           const float* lse, float* delta, void* dqkv, int B, int S, int H,
-                           mh_stream_t stream) {
+                           const float* lse, float* delta, void* dqkv, int B, int S, int H, const uint32_t* rng,
+                           float drop_p, uint32_t drop_stream, mh_stream_t stream) {
     if (!qkv || !out || !dout || !lse || !delta || !dqkv) return MH_EINVAL;
-    if (B < 1 || S < 1 || H < 1) return MH_ESHAPE;
+    if (B < 1 || S < 1 || H < 1 || drop_p < 0.f || drop_p >= 1.f) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int n = B * S * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const h16*)out,
@@ -540,25 +572,22 @@ extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void*
     const h16* q = (const h16*)qkv;
     const h16* dO = (const h16*)dout;
     h16* dq = (h16*)dqkv;
+    const bool dr = rng && drop_p > 0.f;
     if (S <= 128) {
         constexpr int L1 = 3 * 2 * IMG + 2 * TILE * 4 + 64, L2 = 4 * 2 * IMG + 2 * 2 * TILE * 4;
-        static bool once = (set_lds(attn_bwd_dq_kernel<4, 2>, L1), set_lds(attn_bwd_dkv_kernel<4, 2>, L2), true);
-        (void)once;
-        dim3 grid(split_for(S), B * H);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2>), grid, dim3(256), L1, s, q, key_mask, dO, lse, delta, dq, B, S, H);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 2>), grid, dim3(256), L2, s, q, key_mask, dO, lse, delta, dq, B, S, H);
+        const dim3 grid(split_for(S), B * H);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, L1, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 2, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
     } else if (S <= 256) {
         constexpr int L1 = 3 * 4 * IMG + 4 * TILE * 4 + 64, L2 = 4 * 4 * IMG + 2 * 4 * TILE * 4;
-        static bool once = (set_lds(attn_bwd_dq_kernel<4, 4>, L1), set_lds(attn_bwd_dkv_kernel<4, 4>, L2), true);
-        (void)once;
-        dim3 grid(split_for(S), B * H);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 4>), grid, dim3(256), L1, s, q, key_mask, dO, lse, delta, dq, B, S, H);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 4>), grid, dim3(256), L2, s, q, key_mask, dO, lse, delta, dq, B, S, H);
+        const dim3 grid(split_for(S), B * H);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, L1, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 4, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
     } else {
         constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
-        dim3 grid((S + 127) / 128, B * H);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 0>), grid, dim3(256), L1, s, q, key_mask, dO, lse, delta, dq, B, S, H);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 0>), grid, dim3(256), L2, s, q, key_mask, dO, lse, delta, dq, B, S, H);
+        const dim3 grid((S + 127) / 128, B * H);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 0, grid, L1, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
     }
     return mh_launch_status();
 }

@@ -94,6 +94,42 @@ MH_DEV float dgelu_f(float x) {
     return g.cdf + x * g.pdf;
 }
 
+// ---- dropout: stateless counter-based mask ------------------------------------------------------------
+// keep(idx) for element `idx` of dropout site `stream` under the step's rng words {seed_lo, seed_hi, step, -}:
+// two rounds of the lowbias32 integer hash over (seed, step, stream, idx).  The same function regenerates the
+// mask in the backward kernels, so no mask is ever stored.
+MH_DEV uint32_t mh_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+struct DropCtx {
+    uint32_t k0, k1, thresh;
+    float scale;      // 1 / (1 - p)
+    bool on;
+};
+MH_DEV DropCtx mh_drop_ctx(const uint32_t* rng, float p, uint32_t stream) {
+    DropCtx c;
+    c.on = (rng != nullptr) && (p > 0.f);
+    c.k0 = c.k1 = c.thresh = 0;
+    c.scale = 1.f;
+    if (c.on) {
+        c.k0 = mh_hash32(rng[0] ^ (stream * 0x9E3779B9u));
+        c.k1 = mh_hash32(rng[1] + rng[2] * 0x85EBCA6Bu + stream);
+        c.thresh = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
+        c.scale = 1.0f / (1.0f - p);
+    }
+    return c;
+}
+MH_DEV bool mh_keep(const DropCtx& c, uint64_t idx) {
+    const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    return mh_hash32(mh_hash32(lo ^ c.k0) + c.k1 + hi * 0xC2B2AE35u) >= c.thresh;
+}
+// multiplier for element idx: 0 (dropped) or 1/(1-p); 1 when dropout is off
+MH_DEV float mh_drop_mul(const DropCtx& c, uint64_t idx) {
+    if (!c.on) return 1.f;
+    return mh_keep(c, idx) ? c.scale : 0.f;
+}
+
 static inline int mh_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MH_OK : MH_ELAUNCH;

@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
     const float* __restrict__ type0, const float* __restrict__ gamma, const float* __restrict__ beta,
     h16* __restrict__ pre, h16* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int T, int S,
-    int D, int vocab, float eps) {
+    int D, int vocab, float eps, const uint32_t* __restrict__ rng, float drop_p, uint32_t drop_stream) {
+    const DropCtx drop = mh_drop_ctx(rng, drop_p, drop_stream);
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(
                 up.e[e] = mh_f2bf(v[i][e]);
                 const float g = e < 4 ? g0[e & 3] : g1[e & 3];
                 const float b = e < 4 ? b0[e & 3] : b1[e & 3];
-                uy.e[e] = mh_f2bf((v[i][e] - mu) * rs * g + b);
+                uy.e[e] = mh_f2bf(((v[i][e] - mu) * rs * g + b) * mh_drop_mul(drop, (uint64_t)t * D + c + e));
             }
             *(i32x4*)(pre + (size_t)t * D + c) = up.v;
             *(i32x4*)(y + (size_t)t * D + c) = uy.v;
@@ -243,6 +244,25 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_copy_kernel(const h16* _
     *(i32x4*)(dproj + row * D + c) = *(const i32x4*)(dx + ((size_t)b * (Np + 1) + 1 + p) * D + c);
 }
 
+// x[i] *= mask(i) / (1 - p), in place (16-bit), 8 elements per thread
+__global__ __launch_bounds__(256) void dropout_apply_kernel(h16* __restrict__ x, int64_t n, const uint32_t* __restrict__ rng,
+                                                            float p, uint32_t stream_id) {
+    const DropCtx drop = mh_drop_ctx(rng, p, stream_id);
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    Pack8 u;
+    u.v = *(const i32x4*)(x + i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u.e[e] = mh_f2bf(mh_bf2f(u.e[e]) * mh_drop_mul(drop, (uint64_t)(i + e)));
+    *(i32x4*)(x + i) = u.v;
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n,
+                                                           const uint32_t* __restrict__ rng, float p, uint32_t stream_id) {
+    const DropCtx drop = mh_drop_ctx(rng, p, stream_id);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = drop.on ? (mh_keep(drop, (uint64_t)i) ? 1 : 0) : 1;
+}
+
 }  // namespace
 
 #define NCH_DISPATCH(NAME, ...)                                         \
@@ -256,13 +276,14 @@ __global__ __launch_bounds__(256) void vit_assemble_bwd_copy_kernel(const h16* _
 
 extern "C" int mh_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
                                  const float* gamma, const float* beta, void* pre, void* y, float* mean,
-                                 float* rstd, int B, int S, int D, int vocab, float eps, mh_stream_t stream) {
+                                 float* rstd, int B, int S, int D, int vocab, float eps, const uint32_t* rng,
+                                 float drop_p, uint32_t drop_stream, mh_stream_t stream) {
     if (!ids || !word || !pos || !gamma || !beta || !pre || !y || !mean || !rstd) return MH_EINVAL;
     if (B < 1 || S < 1 || D < 8 || (D % 8) || D > 4096 || vocab < 1) return MH_ESHAPE;
     const int T = B * S;
     hipStream_t s = (hipStream_t)stream;
     NCH_DISPATCH(bert_embed_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, word, pos, type0, gamma, beta,
-                 (h16*)pre, (h16*)y, mean, rstd, T, S, D, vocab, eps);
+                 (h16*)pre, (h16*)y, mean, rstd, T, S, D, vocab, eps, rng, drop_p, drop_stream);
     return mh_launch_status();
 }
 
@@ -320,5 +341,21 @@ extern "C" int mh_vit_assemble_bwd(const void* dx, void* dproj, float* dcls, flo
     NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const h16*)dx, dpos, B, S, D, scale);
     // d cls = sum_b dx[b][0] = dpos row 0
     hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dpos, dcls, 1, D);
+    return mh_launch_status();
+}
+
+extern "C" int mh_dropout_apply(void* x, int64_t n, const uint32_t* rng, float p, uint32_t stream_id, mh_stream_t stream) {
+    if (!x) return MH_EINVAL;
+    if (n < 8 || (n % 8) || p < 0.f || p >= 1.f) return MH_ESHAPE;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (h16*)x, n, rng, p, stream_id);
+    return mh_launch_status();
+}
+extern "C" int mh_dropout_mask_u8(uint8_t* out, int64_t n, const uint32_t* rng, float p, uint32_t stream_id,
+                                  mh_stream_t stream) {
+    if (!out) return MH_EINVAL;
+    if (n < 1 || p < 0.f || p >= 1.f) return MH_ESHAPE;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       rng, p, stream_id);
     return mh_launch_status();
 }

@@ -125,12 +125,13 @@ MH_DEV h16x8 read_frag(const char* lds, int rb, int kk, int lane) {
 }
 
 // ---- epilogue: f32 tile in LDS -> bias / GELU / gelu' / residual -> 16-B coalesced stores ----------
-template <int TM, int NTHR = TM * 2>
+template <int TM, int NTHR = TM * 2, bool DROP = true>
 MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n0, int tid) {
     const int M = P.M;
     const int flags = P.flags;
     const int ldc = P.ldc;
     const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
+    const DropCtx drop = mh_drop_ctx(DROP ? P.drop_rng : nullptr, P.drop_p, P.drop_stream);
     constexpr int nthreads = NTHR;
     constexpr int iters = TM * 16 / NTHR;
 #pragma unroll
@@ -153,6 +154,10 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
         }
         const size_t o = (size_t)gm * ldc + gn;
+        if (DROP && drop.on) {     // nn.Dropout on the Linear output (BertSelfOutput / BertOutput), before the residual add
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= mh_drop_mul(drop, (uint64_t)gm * (uint64_t)P.N + (uint64_t)(gn + e));
+        }
         if (P.aux) {
             Pack8 u;
 #pragma unroll
@@ -196,7 +201,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
 // NW = 4: four waves, 64x64 each (2 workgroups/CU = 2 waves/SIMD).  NW = 8 / 16 (LDS-DMA staging only): eight
 // waves of 64x32 / sixteen of 32x32 on the same tile and LDS (4 / 8 waves per SIMD): more waves to cover barrier
 // and LDS latency, at 1.5x / 2x the fragment reads per MFMA.
-template <int LA, int LB, int DMA, int NW = 4>
+template <int LA, int LB, int DMA, int NW = 4, bool DROP = true>
 __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g) {
     static_assert(NW == 4 || DMA == 1, "register staging is written for 256 threads");
     constexpr int NWM = NW == 16 ? 4 : 2;      // waves along M
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
             }
     __syncthreads();
 
-    epilogue_rows<BM, NW * 64>(P, cs, m0, n0, tid);
+    epilogue_rows<BM, NW * 64, DROP>(P, cs, m0, n0, tid);
 }
 
 // one 1-KiB LDS-DMA piece of a 16-KiB panel ([128 rows][64 k] or [64 k][128 rows]), swizzle on the source
@@ -653,16 +658,23 @@ int launch1(const GemmGroup& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<LA, LB, DMA>), dim3(g.total_tiles), dim3(NTHREADS), LDS_BYTES, s, g);
     return mh_launch_status();
 }
-template <int LA, int LB, int NW>
-int launch_nw(const GemmGroup& g, hipStream_t s) {
+template <int LA, int LB, int NW, bool DROP>
+int launch_nw2(const GemmGroup& g, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB, 1, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB, 1, NW, DROP>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<LA, LB, 1, NW>), dim3(g.total_tiles), dim3(NW * 64), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_kernel<LA, LB, 1, NW, DROP>), dim3(g.total_tiles), dim3(NW * 64), LDS_BYTES, s, g);
     return mh_launch_status();
+}
+template <int LA, int LB, int NW>
+int launch_nw(const GemmGroup& g, hipStream_t s) {
+    bool any_drop = false;     // the dropout epilogue is compiled only into the variant that needs it
+    for (int i = 0; i < g.n; ++i) any_drop |= (g.d[i].p.drop_rng != nullptr && g.d[i].p.drop_p > 0.f);
+    if (LA == 0 && LB == 0 && any_drop) return launch_nw2<LA, LB, NW, true>(g, s);
+    return launch_nw2<LA, LB, NW, false>(g, s);
 }
 template <int LA, int LB>
 int launch_ring(const GemmGroup& g, hipStream_t s) {

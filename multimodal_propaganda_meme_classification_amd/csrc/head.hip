@@ -7,14 +7,18 @@ namespace {
 constexpr int RB = 32;  // batch rows held in registers per pass
 
 // pooled[b] = [ text_hidden[b][pool][:], image_hidden[b][0][:] ]
+// (+ nn.Dropout(0.3) on the pooled text features, Multimodal_example_task2C.txt:160,178)
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ th, const float* __restrict__ ih,
                                                    float* __restrict__ pooled, int B, int S, int Nt, int Dt, int Di,
-                                                   int pool) {
+                                                   int pool, const uint32_t* __restrict__ rng, float drop_p,
+                                                   uint32_t drop_stream) {
+    const DropCtx drop = mh_drop_ctx(rng, drop_p, drop_stream);
     const int Dp = Dt + Di;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * Dp) return;
     const int b = idx / Dp, d = idx % Dp;
-    pooled[idx] = d < Dt ? th[((size_t)b * S + pool) * Dt + d] : ih[(size_t)b * Nt * Di + (d - Dt)];
+    pooled[idx] = d < Dt ? th[((size_t)b * S + pool) * Dt + d] * mh_drop_mul(drop, (uint64_t)b * Dt + d)
+                         : ih[(size_t)b * Nt * Di + (d - Dt)];
 }
 
 // y[m][n] = b[n] + sum_k x[m][k] W[n][k] ; one wave per output column n
@@ -51,7 +55,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, int ldy,
                                                         const float* __restrict__ W, void* __restrict__ dx,
-                                                        size_t ldx, int M, int N, int K, float scale) {
+                                                        size_t ldx, int M, int N, int K, float scale,
+                                                        const uint32_t* __restrict__ rng, float drop_p,
+                                                        uint32_t drop_stream) {
+    const DropCtx drop = mh_drop_ctx(rng, drop_p, drop_stream);
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int m = blockIdx.y;
     if (k >= K) return;
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
     float acc = 0.f;
 #pragma unroll 8
     for (int n = 0; n < N; ++n) acc += d[n] * W[(size_t)n * K + k];
-    if (OUT_BF16) ((h16*)dx)[(size_t)m * ldx + k] = mh_f2bf(acc * scale);
+    if (OUT_BF16) ((h16*)dx)[(size_t)m * ldx + k] = mh_f2bf(acc * scale * mh_drop_mul(drop, (uint64_t)m * K + k));
     else ((float*)dx)[(size_t)m * ldx + k] = acc;
 }
 
@@ -132,14 +139,15 @@ int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y
 
 extern "C" int mh_head_fwd(const MhHeadParams* p, const float* text_hidden, const float* image_hidden,
                            int text_pool_index, float* pooled, float* feat, float* fused, float* logits, int B,
-                           int S, int Nt, int Dt, int Di, int P, int C, mh_stream_t stream) {
+                           int S, int Nt, int Dt, int Di, int P, int C, const uint32_t* rng, float drop_p,
+                           uint32_t drop_stream, mh_stream_t stream) {
     if (!p || !text_hidden || !image_hidden || !pooled || !feat || !fused || !logits) return MH_EINVAL;
     if (!p->Wt || !p->bt || !p->Wi || !p->bi || !p->Wf || !p->bf_ || !p->Wo || !p->bo) return MH_EINVAL;
     if (B < 1 || text_pool_index < 0 || text_pool_index >= S || Nt < 1 || P < 1 || C < 1) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Dp = Dt + Di;
     hipLaunchKernelGGL(pool_kernel, dim3((B * Dp + 255) / 256), dim3(256), 0, s, text_hidden,
-                       image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index);
+                       image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index, rng, drop_p, drop_stream);
     linear_fwd(pooled, Dp, p->Wt, p->bt, feat, 2 * P, B, P, Dt, s);
     linear_fwd(pooled + Dt, Dp, p->Wi, p->bi, feat + P, 2 * P, B, P, Di, s);
     linear_fwd(feat, 2 * P, p->Wf, p->bf_, fused, P, B, P, 2 * P, s);
@@ -150,7 +158,8 @@ extern "C" int mh_head_fwd(const MhHeadParams* p, const float* text_hidden, cons
 extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const float* dlogits, const float* pooled,
                            const float* feat, const float* fused, float* dfeat, float* dfused, void* d_text_hidden,
                            void* d_image_hidden, int text_pool_index, int B, int S, int Nt, int Dt, int Di, int P,
-                           int C, float out_scale, mh_stream_t stream) {
+                           int C, float out_scale, const uint32_t* rng, float drop_p, uint32_t drop_stream,
+                           mh_stream_t stream) {
     if (!p || !g || !dlogits || !pooled || !feat || !fused || !dfeat || !dfused || !d_text_hidden ||
         !d_image_hidden)
         return MH_EINVAL;
@@ -163,12 +172,12 @@ extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const fl
     hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(P), C), dim3(256), 0, s, dlogits, C, fused, P, g->Wo, g->bo, B,
                        C, P);
     hipLaunchKernelGGL((linear_dx_kernel<false>), dim3(blocks(P), B), dim3(256), 0, s, dlogits, C, p->Wo,
-                       (void*)dfused, (size_t)P, B, C, P, 1.0f);
+                       (void*)dfused, (size_t)P, B, C, P, 1.0f, nullptr, 0.f, 0u);
     // fusion_fc
     hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(2 * P), P), dim3(256), 0, s, dfused, P, feat, 2 * P, g->Wf,
                        g->bf_, B, P, 2 * P);
     hipLaunchKernelGGL((linear_dx_kernel<false>), dim3(blocks(2 * P), B), dim3(256), 0, s, dfused, P, p->Wf,
-                       (void*)dfeat, (size_t)(2 * P), B, P, 2 * P, 1.0f);
+                       (void*)dfeat, (size_t)(2 * P), B, P, 2 * P, 1.0f, nullptr, 0.f, 0u);
     // bert_fc / image_fc
     hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(Dt), P), dim3(256), 0, s, dfeat, 2 * P, pooled, Dp, g->Wt,
                        g->bt, B, P, Dt);
@@ -176,9 +185,9 @@ extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const fl
                        g->Wi, g->bi, B, P, Di);
     // gradients of the pooled rows go straight into the [B][S][D] hidden-state gradient buffers
     hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Dt), B), dim3(256), 0, s, dfeat, 2 * P, p->Wt,
-                       (void*)((h16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt, B, P, Dt, out_scale);
+                       (void*)((h16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt, B, P, Dt, out_scale, rng, drop_p, drop_stream);
     hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Di), B), dim3(256), 0, s, dfeat + P, 2 * P, p->Wi,
-                       d_image_hidden, (size_t)Nt * Di, B, P, Di, out_scale);
+                       d_image_hidden, (size_t)Nt * Di, B, P, Di, out_scale, nullptr, 0.f, 0u);
     return mh_launch_status();
 }
 

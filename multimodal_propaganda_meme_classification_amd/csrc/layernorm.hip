@@ -99,14 +99,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const h16* __restrict__ x, 
     }
 }
 
-template <int NCH>
+template <int NCH, bool DROP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16* __restrict__ dy, const h16* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
                                                      const h16* __restrict__ dx_add, h16* __restrict__ dx,
-                                                     float* __restrict__ part, int n_part, int rows, int D) {
-    __shared__ float red[4][2 * NCH * 512];
+                                                     float* __restrict__ part, int n_part, int rows, int D,
+                                                     h16* __restrict__ dx_drop, const uint32_t* __restrict__ rng,
+                                                     float drop_p, uint32_t drop_stream) {
+    __shared__ float red[4][64 * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float g[NCH][8], dg[NCH][8], db[NCH][8];
     load_row_f32<NCH>(gamma, D, lane, g);
@@ -115,88 +117,75 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16* __restrict__ dy,
 #pragma unroll
         for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
     const float invD = 1.0f / (float)D;
-    // two rows in flight per wave: the loads of the next row are issued before the current row's reductions
-    struct RowRegs {
-        float xv[NCH][8], dv[NCH][8], av[NCH][8];
-        float mu, rs;
-    };
-    auto fetch = [&](int row, RowRegs& r) {
-        load_row<NCH>(x + (size_t)row * D, D, lane, r.xv);
-        load_row<NCH>(dy + (size_t)row * D, D, lane, r.dv);
-        if (dx_add) load_row<NCH>(dx_add + (size_t)row * D, D, lane, r.av);
-        r.mu = mean[row];
-        r.rs = rstd[row];
-    };
-    auto process = [&](int row, RowRegs& r) {
+    const DropCtx drop = mh_drop_ctx(DROP ? rng : nullptr, drop_p, drop_stream);
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        float xv[NCH][8], dv[NCH][8];
+        load_row<NCH>(x + (size_t)row * D, D, lane, xv);
+        load_row<NCH>(dy + (size_t)row * D, D, lane, dv);
+        const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const bool ok = (lane + 64 * i) * 8 < D;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xh = ok ? (r.xv[i][e] - r.mu) * r.rs : 0.f;
-                const float dyg = r.dv[i][e] * g[i][e];
-                r.xv[i][e] = xh;
-                dg[i][e] += r.dv[i][e] * xh;
-                db[i][e] += r.dv[i][e];
+                const float xh = ok ? (xv[i][e] - mu) * rs : 0.f;
+                const float dyg = dv[i][e] * g[i][e];
+                xv[i][e] = xh;
+                dg[i][e] += dv[i][e] * xh;
+                db[i][e] += dv[i][e];
                 c1 += dyg;
                 c2 += dyg * xh;
             }
         }
         c1 = wave_sum(c1) * invD;
         c2 = wave_sum(c2) * invD;
+        if (dx_add) {
+            float av[NCH][8];
+            load_row<NCH>(dx_add + (size_t)row * D, D, lane, av);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i)
+            for (int i = 0; i < NCH; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = r.rs * (r.dv[i][e] * g[i][e] - c1 - r.xv[i][e] * c2);
-                if (dx_add) v += r.av[i][e];
-                r.dv[i][e] = v;
-            }
-        store_row<NCH>(dx + (size_t)row * D, D, lane, r.dv);
-    };
-    const int stride = gridDim.x * 4;
-    int row = blockIdx.x * 4 + wave;
-    if constexpr (NCH <= 1) {   // (measured: no gain at D = 768, and it doubles the registers)
-        RowRegs ra, rb;
-        if (row < rows) fetch(row, ra);
-        while (row < rows) {
-            const int r1 = row + stride;
-            if (r1 < rows) fetch(r1, rb);
-            process(row, ra);
-            if (r1 >= rows) break;
-            const int r2 = r1 + stride;
-            if (r2 < rows) fetch(r2, ra);
-            process(r1, rb);
-            row = r2;
+                for (int e = 0; e < 8; ++e)
+                    dv[i][e] = rs * (dv[i][e] * g[i][e] - c1 - xv[i][e] * c2) + av[i][e];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[i][e] = rs * (dv[i][e] * g[i][e] - c1 - xv[i][e] * c2);
         }
-    } else {   // wide rows: one row at a time (two would spill)
-        RowRegs ra;
-        for (; row < rows; row += stride) {
-            fetch(row, ra);
-            process(row, ra);
+        store_row<NCH>(dx + (size_t)row * D, D, lane, dv);
+        if (DROP) {    // gradient w.r.t. the dropped Linear output that fed this LayerNorm: dx * mask / (1 - p)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = (lane + 64 * i) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[i][e] *= mh_drop_mul(drop, (uint64_t)row * D + c + e);
+            }
+            store_row<NCH>(dx_drop + (size_t)row * D, D, lane, dv);
         }
     }
-    // cross-wave reduce of the column partials: everything to LDS at once, one barrier
+    // cross-wave reduce of the column partials, one chunk slot at a time (8 KB of LDS: a workgroup must fit
+    // beside two 64-KB GEMM workgroups when the weight-gradient GEMMs run on the side stream)
     float* pg = part + (size_t)blockIdx.x * D;
     float* pb = part + (size_t)n_part * D + (size_t)blockIdx.x * D;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[wave][(0 * NCH + i) * 512 + lane * 8 + e] = dg[i][e];
-            red[wave][(1 * NCH + i) * 512 + lane * 8 + e] = db[i][e];
-        }
-    __syncthreads();
+        for (int i = 0; i < NCH; ++i) {
+            __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2 * NCH * 2; ++k) {
-        const int idx = threadIdx.x + 256 * k;          // [pass][chunk slot][lane*8+e]
-        const int pass = idx / (NCH * 512), rem = idx % (NCH * 512);
-        const int i = rem / 512, cidx = rem % 512;
-        const int col = (cidx >> 3) * 8 + 512 * i + (cidx & 7);
-        if (col < D) {
-            const float s = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
-            (pass == 0 ? pg : pb)[col] = s;
+            for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = pass == 0 ? dg[i][e] : db[i][e];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int cidx = threadIdx.x + 256 * k;  // = l*8+e
+                const int col = (cidx >> 3) * 8 + 64 * 8 * i + (cidx & 7);
+                if (col < D) {
+                    const float s = red[0][cidx] + red[1][cidx] + red[2][cidx] + red[3][cidx];
+                    (pass == 0 ? pg : pb)[col] = s;
+                }
+            }
         }
     }
 }
@@ -248,17 +237,20 @@ extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* 
 
 extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, const void* dx_add, void* dx, float* part, int n_part, int rows,
-                                int D, mh_stream_t stream) {
+                                int D, void* dx_drop, const uint32_t* rng, float drop_p, uint32_t drop_stream,
+                                mh_stream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !part) return MH_EINVAL;
     if (rows < 1 || n_part < 1 || D < 8 || (D % 8) || D > 2048) return MH_ESHAPE;   // backward: D <= 2048
     hipStream_t s = (hipStream_t)stream;
     {
         const int nch = (D / 8 + 63) / 64;
 #define LN_BWD_ARGS dim3(n_part), dim3(256), 0, s, (const h16*)dy, (const h16*)x, gamma, mean, rstd, \
-                    (const h16*)dx_add, (h16*)dx, part, n_part, rows, D
-        if (nch <= 1) hipLaunchKernelGGL((ln_bwd_kernel<1>), LN_BWD_ARGS);
-        else if (nch <= 2) hipLaunchKernelGGL((ln_bwd_kernel<2>), LN_BWD_ARGS);
-        else hipLaunchKernelGGL((ln_bwd_kernel<4>), LN_BWD_ARGS);
+                    (const h16*)dx_add, (h16*)dx, part, n_part, rows, D, (h16*)dx_drop, rng, drop_p, drop_stream
+        const bool dr = dx_drop && rng && drop_p > 0.f;
+        if (dx_drop && !dr) return MH_EINVAL;
+        if (nch <= 1) { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<1, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), LN_BWD_ARGS); }
+        else if (nch <= 2) { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<2, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<2, false>), LN_BWD_ARGS); }
+        else { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<4, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<4, false>), LN_BWD_ARGS); }
 #undef LN_BWD_ARGS
     }
     return mh_launch_status();

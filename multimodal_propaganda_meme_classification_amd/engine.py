@@ -213,6 +213,8 @@ class Engine:
             e.flags = (MH_GEMM_GELU if d.get("gelu") else 0) | (MH_GEMM_OUT_F32 if Cm.dtype == F32 else 0) | \
                       (MH_GEMM_ACCUM if d.get("accum") else 0)
             e.alpha = float(d.get("alpha", 1.0))
+            if d.get("drop") is not None:
+                e.drop_rng, e.drop_p, e.drop_stream = d["drop"]
         plan.keep.append(arr)
         flops = float(sum(2.0 * d["M"] * d["N"] * d["K"] for d in probs))
         plan.gemm_flops += flops
@@ -236,21 +238,27 @@ class Engine:
         seg.c("mh_layernorm_fwd", _ptr(x), _ptr(self.p(gname)), _ptr(self.p(bname)), _ptr(y), _ptr(y32), _ptr(mean),
               _ptr(rstd), rows, D, float(eps), lane=lane)
 
-    def _ln_bwd(self, plan, seg, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None, lane=0):
+    def _ln_bwd(self, plan, seg, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None, lane=0, dx_drop=None,
+                drop=None):
         part = torch.empty((2, LN_PARTS, D), dtype=F32, device=self.dev)
         plan.buf[f"lnpart.{gname}"] = part
+        rng, p_, sid = drop if (drop is not None and dx_drop is not None) else (None, 0.0, 0)
         seg.c("mh_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(self.p(gname)), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
-              _ptr(part), LN_PARTS, rows, D, lane=lane)
+              _ptr(part), LN_PARTS, rows, D, _ptr(dx_drop) if rng is not None else None, rng, float(p_), int(sid),
+              lane=lane)
         plan._ln_jobs.setdefault(D, []).append((part, self.g(gname), self.g(bname)))
 
     # ---- plan ----------------------------------------------------------------------------------------------
-    def plan(self, B: int, S: int) -> Plan:
-        key = (B, S)
+    def plan(self, B: int, S: int, training: bool = True) -> Plan:
+        """Plans differ between train and eval only when some dropout probability is non-zero."""
+        cfg = self.cfg
+        has_drop = (cfg.text.hidden_dropout > 0 or cfg.text.attention_dropout > 0 or cfg.head_dropout > 0)
+        key = (B, S, bool(training and has_drop))
         if key not in self.plans:
-            self.plans[key] = self._build(B, S)
+            self.plans[key] = self._build(B, S, key[2])
         return self.plans[key]
 
-    def _build(self, B: int, S: int) -> Plan:
+    def _build(self, B: int, S: int, dropout_on: bool = False) -> Plan:
         cfg, t, v = self.cfg, self.cfg.text, self.cfg.image
         if S > t.max_position:
             raise ValueError(f"sequence length {S} > max_position {t.max_position}")
@@ -259,6 +267,19 @@ class Engine:
         pl = Plan(B, S, self.lib)
         pl._ln_jobs = {}
         BF16 = self.T16          # every 16-bit buffer below uses the configured storage type
+        # dropout sites: (rng words pointer, p, site id); None when off.  rng = int32[4] {seed_lo, seed_hi, step, -}
+        rng_t = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        pl.buf["rng"] = rng_t
+        pl.dropout_on = dropout_on
+        p_h = t.hidden_dropout if dropout_on else 0.0
+        p_a = t.attention_dropout if dropout_on else 0.0
+        p_head = cfg.head_dropout if dropout_on else 0.0
+
+        def site(p_, sid):
+            return (rng_t.data_ptr(), float(p_), int(sid)) if p_ > 0 else None
+
+        def site_args(p_, sid):
+            return (rng_t.data_ptr(), float(p_), int(sid)) if p_ > 0 else (None, 0.0, 0)
         dev = self.dev
         Dt, It, Ht, Lt = t.hidden, t.intermediate, t.heads, t.layers
         Di, Ii, Hi, Li = v.hidden, v.intermediate, v.heads, v.layers
@@ -290,7 +311,7 @@ class Engine:
         f.c("mh_bert_embed_fwd", _ptr(ids), _ptr(self.p(TXT + "embeddings.word_embeddings.weight")),
             _ptr(self.p(TXT + "embeddings.position_embeddings.weight")), _ptr(type0),
             _ptr(self.p(TXT + "embeddings.LayerNorm.weight")), _ptr(self.p(TXT + "embeddings.LayerNorm.bias")),
-            _ptr(pre0), _ptr(xt[0]), _ptr(m0), _ptr(r0), B, S, Dt, t.vocab_size, float(t.ln_eps))
+            _ptr(pre0), _ptr(xt[0]), _ptr(m0), _ptr(r0), B, S, Dt, t.vocab_size, float(t.ln_eps), *site_args(p_h, 1))
         # image embeddings
         patches = alloc("i.patches", (B * Np, Kp))
         proj = alloc("i.proj", (B * Np, Di))
@@ -342,15 +363,17 @@ class Engine:
             self._gemm(pl, f, pr, False, False)
             f.fork()
             if has_i:
-                f.c("mh_attn_fwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(b_["lse"]), B, Nt, Hi, lane=2)
+                f.c("mh_attn_fwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(b_["lse"]), B, Nt, Hi, None, 0.0, 0, lane=2)
             if has_t:
-                f.c("mh_attn_fwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(a["lse"]), B, S, Ht)
+                f.c("mh_attn_fwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(a["lse"]), B, S, Ht,
+                    *site_args(p_a, 16 * (l + 1) + 1))
             f.join()
             # attention output projection + residual
             pr = []
             if has_t:
                 pr.append(self._fwd_prob(a["ctx"], self.w(LT + "attention.output.dense.weight"), a["a"], Tt, Dt, Dt,
-                                         bias=self.p(LT + "attention.output.dense.bias"), residual=xt[l]))
+                                         bias=self.p(LT + "attention.output.dense.bias"), residual=xt[l],
+                                         drop=site(p_h, 16 * (l + 1) + 2)))
             if has_i:
                 pr.append(self._fwd_prob(b_["ctx"], self.w(LI + "attention.output.dense.weight"), b_["xp"], Ti, Di, Di,
                                          bias=self.p(LI + "attention.output.dense.bias"), residual=xi[l]))
@@ -376,7 +399,8 @@ class Engine:
             pr = []
             if has_t:
                 pr.append(self._fwd_prob(a["g"], self.w(LT + "output.dense.weight"), a["f"], Tt, Dt, It,
-                                         bias=self.p(LT + "output.dense.bias"), residual=a["y"]))
+                                         bias=self.p(LT + "output.dense.bias"), residual=a["y"],
+                                         drop=site(p_h, 16 * (l + 1) + 3)))
             if has_i:
                 pr.append(self._fwd_prob(b_["g"], self.w(LI + "output.dense.weight"), xi[l + 1], Ti, Di, Ii,
                                          bias=self.p(LI + "output.dense.bias"), residual=b_["xp"]))
@@ -405,7 +429,7 @@ class Engine:
         feat, fused = alloc("h.feat", (B, 2 * P_), F32), alloc("h.fused", (B, P_), F32)
         logits = alloc("logits", (B, Cn), F32)
         f.c("mh_head_fwd", C.byref(hp), _ptr(xt_last32), _ptr(xf32), pool_index, _ptr(pooled), _ptr(feat), _ptr(fused),
-            _ptr(logits), B, S, Nt, Dt, Di, P_, Cn)
+            _ptr(logits), B, S, Nt, Dt, Di, P_, Cn, *site_args(p_head, 7))
 
         # loss
         loss = alloc("loss", (1,), F32, zero=True)
@@ -432,12 +456,16 @@ class Engine:
         s.py(dXt[0].zero_)
         s.py(dXf.zero_)
         s.c("mh_head_bwd", C.byref(hp), C.byref(hg), _ptr(dlogits), _ptr(pooled), _ptr(feat), _ptr(fused), _ptr(dfeat),
-            _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale))
+            _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale),
+            *site_args(p_head, 7))
         self._ln_bwd(pl, s, dXf, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", mf, rf, dXi[0], Ti, Di)
 
         # backward temporaries, one set per layer parity
         T_ = [dict(df=alloc(f"t.df{i}", (Tt, Dt)), dh=alloc(f"t.dh{i}", (Tt, It)), da=alloc(f"t.da{i}", (Tt, Dt)),
-                   dqkv=alloc(f"t.dqkv{i}", (Tt, 3 * Dt))) for i in range(2)]
+                   dqkv=alloc(f"t.dqkv{i}", (Tt, 3 * Dt)),
+                   dfm=alloc(f"t.dfm{i}", (Tt, Dt)) if p_h > 0 else None,     # df / da times the dropout mask of the
+                   dam=alloc(f"t.dam{i}", (Tt, Dt)) if p_h > 0 else None)     # Linear output that fed the LayerNorm
+              for i in range(2)]
         I_ = [dict(dh=alloc(f"i.dh{i}", (Ti, Ii)), dxp=alloc(f"i.dxp{i}", (Ti, Di)),
                    dqkv=alloc(f"i.dqkv{i}", (Ti, 3 * Di))) for i in range(2)]
         t_dy, t_dctx = alloc("t.dy", (Tt, Dt)), alloc("t.dctx", (Tt, Dt))
@@ -454,14 +482,16 @@ class Engine:
             a = tl[l] if has_t else None
             b_ = il[l] if has_i else None
             t_df, t_dh, t_da, t_dqkv = (T_[l & 1][k] for k in ("df", "dh", "da", "dqkv"))
+            t_dfm = T_[l & 1]["dfm"] if p_h > 0 else t_df      # gradient w.r.t. the (dropped) FFN output dense
+            t_dam = T_[l & 1]["dam"] if p_h > 0 else t_da      # gradient w.r.t. the (dropped) attention output dense
             i_dh, i_dxp, i_dqkv = (I_[l & 1][k] for k in ("dh", "dxp", "dqkv"))
             if has_t:   # through the output LayerNorm
                 self._ln_bwd(pl, s, dXt[ct], a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", a["m2"],
-                             a["r2"], t_df, Tt, Dt)
+                             a["r2"], t_df, Tt, Dt, dx_drop=t_dfm if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 3))
             # d gelu_in = (d_out @ W2) * gelu'(h)
             pr = []
             if has_t:
-                pr.append(self._dgrad_prob(t_df, self.w(LT + "output.dense.weight"), t_dh, Tt, Dt, It, mul=a["h"]))
+                pr.append(self._dgrad_prob(t_dfm, self.w(LT + "output.dense.weight"), t_dh, Tt, Dt, It, mul=a["h"]))
             if has_i:
                 pr.append(self._dgrad_prob(dXi[ci], self.w(LI + "output.dense.weight"), i_dh, Ti, Di, Ii, mul=b_["h"]))
             self._gemm(pl, s, pr, False, True)
@@ -478,22 +508,23 @@ class Engine:
                              b_["r2"], i_dxp, Ti, Di, dx_add=dXi[ci], lane=2)
             if has_t:
                 self._ln_bwd(pl, s, t_dy, a["a"], LT + "attention.output.LayerNorm.weight",
-                             LT + "attention.output.LayerNorm.bias", a["m1"], a["r1"], t_da, Tt, Dt)
+                             LT + "attention.output.LayerNorm.bias", a["m1"], a["r1"], t_da, Tt, Dt,
+                             dx_drop=t_dam if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 2))
             s.join()
             # through the attention output projection
             pr = []
             if has_t:
-                pr.append(self._dgrad_prob(t_da, self.w(LT + "attention.output.dense.weight"), t_dctx, Tt, Dt, Dt))
+                pr.append(self._dgrad_prob(t_dam, self.w(LT + "attention.output.dense.weight"), t_dctx, Tt, Dt, Dt))
             if has_i:
                 pr.append(self._dgrad_prob(i_dxp, self.w(LI + "attention.output.dense.weight"), i_dctx, Ti, Di, Di))
             self._gemm(pl, s, pr, False, True)
             s.fork()
             if has_i:
                 s.c("mh_attn_bwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(i_dctx), _ptr(b_["lse"]), _ptr(i_delta),
-                    _ptr(i_dqkv), B, Nt, Hi, lane=2)
+                    _ptr(i_dqkv), B, Nt, Hi, None, 0.0, 0, lane=2)
             if has_t:
                 s.c("mh_attn_bwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(t_dctx), _ptr(a["lse"]), _ptr(t_delta),
-                    _ptr(t_dqkv), B, S, Ht)
+                    _ptr(t_dqkv), B, S, Ht, *site_args(p_a, 16 * (l + 1) + 1))
             s.join()
             # through the QKV projection
             pr = []
@@ -511,9 +542,9 @@ class Engine:
             # take 254 us, the two 432-tile launches back to back 215 us.
             if has_t:
                 self._gemm(pl, s, [
-                    self._wgrad_prob(t_df, a["g"], self.g(LT + "output.dense.weight"), self.g(LT + "output.dense.bias"), Tt, Dt, It),
+                    self._wgrad_prob(t_dfm, a["g"], self.g(LT + "output.dense.weight"), self.g(LT + "output.dense.bias"), Tt, Dt, It),
                     self._wgrad_prob(t_dh, a["y"], self.g(LT + "intermediate.dense.weight"), self.g(LT + "intermediate.dense.bias"), Tt, It, Dt),
-                    self._wgrad_prob(t_da, a["ctx"], self.g(LT + "attention.output.dense.weight"), self.g(LT + "attention.output.dense.bias"), Tt, Dt, Dt),
+                    self._wgrad_prob(t_dam, a["ctx"], self.g(LT + "attention.output.dense.weight"), self.g(LT + "attention.output.dense.bias"), Tt, Dt, Dt),
                     self._wgrad_prob(t_dqkv, xt[l], self.g(LT + "attention.self.query.weight", 3), self.g(LT + "attention.self.query.bias", 3), Tt, 3 * Dt, Dt)],
                     True, True, lane=1)
             if has_i:
@@ -533,6 +564,8 @@ class Engine:
         # embeddings
         s = seg("bwd_embed")
         t_dpre = alloc("t.dpre", (Tt, Dt))
+        if p_h > 0:     # gradient w.r.t. the dropped embedding output -> w.r.t. the LayerNorm output
+            s.c("mh_dropout_apply", _ptr(dXt[ct]), Tt * Dt, rng_t.data_ptr(), float(p_h), 1)
         self._ln_bwd(pl, s, dXt[ct], pre0, TXT + "embeddings.LayerNorm.weight", TXT + "embeddings.LayerNorm.bias", m0, r0,
                      t_dpre, Tt, Dt)
         gword = self.g(TXT + "embeddings.word_embeddings.weight")

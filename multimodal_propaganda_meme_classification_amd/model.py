@@ -132,6 +132,8 @@ class MultimodalClassifier(nn.Module):
             _register(self, name, prm)
         self._engine: Optional[Engine] = None
         self._shadow_stale = True
+        self._rng_seed, self._rng_step = 0x5EED1234, 0
+        self._rng_ring = None
         if init:
             self.reset_parameters(seed)
         self._attach_grads()
@@ -217,6 +219,23 @@ class MultimodalClassifier(nn.Module):
     def mark_weights_changed(self):
         self._shadow_stale = True
 
+    def manual_seed(self, seed: int):
+        """Seed of the dropout masks (stateless counter RNG: mask = f(seed, step, site, element))."""
+        self._rng_seed, self._rng_step = int(seed) & 0x7FFFFFFFFFFFFFFF, 0
+
+    def _advance_rng(self, plan: Plan):
+        """New dropout masks for the next step: writes {seed_lo, seed_hi, step, 0} to the plan's device words
+        (pinned ring + async copy, so a captured graph picks the new values up on replay)."""
+        if not getattr(plan, "dropout_on", False):
+            return
+        if self._rng_ring is None:
+            self._rng_ring = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(32)]
+        self._rng_step += 1
+        host = self._rng_ring[self._rng_step % 32]
+        lo, hi = self._rng_seed & 0x7FFFFFFF, (self._rng_seed >> 31) & 0x7FFFFFFF
+        host.copy_(torch.tensor([lo, hi, self._rng_step & 0x7FFFFFFF, 0], dtype=torch.int32))
+        plan.buf["rng"].copy_(host, non_blocking=True)
+
     def _prepare(self, text, image, mask, labels=None) -> Plan:
         eng = self._get_engine()
         if text.dim() != 2 or mask.shape != text.shape:
@@ -225,9 +244,11 @@ class MultimodalClassifier(nn.Module):
         v = self.config.image
         if tuple(image.shape) != (B, v.channels, v.image_size, v.image_size):
             raise ValueError(f"image must be [B,{v.channels},{v.image_size},{v.image_size}], got {tuple(image.shape)}")
-        plan = eng.plan(B, S)
+        plan = eng.plan(B, S, self.training)
         if self._shadow_stale:
             self.refresh_shadow()
+        if self.training:
+            self._advance_rng(plan)
         plan.buf["ids"].copy_(text.to(torch.int64), non_blocking=True)
         plan.buf["mask"].copy_(mask.to(torch.int64), non_blocking=True)
         plan.buf["image"].copy_(image.to(F32), non_blocking=True)
@@ -374,7 +395,7 @@ class GraphedStep:
         self.model, self.opt = model, optimizer
         optimizer._model = model
         eng = model._get_engine()
-        self.plan = eng.plan(batch, seq_len)
+        self.plan = eng.plan(batch, seq_len, True)
         if model._shadow_stale:
             model.refresh_shadow()
         self.use_graph = use_graph
@@ -438,6 +459,7 @@ class GraphedStep:
             opt._bind()
         opt._step += 1
         opt._write_hyper()
+        self.model._advance_rng(self.plan)
         if not self.use_graph:
             self._run_eager()
         else:

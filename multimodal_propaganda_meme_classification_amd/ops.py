@@ -58,16 +58,45 @@ class Gemm:
     """One problem of a grouped launch (see MhGemmProblem in include/memehip.h)."""
 
     __slots__ = ("A", "B", "C", "bias", "residual", "aux", "mul", "rowsum", "M", "N", "K", "lda", "ldb", "ldc",
-                 "flags", "alpha")
+                 "flags", "alpha", "drop")
 
     def __init__(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, residual=None, aux=None, mul=None,
-                 rowsum=None, gelu=False, accum=False, alpha=1.0):
+                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None):
         self.alpha = alpha
+        self.drop = drop            # (rng u32[4] device tensor, p, site id) or None
         self.A, self.B, self.C = A, B, C
         self.bias, self.residual, self.aux, self.mul, self.rowsum = bias, residual, aux, mul, rowsum
         self.M, self.N, self.K, self.lda, self.ldb, self.ldc = M, N, K, lda, ldb, ldc
         self.flags = (MH_GEMM_GELU if gelu else 0) | (MH_GEMM_OUT_F32 if C.dtype == F32 else 0) | \
                      (MH_GEMM_ACCUM if accum else 0)
+
+
+def _rng(t: Optional[torch.Tensor]):
+    """device int32/uint32[4] rng words {seed_lo, seed_hi, step, -} of a dropout site, or None (dropout off)"""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.int32 and t.numel() >= 4):
+        raise TypeError("rng must be a device int32 tensor with 4 words")
+    return t.data_ptr()
+
+
+def _drop(drop):
+    return (None, 0.0, 0) if drop is None else (_rng(drop[0]), float(drop[1]), int(drop[2]))
+
+
+def dropout_mask(n: int, drop, device) -> torch.Tensor:
+    """0/1 mask (uint8) the kernels use for element indices 0..n-1 of dropout site `drop` = (rng, p, site)."""
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    r, p, sid = _drop(drop)
+    check(_lib.load().mh_dropout_mask_u8(_p(out), n, r, p, sid, _stream()), "mh_dropout_mask_u8")
+    return out
+
+
+def dropout_apply(x, drop):
+    _chk(x, BF16, "x")
+    r, p, sid = _drop(drop)
+    check(_L(x).mh_dropout_apply(_p(x), x.numel(), r, p, sid, _stream()), "mh_dropout_apply")
+    return x
 
 
 def _min_elems(rows: int, ld: int, cols: int) -> int:
@@ -100,17 +129,19 @@ def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
         a.A, a.B, a.C = _p(g.A), _p(g.B), _p(g.C)
         a.bias, a.residual, a.aux, a.mul, a.rowsum = _p(g.bias), _p(g.residual), _p(g.aux), _p(g.mul), _p(g.rowsum)
         a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.flags, a.alpha = g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.flags, g.alpha
+        if g.drop is not None:
+            a.drop_rng, a.drop_p, a.drop_stream = _rng(g.drop[0]), float(g.drop[1]), int(g.drop[2])
     check(_L(problems[0].A).mh_gemm_bf16_grouped(arr, n, int(a_kmajor), int(b_kmajor), _stream()), "mh_gemm_bf16_grouped")
 
 
-def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False):
+def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False, drop=None):
     """y[T,N] = epi(x[T,K] @ w[N,K]^T)"""
     T, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((T, N), dtype=x.dtype, device=x.device)
     gemm_grouped([Gemm(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual,
-                       aux=aux, gelu=gelu)], False, False)
+                       aux=aux, gelu=gelu, drop=drop)], False, False)
     return out
 
 
@@ -152,14 +183,15 @@ def layernorm_fwd(x, gamma, beta, eps, y=None, mean=None, rstd=None, y_f32=None)
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, part, dx=None, dx_add=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, part, dx=None, dx_add=None, dx_drop=None, drop=None):
     _chk(dy, BF16, "dy"), _chk(x, BF16, "x"), _chk(gamma, F32, "gamma"), _chk(part, F32, "part")
     rows, D = x.shape
     n_part = part.shape[1]
     assert part.shape == (2, n_part, D) and mean.numel() >= rows and rstd.numel() >= rows
     dx = torch.empty_like(x) if dx is None else _chk(dx, BF16, "dx")
+    r, p, sid = _drop(drop)
     check(_L(x).mh_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx), _p(part),
-                                       n_part, rows, D, _stream()), "mh_layernorm_bwd")
+                                 n_part, rows, D, _p(dx_drop), r, p, sid, _stream()), "mh_layernorm_bwd")
     return dx
 
 
@@ -183,7 +215,7 @@ def colsum_partials(jobs, n_part: int, D: int, scale: float = 1.0):
 # attention
 # ---------------------------------------------------------------------------------------------
 
-def attn_fwd(qkv, key_mask, B, S, H, out=None, lse=None):
+def attn_fwd(qkv, key_mask, B, S, H, out=None, lse=None, drop=None):
     _chk(qkv, BF16, "qkv")
     assert qkv.numel() == B * S * 3 * H * 64
     if key_mask is not None:
@@ -192,19 +224,21 @@ def attn_fwd(qkv, key_mask, B, S, H, out=None, lse=None):
     out = torch.empty((B * S, H * 64), dtype=qkv.dtype, device=qkv.device) if out is None else _chk(out, BF16, "out")
     lse = torch.empty((B, H, S), dtype=F32, device=qkv.device) if lse is None else _chk(lse, F32, "lse")
     assert out.numel() == B * S * H * 64 and lse.numel() == B * H * S
-    check(_L(qkv).mh_attn_fwd(_p(qkv), _p(key_mask), _p(out), _p(lse), B, S, H, _stream()), "mh_attn_fwd")
+    r, p, sid = _drop(drop)
+    check(_L(qkv).mh_attn_fwd(_p(qkv), _p(key_mask), _p(out), _p(lse), B, S, H, r, p, sid, _stream()), "mh_attn_fwd")
     return out, lse
 
 
-def attn_bwd(qkv, key_mask, out, dout, lse, B, S, H, dqkv=None, delta=None):
+def attn_bwd(qkv, key_mask, out, dout, lse, B, S, H, dqkv=None, delta=None, drop=None):
     _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse")
     assert qkv.numel() == B * S * 3 * H * 64 and out.numel() == B * S * H * 64 == dout.numel()
     assert lse.numel() == B * H * S
     dqkv = torch.empty_like(qkv) if dqkv is None else _chk(dqkv, BF16, "dqkv")
     delta = torch.empty((B, H, S), dtype=F32, device=qkv.device) if delta is None else _chk(delta, F32, "delta")
     assert dqkv.numel() == qkv.numel() and delta.numel() == B * H * S
+    r, p, sid = _drop(drop)
     check(_L(qkv).mh_attn_bwd(_p(qkv), _p(key_mask), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), B, S, H,
-                                  _stream()), "mh_attn_bwd")
+                              r, p, sid, _stream()), "mh_attn_bwd")
     return dqkv
 
 
@@ -212,7 +246,7 @@ def attn_bwd(qkv, key_mask, out, dout, lse, B, S, H, dqkv=None, delta=None):
 # embeddings / patches
 # ---------------------------------------------------------------------------------------------
 
-def bert_embed_fwd(ids, word, pos, type0, gamma, beta, eps, pre, y, mean, rstd):
+def bert_embed_fwd(ids, word, pos, type0, gamma, beta, eps, pre, y, mean, rstd, drop=None):
     _chk(ids, I64, "ids"), _chk(word, F32, "word"), _chk(pos, F32, "pos")
     B, S = ids.shape
     V, D = word.shape
@@ -220,7 +254,7 @@ def bert_embed_fwd(ids, word, pos, type0, gamma, beta, eps, pre, y, mean, rstd):
     assert pre.numel() >= B * S * D and y.numel() >= B * S * D and mean.numel() >= B * S and rstd.numel() >= B * S
     check(_L(pre).mh_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta),
                                         _p(_chk(pre, BF16, "pre")), _p(_chk(y, BF16, "y")), _p(mean), _p(rstd), B, S,
-                                        D, V, float(eps), _stream()), "mh_bert_embed_fwd")
+                                        D, V, float(eps), *_drop(drop), _stream()), "mh_bert_embed_fwd")
 
 
 def bert_embed_bwd(ids, d_pre, dword, dpos, dtype0, pad_id: int, scale: float = 1.0):
@@ -272,18 +306,19 @@ def _head_struct(cls, tensors):
     return s
 
 
-def head_fwd(params, text_hidden, image_hidden, pool_index, pooled, feat, fused, logits, B, S, Nt, Dt, Di, P, Cn):
+def head_fwd(params, text_hidden, image_hidden, pool_index, pooled, feat, fused, logits, B, S, Nt, Dt, Di, P, Cn,
+             drop=None):
     hp = _head_struct(MhHeadParams, params)
     _chk(text_hidden, F32, "text_hidden"), _chk(image_hidden, F32, "image_hidden")
     assert text_hidden.numel() >= B * S * Dt and image_hidden.numel() >= B * Nt * Di
     assert pooled.numel() >= B * (Dt + Di) and feat.numel() >= B * 2 * P and fused.numel() >= B * P and logits.numel() >= B * Cn
     assert params[0].numel() == P * Dt and params[2].numel() == P * Di and params[4].numel() == P * 2 * P and params[6].numel() == Cn * P
     check(_lib.load().mh_head_fwd(C.byref(hp), _p(text_hidden), _p(image_hidden), pool_index, _p(pooled), _p(feat),
-                                  _p(fused), _p(logits), B, S, Nt, Dt, Di, P, Cn, _stream()), "mh_head_fwd")
+                                  _p(fused), _p(logits), B, S, Nt, Dt, Di, P, Cn, *_drop(drop), _stream()), "mh_head_fwd")
 
 
 def head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, d_text_hidden, d_image_hidden, pool_index,
-             B, S, Nt, Dt, Di, P, Cn, out_scale: float = 1.0):
+             B, S, Nt, Dt, Di, P, Cn, out_scale: float = 1.0, drop=None):
     hp = _head_struct(MhHeadParams, params)
     hg = _head_struct(MhHeadGrads, grads)
     for a, b in zip(params, grads):
@@ -293,7 +328,7 @@ def head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, d_text_
     assert dfeat.numel() >= B * 2 * P and dfused.numel() >= B * P and dlogits.numel() >= B * Cn
     check(_L(d_text_hidden).mh_head_bwd(C.byref(hp), C.byref(hg), _p(dlogits), _p(pooled), _p(feat), _p(fused), _p(dfeat),
                                         _p(dfused), _p(d_text_hidden), _p(d_image_hidden), pool_index, B, S, Nt, Dt, Di, P,
-                                        Cn, float(out_scale), _stream()), "mh_head_bwd")
+                                        Cn, float(out_scale), *_drop(drop), _stream()), "mh_head_bwd")
 
 
 def ce_fwd_bwd(logits, labels, loss, dlogits, n_correct=None, grad_scale: float = 1.0):

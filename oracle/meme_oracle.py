@@ -222,7 +222,7 @@ def n_params(cfg: OracleConfig) -> int:
 # --------------------------------------------------------------------------
 
 def _mha(x_q: torch.Tensor, wq, bq, wk, bk, wv, bv, heads: int,
-         add_mask: Optional[torch.Tensor]) -> torch.Tensor:
+         add_mask: Optional[torch.Tensor], p_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, S, D = x_q.shape
     dh = D // heads
     q = F.linear(x_q, wq, bq).view(B, S, heads, dh).transpose(1, 2)
@@ -232,13 +232,19 @@ def _mha(x_q: torch.Tensor, wq, bq, wk, bk, wv, bv, heads: int,
     if add_mask is not None:
         scores = scores + add_mask
     p = torch.softmax(scores, dim=-1)
+    if p_mask is not None:            # nn.Dropout on the probabilities, mask given as 0 or 1/(1-p)
+        p = p * p_mask
     ctx = torch.matmul(p, v).transpose(1, 2).reshape(B, S, D)
     return ctx
 
 
 def text_tower(p: Params, ids: torch.Tensor, mask: torch.Tensor, c: TextConfig,
-               pfx: str = "bert.") -> torch.Tensor:
-    """BERT / DistilBERT encoder -> last_hidden_state [B,S,D]."""
+               pfx: str = "bert.", masks: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """BERT / DistilBERT encoder -> last_hidden_state [B,S,D].
+    ``masks`` injects dropout masks (values 0 or 1/(1-p)) at BERT's four dropout sites -- "emb" [B,S,D],
+    "attn{l}" [B,H,S,S], "so{l}" (BertSelfOutput) and "ffn{l}" (BertOutput) [B,S,D] -- so that a
+    training-mode run can be compared element for element; None = p 0 everywhere."""
+    masks = masks or {}
     B, S = ids.shape
     pos = torch.arange(S, device=ids.device)
     # transformers builds word_embeddings with padding_idx=pad_token_id: forward is a plain
@@ -249,6 +255,8 @@ def text_tower(p: Params, ids: torch.Tensor, mask: torch.Tensor, c: TextConfig,
         x = x + p[pfx + "embeddings.token_type_embeddings.weight"][0][None, None]
     x = F.layer_norm(x, (c.hidden,), p[pfx + "embeddings.LayerNorm.weight"],
                      p[pfx + "embeddings.LayerNorm.bias"], c.ln_eps)
+    if "emb" in masks:
+        x = x * masks["emb"]
     # transformers' extended attention mask: (1 - mask) * finfo(dtype).min
     add_mask = (1.0 - mask.to(x.dtype))[:, None, None, :] * torch.finfo(x.dtype).min
     for i in range(c.layers):
@@ -257,12 +265,16 @@ def text_tower(p: Params, ids: torch.Tensor, mask: torch.Tensor, c: TextConfig,
                    p[L + "attention.self.query.weight"], p[L + "attention.self.query.bias"],
                    p[L + "attention.self.key.weight"], p[L + "attention.self.key.bias"],
                    p[L + "attention.self.value.weight"], p[L + "attention.self.value.bias"],
-                   c.heads, add_mask)
+                   c.heads, add_mask, masks.get(f"attn{i}"))
         a = F.linear(ctx, p[L + "attention.output.dense.weight"], p[L + "attention.output.dense.bias"])
+        if f"so{i}" in masks:
+            a = a * masks[f"so{i}"]
         x = F.layer_norm(x + a, (c.hidden,), p[L + "attention.output.LayerNorm.weight"],
                          p[L + "attention.output.LayerNorm.bias"], c.ln_eps)
         h = F.gelu(F.linear(x, p[L + "intermediate.dense.weight"], p[L + "intermediate.dense.bias"]))
         o = F.linear(h, p[L + "output.dense.weight"], p[L + "output.dense.bias"])
+        if f"ffn{i}" in masks:
+            o = o * masks[f"ffn{i}"]
         x = F.layer_norm(x + o, (c.hidden,), p[L + "output.LayerNorm.weight"],
                          p[L + "output.LayerNorm.bias"], c.ln_eps)
     return x
@@ -310,10 +322,13 @@ def pool_text(hidden: torch.Tensor, pool: str) -> torch.Tensor:
 
 
 def forward(p: Params, text: torch.Tensor, image: torch.Tensor, mask: torch.Tensor,
-            cfg: OracleConfig) -> torch.Tensor:
+            cfg: OracleConfig, masks: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """MultimodalClassifier.forward(text, image, mask) -> logits [B,num_classes]
-    (...task2C.txt:172-197; argument order text, image, mask)."""
-    t = pool_text(text_tower(p, text, mask, cfg.text), cfg.pool)
+    (...task2C.txt:172-197; argument order text, image, mask).  ``masks``: see text_tower, plus "head" [B,D]
+    for ``bert_drop`` (...task2C.txt:160,178)."""
+    t = pool_text(text_tower(p, text, mask, cfg.text, masks=masks), cfg.pool)
+    if masks and "head" in masks:
+        t = t * masks["head"]
     t = F.linear(t, p["bert_fc.weight"], p["bert_fc.bias"])
     v = image_tower(p, image, cfg.image)[:, 0]
     v = F.linear(v, p["image_fc.weight"], p["image_fc.bias"])
@@ -327,9 +342,9 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return (lse - logits.gather(1, labels[:, None]).squeeze(1)).mean()
 
 
-def loss_and_grads(p: Params, text, image, mask, labels, cfg: OracleConfig):
+def loss_and_grads(p: Params, text, image, mask, labels, cfg: OracleConfig, masks=None):
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    logits = forward(leaves, text, image, mask, cfg)
+    logits = forward(leaves, text, image, mask, cfg, masks=masks)
     loss = cross_entropy(logits, labels)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}

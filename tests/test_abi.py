@@ -43,8 +43,8 @@ def test_binding_covers_header(lib):
 
 
 def test_struct_layout_matches_header(lib):
-    # 8 pointers + 8 int32 = 96 bytes; a drift here would corrupt every grouped launch
-    assert ctypes.sizeof(lib.MhGemmProblem) == 96
+    # 8 pointers + 7 int32 + float + pointer + float + uint32 = 112 bytes; a drift here would corrupt every grouped launch
+    assert ctypes.sizeof(lib.MhGemmProblem) == 112
     assert ctypes.sizeof(lib.MhColsumJob) == 24
     assert ctypes.sizeof(lib.MhHeadParams) == 64 == ctypes.sizeof(lib.MhHeadGrads)
 
