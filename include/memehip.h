@@ -210,6 +210,12 @@ int mh_head_bwd(const MhHeadParams* p /*host*/, const MhHeadGrads* g /*host*/, c
                 uint32_t drop_stream, mh_stream_t stream);
 int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
                   int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream);
+/* sigmoid focal loss over one logit per sample (torchvision.ops.sigmoid_focal_loss(inputs, targets, alpha, gamma,
+ * reduction="mean") as called at Multimodal_example_task2C.py:167,711): loss, dlogits (stride ld), #(logit>0 == target).
+ * alpha < 0 disables the class weighting, as in torchvision. */
+int mh_focal_fwd_bwd(const float* logits, int ld, const float* targets /*f32 [B] in {0,1}*/, float* loss,
+                     float* dlogits, int32_t* n_correct, int B, float alpha, float gamma, float grad_scale,
+                     mh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam / AdamW, Multimodal_example_task2C.txt:249,217; HF Trainer

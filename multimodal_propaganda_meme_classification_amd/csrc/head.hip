@@ -129,6 +129,48 @@ __global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logi
     }
 }
 
+// sigmoid focal loss (torchvision.ops.sigmoid_focal_loss as called at Multimodal_example_task2C.py:711:
+// alpha = 0.25, gamma = 2, reduction "mean") over one logit per sample; also d loss / d logit and #correct at 0.
+__global__ __launch_bounds__(1024) void focal_kernel(const float* __restrict__ logits, int ld,
+                                                     const float* __restrict__ targets, float* __restrict__ loss,
+                                                     float* __restrict__ dlogits, int32_t* __restrict__ n_correct, int B,
+                                                     float alpha, float gamma, float grad_scale) {
+    __shared__ float red[16];
+    __shared__ int redc[16];
+    const int b = threadIdx.x;
+    float li = 0.f;
+    int ok = 0;
+    if (b < B) {
+        const float x = logits[(size_t)b * ld], t = targets[b];
+        const float p = 1.0f / (1.0f + expf(-x));
+        const float ce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));       // BCE with logits
+        const float pt = p * t + (1.f - p) * (1.f - t);
+        const float om = 1.f - pt;
+        const float mod = powf(om, gamma);
+        const float at = alpha >= 0.f ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
+        li = at * ce * mod;
+        // d/dx: d ce = p - t ; d pt = (2t - 1) p (1 - p) ; d mod = -gamma om^(gamma-1) d pt
+        const float dce = p - t;
+        const float dpt = (2.f * t - 1.f) * p * (1.f - p);
+        const float dmod = om > 0.f ? -gamma * powf(om, gamma - 1.f) * dpt : 0.f;
+        dlogits[(size_t)b * ld] = at * (dce * mod + ce * dmod) * grad_scale / (float)B;
+        ok = ((x > 0.f) == (t > 0.5f));
+    }
+    float s = wave_sum(li);
+    int cs = ok;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o, 64);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; redc[threadIdx.x >> 6] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tt = 0.f;
+        int tc = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { tt += red[i]; tc += redc[i]; }
+        *loss = tt / (float)B;
+        if (n_correct) *n_correct = tc;
+    }
+}
+
 int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N, int K,
                hipStream_t s) {
     hipLaunchKernelGGL(linear_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, ldx, W, b, y, ldy, M, N, K);
@@ -198,5 +240,16 @@ extern "C" int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* 
     const int threads = ((B + 63) / 64) * 64;
     hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, logits, labels, loss, dlogits,
                        n_correct, B, C, grad_scale);
+    return mh_launch_status();
+}
+
+extern "C" int mh_focal_fwd_bwd(const float* logits, int ld, const float* targets, float* loss, float* dlogits,
+                                int32_t* n_correct, int B, float alpha, float gamma, float grad_scale,
+                                mh_stream_t stream) {
+    if (!logits || !targets || !loss || !dlogits) return MH_EINVAL;
+    if (B < 1 || B > 1024 || ld < 1 || gamma < 0.f) return MH_ESHAPE;
+    const int threads = ((B + 63) / 64) * 64;
+    hipLaunchKernelGGL(focal_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, logits, ld, targets, loss, dlogits,
+                       n_correct, B, alpha, gamma, grad_scale);
     return mh_launch_status();
 }

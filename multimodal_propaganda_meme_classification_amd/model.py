@@ -106,6 +106,65 @@ class CrossEntropyLoss(nn.Module):
         return _LossFn.apply(logits, labels, self)
 
 
+class _FocalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, crit):
+        flat = logits.reshape(-1).contiguous()
+        w = crit._workspace(logits.device, flat.numel())
+        ops.focal_fwd_bwd(flat, targets.to(F32).reshape(-1).contiguous(), w["loss"], w["dlogits"], w["ncorrect"], crit.alpha,
+                          crit.gamma)
+        ctx.dl, ctx.shape = w["dlogits"], logits.shape
+        return w["loss"][0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (ctx.dl * gout).view(ctx.shape), None, None
+
+
+class SigmoidFocalLoss(nn.Module):
+    """``criterion = sigmoid_focal_loss`` of Multimodal_example_task2C.py:167 called as
+    ``criterion(output, labels, alpha=0.25, gamma=2.0, reduction='mean')`` (:711), on one logit per sample
+    (a model built with ``num_classes=1``)."""
+
+    def __init__(self, alpha: float = 0.25, gamma: float = 2.0):
+        super().__init__()
+        self.alpha, self.gamma = alpha, gamma
+        self._ws: Dict = {}
+
+    def _workspace(self, device, B):
+        key = (str(device), B)
+        if key not in self._ws:
+            self._ws[key] = dict(loss=torch.zeros(1, device=device), dlogits=torch.zeros(B, device=device),
+                                 ncorrect=torch.zeros(1, dtype=torch.int32, device=device))
+        self._last = self._ws[key]
+        return self._ws[key]
+
+    @property
+    def last_correct(self) -> torch.Tensor:
+        return self._last["ncorrect"]
+
+    def forward(self, logits, targets, alpha=None, gamma=None, reduction: str = "mean"):
+        if reduction != "mean":
+            raise ValueError("SigmoidFocalLoss supports reduction='mean' (the reference's call)")
+        if alpha is not None:
+            self.alpha = alpha
+        if gamma is not None:
+            self.gamma = gamma
+        if not logits.is_cuda:
+            raise _lib.MemehipError("SigmoidFocalLoss: logits must be on the HIP device (no CPU fallback)")
+        return _FocalFn.apply(logits, targets, self)
+
+
+def get_linear_schedule_with_warmup(optimizer, num_warmup_steps: int, num_training_steps: int, last_epoch: int = -1):
+    """transformers.get_linear_schedule_with_warmup (Multimodal_example_task2C.py:172-174): lr multiplier rises
+    linearly 0 -> 1 over the warm-up steps, then decays linearly to 0 at num_training_steps."""
+    def lr_lambda(step: int):
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda, last_epoch)
+
+
 class MultimodalClassifier(nn.Module):
     """Dual-encoder late-fusion classifier (BERT-family text tower + ViT image tower)."""
 
@@ -282,6 +341,14 @@ class MultimodalClassifier(nn.Module):
         self._run_backward(plan, grad_hook)
         return plan.buf["loss"], plan.buf["ncorrect"], plan.buf["logits"]
 
+    def get_params(self, lr: float):
+        """Kevin's parameter groups (Multimodal_example_task2C.py:645-664): fusion / head parameters at ``lr``,
+        text-encoder and image-encoder parameters at ``0.8 * lr``."""
+        head, text, image = [], [], []
+        for name, p in self.named_parameters():
+            (text if name.startswith("bert.") else image if name.startswith("image_model.") else head).append(p)
+        return [{"params": head, "lr": lr}, {"params": text, "lr": lr * 0.8}, {"params": image, "lr": lr * 0.8}]
+
     @property
     def flat_params(self):
         return self._P
@@ -296,17 +363,18 @@ class MultimodalClassifier(nn.Module):
 
 
 class Adam(torch.optim.Optimizer):
-    """torch.optim.Adam / AdamW semantics over the model's flat buffers in ONE fused HIP launch
-    (dense over all parameters, as the reference's optim.Adam is).  ``max_grad_norm`` adds the
-    HF-Trainer clip (DistilBERT_example_task2A.ipynb:3280) fused into the same launch."""
+    """torch.optim.Adam / AdamW semantics over the model's flat buffers in fused HIP launches (dense over all
+    parameters, as the reference's optim.Adam is): one launch per contiguous run of a parameter group, so
+    ``Adam(model.parameters())`` is ONE launch and ``Adam(model.get_params(lr))`` (Kevin's 0.8x encoder learning
+    rate, Multimodal_example_task2C.py:645-664,168) is three.  ``max_grad_norm`` adds the clip of
+    DistilBERT_example_task2A.ipynb:3280 / ...task2C.py:713-715 fused into the same launches; learning-rate
+    schedulers (torch.optim.lr_scheduler.*) work unchanged because the rate is re-read every step."""
 
-    def __init__(self, params: Iterable[nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, decoupled_weight_decay: bool = False, max_grad_norm: Optional[float] = None,
                  model: Optional[MultimodalClassifier] = None):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        if len(self.param_groups) != 1:
-            raise ValueError("the fused Adam takes one parameter group (all of model.parameters())")
         self.decoupled = decoupled_weight_decay
         self.max_grad_norm = max_grad_norm
         self._model = model
@@ -317,7 +385,7 @@ class Adam(torch.optim.Optimizer):
     def _bind(self):
         if self._flat is not None:
             return
-        ps = self.param_groups[0]["params"]
+        ps = [p for g in self.param_groups for p in g["params"]]
         base = min(ps, key=lambda p: p.data_ptr())
         storage = base.untyped_storage()
         n = storage.nbytes() // 4
@@ -335,10 +403,24 @@ class Adam(torch.optim.Optimizer):
         if self._model is None:
             self._model = _REGISTRY.get(storage.data_ptr())
         dev = base.device
+        # contiguous runs (in elements, 4-aligned) of every parameter group
+        runs = []
+        for gi, g in enumerate(self.param_groups):
+            spans = sorted((p.storage_offset(), p.storage_offset() + (p.numel() + 3) // 4 * 4) for p in g["params"])
+            cur = None
+            for a, b in spans:
+                if cur is not None and a <= cur[1]:
+                    cur[1] = max(cur[1], b)
+                else:
+                    if cur is not None:
+                        runs.append((gi, cur[0], cur[1]))
+                    cur = [a, b]
+            if cur is not None:
+                runs.append((gi, cur[0], cur[1]))
         self._flat = dict(P=P, G=G, M=torch.zeros(n, device=dev), V=torch.zeros(n, device=dev),
-                          hyper=torch.zeros(8, device=dev), ws=torch.zeros(1024, device=dev),
-                          nrm=torch.zeros(1, device=dev),
-                          ring=[torch.zeros(8, dtype=F32).pin_memory() for _ in range(32)])
+                          hyper=[torch.zeros(8, device=dev) for _ in self.param_groups], ws=torch.zeros(1024, device=dev),
+                          nrm=torch.zeros(1, device=dev), runs=runs,
+                          ring=[torch.zeros((len(self.param_groups), 8), dtype=F32).pin_memory() for _ in range(32)])
 
     def zero_grad(self, set_to_none: bool = False):
         # every gradient is overwritten by the next backward (the embedding table re-zeroes the rows
@@ -346,13 +428,13 @@ class Adam(torch.optim.Optimizer):
         return None
 
     def _write_hyper(self):
-        g = self.param_groups[0]
-        b1, b2 = g["betas"]
         t = self._step
         host = self._flat["ring"][t % 32]
-        host.copy_(torch.tensor([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1.0 / (1.0 - b1 ** t),
-                                 1.0 / math.sqrt(1.0 - b2 ** t), self.grad_scale], dtype=F32))
-        self._flat["hyper"].copy_(host, non_blocking=True)
+        for gi, g in enumerate(self.param_groups):
+            b1, b2 = g["betas"]
+            host[gi].copy_(torch.tensor([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1.0 / (1.0 - b1 ** t),
+                                         1.0 / math.sqrt(1.0 - b2 ** t), self.grad_scale], dtype=F32))
+            self._flat["hyper"][gi].copy_(host[gi], non_blocking=True)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -362,23 +444,26 @@ class Adam(torch.optim.Optimizer):
         self.launch()
 
     def launch(self):
-        """Enqueue grad-norm (if clipping) + the fused update; reads hyper-parameters from device memory."""
+        """Enqueue grad-norm (if clipping) + the fused update(s); hyper-parameters are read from device memory."""
         f = self._flat
         model = self._model
-        shadow, n_shadow = (model.flat_shadow, model.layout.n_shadow) if model is not None else (None, 0)
+        n_shadow = model.layout.n_shadow if model is not None else 0
         nrm = None
         if self.max_grad_norm is not None:
             ops.sumsq(f["G"], f["ws"], f["nrm"])
             nrm = f["nrm"]
-        ops.adam_step(f["P"], f["M"], f["V"], f["G"], shadow, n_shadow, f["hyper"], self.decoupled, nrm,
-                      float(self.max_grad_norm or 0.0))
+        for gi, a, b in f["runs"]:
+            sh_n = max(0, min(b, n_shadow) - a)            # part of this run that has a 16-bit shadow
+            shadow = model.flat_shadow[a:a + sh_n] if (model is not None and sh_n > 0) else None
+            ops.adam_step(f["P"][a:b], f["M"][a:b], f["V"][a:b], f["G"][a:b], shadow, sh_n, f["hyper"][gi], self.decoupled,
+                          nrm, float(self.max_grad_norm or 0.0))
         if model is not None:
             model._shadow_stale = False
 
     def state_dict(self):
         self._bind()
         return dict(step=self._step, exp_avg=self._flat["M"], exp_avg_sq=self._flat["V"],
-                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+                    param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
 
 
 class GraphedStep:

@@ -341,6 +341,15 @@ def ce_fwd_bwd(logits, labels, loss, dlogits, n_correct=None, grad_scale: float 
                                     float(grad_scale), _stream()), "mh_ce_fwd_bwd")
 
 
+def focal_fwd_bwd(logits, targets, loss, dlogits, n_correct=None, alpha=0.25, gamma=2.0, grad_scale=1.0):
+    """logits f32 [B] or [B,1]; targets f32 [B]"""
+    _chk(logits, F32, "logits"), _chk(targets, F32, "targets"), _chk(loss, F32, "loss"), _chk(dlogits, F32, "dlogits")
+    B = targets.numel()
+    assert logits.numel() == B == dlogits.numel()
+    check(_lib.load().mh_focal_fwd_bwd(_p(logits), 1, _p(targets), _p(loss), _p(dlogits), _p(n_correct), B, float(alpha),
+                                       float(gamma), float(grad_scale), _stream()), "mh_focal_fwd_bwd")
+
+
 def sumsq(g, workspace, out):
     _chk(g, F32, "g"), _chk(workspace, F32, "workspace"), _chk(out, F32, "out")
     assert workspace.numel() >= 1024

@@ -342,6 +342,18 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return (lse - logits.gather(1, labels[:, None]).squeeze(1)).mean()
 
 
+def sigmoid_focal_loss(inputs: torch.Tensor, targets: torch.Tensor, alpha: float = 0.25, gamma: float = 2.0) -> torch.Tensor:
+    """torchvision.ops.sigmoid_focal_loss(..., reduction="mean") restated (torchvision 0.17.2 is not installed;
+    call site Multimodal_example_task2C.py:167,711):  ce * (1 - p_t)^gamma * alpha_t."""
+    p = torch.sigmoid(inputs)
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.mean()
+
+
 def loss_and_grads(p: Params, text, image, mask, labels, cfg: OracleConfig, masks=None):
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
     logits = forward(leaves, text, image, mask, cfg, masks=masks)
@@ -368,7 +380,7 @@ def global_grad_norm(grads: Params) -> torch.Tensor:
 
 def adam_step(p: Params, grads: Params, st: AdamState, lr: float = 2e-5,
               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-              decoupled: bool = False, max_grad_norm: Optional[float] = None) -> Params:
+              decoupled: bool = False, max_grad_norm: Optional[float] = None, lr_of=None) -> Params:
     """torch.optim.Adam / AdamW single-tensor algorithm, dense over every parameter
     (...task2C.txt:249,217).  ``max_grad_norm`` applies clip_grad_norm_ first
     (coef = max_norm / (norm + 1e-6), clamped to 1)."""
@@ -398,7 +410,8 @@ def adam_step(p: Params, grads: Params, st: AdamState, lr: float = 2e-5,
         v = v * b2 + (1.0 - b2) * g * g
         st.m[k], st.v[k] = m, v
         denom = v.sqrt() / math.sqrt(bc2) + eps
-        out[k] = w - (lr / bc1) * (m / denom)
+        lr_k = lr_of(k) if lr_of is not None else lr      # parameter groups (Multimodal_example_task2C.py:645-664)
+        out[k] = w - (lr_k / bc1) * (m / denom)
     return out
 
 

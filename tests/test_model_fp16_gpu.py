@@ -98,3 +98,25 @@ def test_config3_within_1e3(pkg, golden_dir):
     name, worst = _grad_rel(model, ref_grads)
     print("config3 fp16 worst relative grad error", name, worst)
     assert worst <= 2e-2, (name, worst)
+
+
+@pytest.mark.slow
+def test_config5_widths_two_layers(pkg):
+    """BASELINE configs[4] widths (BERT-large / ViT-L: D = 1024, 16 heads, I = 4096, S = 256) at depth 2 and
+    patch 16 @ 224 (197 tokens): exercises the D = 1024 LayerNorm / GEMM / attention paths end to end."""
+    from oracle import meme_oracle as O
+    cfg = O.OracleConfig(
+        text=O.TextConfig(vocab_size=30522, hidden=1024, layers=2, heads=16, intermediate=4096, max_position=512),
+        image=O.ImageConfig(image_size=224, patch=16, hidden=1024, layers=2, heads=16, intermediate=4096),
+        proj=512, num_classes=2, pool="cls")
+    model, params = _make(pkg, O, cfg, 8)
+    text, image, mask, labels = O.synthetic_batch(cfg, 2, 256, seed=42)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(params, text, image, mask, labels, cfg)
+    model.train()
+    loss, _, logits = model.forward_backward(text.cuda(), image.cuda(), mask.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    err = float((logits.float().cpu() - ref_logits).abs().max())
+    print("config-5 widths: logits err", err)
+    assert err <= LOGIT_TOL and abs(float(loss) - float(ref_loss)) <= LOGIT_TOL
+    name, worst = _grad_rel(model, ref_grads)
+    assert worst <= 1e-2, (name, worst)
