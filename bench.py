@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--tiny", action="store_true", help="tiny model (debug only; not a bench line)")
+    ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight-gradient GEMMs on the main stream")
+    ap.add_argument("--no-overlap-opt", action="store_true", help="A/B: whole Adam update after the backward")
     ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
                     help="16-bit storage / MFMA operand type of the towers (same kernels, same MFMA peak)")
     return ap.parse_args()
@@ -117,7 +119,8 @@ def main():
         model.mark_weights_changed()
         reducer = ddp.GradientReducer(model.flat_grads)
     opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)
-    step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer)
+    step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer,
+                           overlap_wgrad=not args.no_overlap_wgrad, overlap_optimizer=not args.no_overlap_opt)
     if reducer is not None:
         ddp.check_bucket_cover(step.plan.bucket_after, model.layout.n_total)
     batch = synthetic_batch(cfg, args.batch, args.seq, seed=1234 + rank, device=device)

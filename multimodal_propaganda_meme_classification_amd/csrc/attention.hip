@@ -16,6 +16,7 @@
 //   row image: 16-B chunk c of row r at chunk c ^ (r & 7)            (ds_read_b128 fragments)
 //   tr  image: 32-B unit u of row r at unit u ^ (((r >> 1) & 1) << 1) (ds_read_b64_tr_b16)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -520,6 +521,16 @@ template <typename K>
 void set_lds(K kern, int bytes) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
+// sequences up to this length keep a head's whole K/V (or Q/dO) resident in LDS in the BACKWARD kernels
+// (96-128 KB per workgroup at S = 197); env MEMEHIP_ATTN_BWD_RESIDENT_MAX overrides for A/B runs
+int bwd_resident_max() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MEMEHIP_ATTN_BWD_RESIDENT_MAX");
+        v = e ? atoi(e) : 128;   // measured: at S = 197 the 24-KB streaming kernels co-schedule better with the side-stream GEMMs
+    }
+    return v;
+}
 int split_for(int S) {
     const int tiles32 = (S + 31) / 32;
     return tiles32 > 4 ? 2 : 1;
@@ -573,12 +584,13 @@ extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void*
     const h16* dO = (const h16*)dout;
     h16* dq = (h16*)dqkv;
     const bool dr = rng && drop_p > 0.f;
-    if (S <= 128) {
+    const int rmax = bwd_resident_max();
+    if (S <= 128 && S <= rmax) {
         constexpr int L1 = 3 * 2 * IMG + 2 * TILE * 4 + 64, L2 = 4 * 2 * IMG + 2 * 2 * TILE * 4;
         const dim3 grid(split_for(S), B * H);
         ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, L1, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
         ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 2, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
-    } else if (S <= 256) {
+    } else if (S <= 256 && S <= rmax) {
         constexpr int L1 = 3 * 4 * IMG + 4 * TILE * 4 + 64, L2 = 4 * 4 * IMG + 2 * 4 * TILE * 4;
         const dim3 grid(split_for(S), B * H);
         ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, L1, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);

@@ -72,7 +72,8 @@ class Segment:
         completion event is stored under this segment's name for a later wait().  lane 2 = the image tower's
         small kernels (LayerNorm, attention), which run on `aux` beside the text tower's between fork()
         and join()."""
-        mp, sp = main.cuda_stream, side.cuda_stream
+        mp = main.cuda_stream
+        sp = side.cuda_stream if side is not None else mp      # side=None: lane-1 work stays on the main stream
         ap = aux.cuda_stream if aux is not None else mp
         forked1 = False
         fork_ev = None
@@ -93,7 +94,7 @@ class Segment:
                     main.wait_event(d)
                     aux_dirty = False
                 continue
-            if lane == 1:
+            if lane == 1 and side is not None:
                 if not forked1:
                     e = torch.cuda.Event()
                     e.record(main)

@@ -443,16 +443,36 @@ class Adam(torch.optim.Optimizer):
         self._write_hyper()
         self.launch()
 
-    def launch(self):
-        """Enqueue grad-norm (if clipping) + the fused update(s); hyper-parameters are read from device memory."""
+    def launch(self, only: Optional[tuple] = None, skip: Optional[list] = None):
+        """Enqueue grad-norm (if clipping) + the fused update(s); hyper-parameters are read from device memory.
+        ``only=(a, b)`` updates just that slice of the flat buffer (optimizer-in-backward: a layer's matrices are
+        updated on the side stream as soon as their gradients are complete); ``skip`` = slices already done."""
         f = self._flat
         model = self._model
         n_shadow = model.layout.n_shadow if model is not None else 0
         nrm = None
         if self.max_grad_norm is not None:
+            assert only is None, "clipping needs the global gradient norm before any update"
             ops.sumsq(f["G"], f["ws"], f["nrm"])
             nrm = f["nrm"]
+        runs = []
         for gi, a, b in f["runs"]:
+            pieces = [(a, b)]
+            if only is not None:
+                pieces = [(max(a, only[0]), min(b, only[1]))]
+            for sa, sb in (skip or []):
+                nxt = []
+                for x, y in pieces:
+                    if sb <= x or sa >= y:
+                        nxt.append((x, y))
+                    else:
+                        if x < sa:
+                            nxt.append((x, sa))
+                        if sb < y:
+                            nxt.append((sb, y))
+                pieces = nxt
+            runs += [(gi, x, y) for x, y in pieces if y > x]
+        for gi, a, b in runs:
             sh_n = max(0, min(b, n_shadow) - a)            # part of this run that has a 16-bit shadow
             shadow = model.flat_shadow[a:a + sh_n] if (model is not None and sh_n > 0) else None
             ops.adam_step(f["P"][a:b], f["M"][a:b], f["V"][a:b], f["G"][a:b], shadow, sh_n, f["hyper"][gi], self.decoupled,
@@ -476,7 +496,7 @@ class GraphedStep:
     """
 
     def __init__(self, model: MultimodalClassifier, optimizer: Adam, batch: int, seq_len: int, use_graph: bool = True,
-                 reducer=None, overlap_wgrad: bool = True, overlap_towers: bool = False):
+                 reducer=None, overlap_wgrad: bool = True, overlap_towers: bool = False, overlap_optimizer: bool = True):
         self.model, self.opt = model, optimizer
         optimizer._model = model
         eng = model._get_engine()
@@ -489,11 +509,16 @@ class GraphedStep:
             optimizer.grad_scale = reducer.grad_scale
         self.graphs = None
         # single GPU: weight-gradient GEMMs run on a second stream beside the LayerNorm / attention / dgrad chain
-        self.side = torch.cuda.Stream() if (overlap_wgrad and reducer is None) else None
+        self.side = torch.cuda.Stream() if ((overlap_wgrad or overlap_optimizer) and reducer is None) else None
+        self.wgrad_side = bool(overlap_wgrad)
         # optional third stream for the image tower's LayerNorm / attention beside the text tower's.  Measured on
         # MI355X (hipGraph, config 3): 13.68 ms/step with it vs 13.32 without -- the ~70 extra cross-stream
         # edges cost more than the overlap of these short kernels returns -- so it is off by default.
         self.aux = torch.cuda.Stream() if (self.side is not None and overlap_towers) else None
+        # optimizer-in-backward: the (HBM-bound) Adam update of a layer pair's matrices follows their weight-gradient
+        # GEMMs on the side stream, under the (MFMA-bound) backward chain of the layers below; only the tail
+        # (embeddings, biases, head) is updated after the backward.  Needs no global clip and a single GPU.
+        self.opt_in_bwd = bool(overlap_optimizer and self.side is not None and optimizer.max_grad_norm is None)
 
     # ---- pieces ------------------------------------------------------------------------------------------
     def _pieces(self):
@@ -502,7 +527,7 @@ class GraphedStep:
             if self.side is None:
                 p.fwd.run(stream)
             else:
-                p.fwd.run2(torch.cuda.current_stream(), self.side, {}, self.aux)
+                p.fwd.run2(torch.cuda.current_stream(), None, {}, self.aux)
             p.loss.run(stream)
         pieces = [("fwd", fwd, None)]
         if self.side is None:
@@ -512,12 +537,26 @@ class GraphedStep:
             def bwd(stream):
                 main = torch.cuda.current_stream()
                 events = {}
+                done = []
                 for seg in p.bwd:
-                    seg.run2(main, self.side, events, self.aux)
-                for ev in events.values():      # join before the optimizer reads the gradients
+                    seg.run2(main, self.side if self.wgrad_side else None, events, self.aux)
+                    rng = p.bucket_after.get(seg.name)
+                    if self.opt_in_bwd and seg.name.startswith("bwd_layer_") and rng is not None:
+                        if seg.name not in events:      # weight gradients ran on the main stream: fork behind them
+                            e = torch.cuda.Event()
+                            e.record(main)
+                            self.side.wait_event(e)
+                        with torch.cuda.stream(self.side):
+                            self.opt.launch(only=rng)
+                        ev = torch.cuda.Event()
+                        ev.record(self.side)
+                        events[seg.name] = ev
+                        done.append(rng)
+                for ev in events.values():      # join before the optimizer reads the remaining gradients
                     main.wait_event(ev)
+                self._opt_done = done
             pieces.append(("bwd", bwd, None))
-        pieces.append(("opt", lambda stream: self.opt.launch(), None))
+        pieces.append(("opt", lambda stream: self.opt.launch(skip=getattr(self, "_opt_done", None)), None))
         return pieces
 
     def _run_eager(self):

@@ -142,6 +142,28 @@ def test_fused_and_graphed_step_equal_autograd_path(pkg):
         assert float(loss2) == float(loss3)
 
 
+def test_optimizer_in_backward_equals_plain_step(pkg):
+    """Without clipping the graphed step updates each layer pair's matrices on the side stream right after their
+    weight-gradient GEMMs; results must be bit-identical to backward-then-Adam."""
+    O = _oracle()
+    cfg = O.tiny_config("last")
+    text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=6)
+    dev = [t.cuda() for t in (text, image, mask, labels)]
+    m1, _ = _make(pkg, O, cfg, 10)
+    m2, _ = _make(pkg, O, cfg, 10)
+    o1, o2 = pkg.Adam(m1.parameters(), lr=1e-3), pkg.Adam(m2.parameters(), lr=1e-3)
+    g2 = pkg.GraphedStep(m2, o2, 4, 16)
+    assert g2.opt_in_bwd
+    for _ in range(4):
+        m1.forward_backward(*dev)
+        o1.step()
+        g2.load_batch(*dev)
+        g2.step()
+        torch.cuda.synchronize()
+        assert torch.equal(m1.flat_params, m2.flat_params)
+        assert torch.equal(m1.flat_shadow, m2.flat_shadow)
+
+
 def test_ragged_and_edge_inputs(pkg):
     """All-ones mask, a single-valid-token row, batch 1, and a sequence length that is not a
     multiple of any tile: logits within 1e-3 of the oracle."""
