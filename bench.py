@@ -122,7 +122,8 @@ def main():
     step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer,
                            overlap_wgrad=not args.no_overlap_wgrad, overlap_optimizer=not args.no_overlap_opt)
     if reducer is not None:
-        ddp.check_bucket_cover(step.plan.bucket_after, model.layout.n_total)
+        end = ddp.check_bucket_cover(step.plan.bucket_after, model.layout.n_total)
+        assert end == model.layout.spec["bert.embeddings.token_type_embeddings.weight"].offset, end
     batch = synthetic_batch(cfg, args.batch, args.seq, seed=1234 + rank, device=device)
     step.load_batch(*batch)
 

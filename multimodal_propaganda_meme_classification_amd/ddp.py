@@ -39,6 +39,15 @@ class GradientReducer:
     def hook(self, seg_name: str, rng: Optional[Tuple[int, int]]):
         self.reduce_range(rng)
 
+    def gather(self, pairs):
+        """all-gather (local, gathered) tensor pairs in rank order (the embedding-gradient exchange)."""
+        if not dist.is_initialized():
+            for local, full in pairs:
+                full.copy_(local.reshape(full.shape))
+            return
+        for local, full in pairs:
+            dist.all_gather_into_tensor(full.view(-1), local.contiguous().view(-1), group=self.group)
+
     def wait(self):
         for w in self.pending:
             w.wait()
@@ -54,13 +63,15 @@ def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group=None):
         dist.broadcast(flat_params, src=src, group=group)
 
 
-def check_bucket_cover(plan_bucket_after: dict, n_total: int):
-    """The per-segment gradient ranges must tile [0, n_total) exactly once."""
+def check_bucket_cover(plan_bucket_after: dict, n_total: int) -> int:
+    """The per-segment gradient ranges must tile [0, end) exactly once; returns `end` (= n_total, or the start of
+    the embedding tables when their gradients are exchanged as gathered rows instead)."""
     rngs = sorted(plan_bucket_after.values())
     pos = 0
     for a, b in rngs:
         if a != pos:
             raise AssertionError(f"gradient buckets leave a gap/overlap at {pos} (next starts at {a})")
         pos = b
-    if pos != n_total:
-        raise AssertionError(f"gradient buckets end at {pos}, expected {n_total}")
+    if pos > n_total:
+        raise AssertionError(f"gradient buckets end at {pos} > {n_total}")
+    return pos

@@ -250,16 +250,18 @@ class Engine:
         plan._ln_jobs.setdefault(D, []).append((part, self.g(gname), self.g(bname)))
 
     # ---- plan ----------------------------------------------------------------------------------------------
-    def plan(self, B: int, S: int, training: bool = True) -> Plan:
-        """Plans differ between train and eval only when some dropout probability is non-zero."""
+    def plan(self, B: int, S: int, training: bool = True, gather_world: int = 0) -> Plan:
+        """Plans differ between train and eval only when some dropout probability is non-zero.
+        gather_world = W > 0 (data parallel): the embedding-table gradients are built from the all-gathered token ids
+        and embedding-gradient rows of all W ranks (6 MB per rank) instead of all-reducing the dense 196-MB table."""
         cfg = self.cfg
         has_drop = (cfg.text.hidden_dropout > 0 or cfg.text.attention_dropout > 0 or cfg.head_dropout > 0)
-        key = (B, S, bool(training and has_drop))
+        key = (B, S, bool(training and has_drop), int(gather_world))
         if key not in self.plans:
-            self.plans[key] = self._build(B, S, key[2])
+            self.plans[key] = self._build(B, S, key[2], key[3])
         return self.plans[key]
 
-    def _build(self, B: int, S: int, dropout_on: bool = False) -> Plan:
+    def _build(self, B: int, S: int, dropout_on: bool = False, gather_world: int = 0) -> Plan:
         cfg, t, v = self.cfg, self.cfg.text, self.cfg.image
         if S > t.max_position:
             raise ValueError(f"sequence length {S} > max_position {t.max_position}")
@@ -570,12 +572,18 @@ class Engine:
         self._ln_bwd(pl, s, dXt[ct], pre0, TXT + "embeddings.LayerNorm.weight", TXT + "embeddings.LayerNorm.bias", m0, r0,
                      t_dpre, Tt, Dt)
         gword = self.g(TXT + "embeddings.word_embeddings.weight")
-        # dense-Adam semantics: the table gradient is dense; only rows touched last step need re-zeroing
-        s.c("mh_zero_rows_f32", _ptr(prev_ids), _ptr(gword), Tt, Dt, t.vocab_size)
         gtype0 = self.g(TXT + "embeddings.token_type_embeddings.weight")[:Dt] if t.type_vocab > 0 else None
-        s.c("mh_bert_embed_bwd", _ptr(ids), _ptr(t_dpre), _ptr(gword), _ptr(self.g(TXT + "embeddings.position_embeddings.weight")),
-            _ptr(gtype0), B, S, Dt, t.vocab_size, int(t.pad_token_id), 1.0 / self.gscale)
-        s.py(lambda: prev_ids.copy_(ids))
+        gpos = self.g(TXT + "embeddings.position_embeddings.weight")
+
+        def table_grads(sg, ids_, dpre_, prev_, nb):
+            # dense-Adam semantics: the table gradient is dense; only rows touched last step need re-zeroing
+            sg.c("mh_zero_rows_f32", _ptr(prev_), _ptr(gword), nb * S, Dt, t.vocab_size)
+            sg.c("mh_bert_embed_bwd", _ptr(ids_), _ptr(dpre_), _ptr(gword), _ptr(gpos), _ptr(gtype0), nb, S, Dt, t.vocab_size,
+                 int(t.pad_token_id), 1.0 / self.gscale)
+            sg.py(lambda: prev_.copy_(ids_))
+
+        if gather_world <= 0:
+            table_grads(s, ids, t_dpre, prev_ids, B)
         i_dproj = alloc("i.dproj", (B * Np, Di))
         s.c("mh_vit_assemble_bwd", _ptr(dXi[ci]), _ptr(i_dproj), _ptr(self.g(IMG + "embeddings.cls_token")),
             _ptr(self.g(IMG + "embeddings.position_embeddings")), B, Np, Di, 1.0 / self.gscale)
@@ -591,6 +599,23 @@ class Engine:
                     arr[j].part, arr[j].out0, arr[j].out1 = _ptr(part), _ptr(o0), _ptr(o1)
                 pl.keep.append(arr)
                 s.c("mh_colsum_partials_f32", arr, len(chunk), LN_PARTS, D, 1.0 / self.gscale)
-        pl.bucket_after[s.name] = (self.layout.layer_ranges[-1][2], self.layout.n_total)
+        tail0 = self.layout.layer_ranges[-1][2]
+        if gather_world <= 0:
+            pl.bucket_after[s.name] = (tail0, self.layout.n_total)
+        else:
+            # data parallel: word / position / token-type tables sit at the end of the flat buffer; their gradients
+            # come from the gathered rows of every rank (already the global sum), so the all-reduce stops before them
+            first_tbl = TXT + ("embeddings.token_type_embeddings.weight" if t.type_vocab > 0
+                               else "embeddings.position_embeddings.weight")
+            tbl0 = self.layout.spec[first_tbl].offset
+            assert self.layout.spec[TXT + "embeddings.word_embeddings.weight"].offset + t.vocab_size * Dt + 3 >= self.layout.n_total - 3
+            pl.bucket_after[s.name] = (tail0, tbl0)
+            W = gather_world
+            ids_all = alloc("ids_all", (W * B, S), I64, zero=True)
+            prev_all = alloc("prev_ids_all", (W * B, S), I64, zero=True)
+            dpre_all = alloc("t.dpre_all", (W * Tt, Dt))
+            pl.gather = [(ids, ids_all), (t_dpre, dpre_all)]      # (local, gathered) pairs, exchanged between segments
+            s2 = seg("bwd_embed_tables")
+            table_grads(s2, ids_all, dpre_all, prev_all, W * B)
         pl.n_launches = sum(1 for sg in [pl.fwd, pl.loss] + pl.bwd for c in sg.calls if c[0] is not None)
         return pl

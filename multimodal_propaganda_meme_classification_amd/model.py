@@ -500,7 +500,7 @@ class GraphedStep:
         self.model, self.opt = model, optimizer
         optimizer._model = model
         eng = model._get_engine()
-        self.plan = eng.plan(batch, seq_len, True)
+        self.plan = eng.plan(batch, seq_len, True, gather_world=(reducer.world if reducer is not None else 0))
         if model._shadow_stale:
             model.refresh_shadow()
         self.use_graph = use_graph
@@ -532,6 +532,8 @@ class GraphedStep:
         pieces = [("fwd", fwd, None)]
         if self.side is None:
             for seg in p.bwd:
+                if seg.name == "bwd_embed_tables":      # needs every rank's token ids + embedding-gradient rows first
+                    pieces.append(("gather", None, None))
                 pieces.append((seg.name, seg.run, p.bucket_after.get(seg.name)))
         else:
             def bwd(stream):
@@ -562,6 +564,9 @@ class GraphedStep:
     def _run_eager(self):
         stream = torch.cuda.current_stream().cuda_stream
         for name, fn, rng in self._pieces():
+            if name == "gather":
+                self.reducer.gather(self.plan.gather)
+                continue
             if name == "opt" and self.reducer is not None:
                 self.reducer.wait()
             fn(stream)
@@ -590,6 +595,9 @@ class GraphedStep:
             if self.graphs is None:
                 self._capture()
             for g, name, rng in self.graphs:
+                if name == "gather":
+                    self.reducer.gather(self.plan.gather)
+                    continue
                 if name == "opt" and self.reducer is not None:
                     self.reducer.wait()
                 g.replay()
@@ -607,7 +615,10 @@ class GraphedStep:
         with torch.cuda.stream(s):
             stream = s.cuda_stream
             for name, fn, rng in self._pieces():
-                fn(stream)
+                if name == "gather":
+                    self.reducer.gather(self.plan.gather)
+                else:
+                    fn(stream)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         f["P"].copy_(snap[0]); f["M"].copy_(snap[1]); f["V"].copy_(snap[2])
@@ -626,6 +637,9 @@ class GraphedStep:
         else:
             pool = None
             for name, fn, rng in pieces:
+                if name == "gather":
+                    graphs.append((None, "gather", None))
+                    continue
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
                     fn(torch.cuda.current_stream().cuda_stream)

@@ -82,7 +82,7 @@ def test_layout_config3():
     # gradient buckets (one per layer pair, then everything else) tile the flat buffer exactly once
     buckets = {f"bwd_layer_{l}": (a, b) for l, a, b in lay.layer_ranges}
     buckets["bwd_embed"] = (lay.layer_ranges[-1][2], lay.n_total)
-    ddp.check_bucket_cover(buckets, lay.n_total)
+    assert ddp.check_bucket_cover(buckets, lay.n_total) == lay.n_total
     with pytest.raises(AssertionError):
         ddp.check_bucket_cover({"a": (0, 10), "b": (12, 20)}, 20)
     names = lay.state_dict_order()

@@ -256,6 +256,25 @@ def test_bert_embed_fwd_bwd(ops):
     assert float(dword.abs().max()) == 0.0
 
 
+def test_embed_bwd_over_gathered_ranks_equals_sum_of_ranks(ops):
+    """Data parallel: the table gradients are computed once from the all-gathered (ids, gradient rows) of every rank;
+    that must equal the sum of the per-rank gradients (what an all-reduce of the dense tables would give)."""
+    W, B, S, D, V, P = 3, 2, 16, 128, 40, 32
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, V, (W * B, S), generator=g).to(dev())          # many duplicates across "ranks", some PAD
+    d_pre = rnd(W * B * S, D, seed=2)
+    tot_w, tot_p, tot_t = (torch.zeros((V, D), device=dev()), torch.zeros((P, D), device=dev()), torch.zeros(D, device=dev()))
+    for r in range(W):
+        dw, dp, dt = torch.zeros((V, D), device=dev()), torch.zeros((P, D), device=dev()), torch.zeros(D, device=dev())
+        ops.bert_embed_bwd(ids[r * B:(r + 1) * B].contiguous(), d_pre[r * B * S:(r + 1) * B * S].contiguous(), dw, dp, dt, 0)
+        tot_w += dw; tot_p += dp; tot_t += dt
+    aw, ap, at = torch.zeros((V, D), device=dev()), torch.zeros((P, D), device=dev()), torch.zeros(D, device=dev())
+    ops.bert_embed_bwd(ids, d_pre, aw, ap, at, 0)
+    close(aw, tot_w, 1e-5, 1e-5, "gathered dword")
+    close(ap, tot_p, 1e-5, 1e-5, "gathered dpos")
+    close(at, tot_t, 1e-5, 1e-4, "gathered dtype0")
+
+
 def test_patchify_bit_exact_and_assemble(ops, golden_dir):
     z = np.load(os.path.join(golden_dir, "index_fixtures.npz"))
     img = torch.from_numpy(z["counting_image"]).to(dev())
