@@ -173,9 +173,10 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
-            key = f"gemm_kernel<{dom[5]}, {dom[7]}, 1>"
-            if key in tj and not args.tiny and args.batch == 32:
-                traffic = tj[key]["hbm_bytes_per_launch"]
+            pref = f"gemm_kernel<{dom[5]}, {dom[7]},"
+            hit = [v for k, v in tj.items() if k.startswith(pref)]
+            if hit and not args.tiny and args.batch == 32:
+                traffic = max(hit, key=lambda v: v["launches_sampled"])["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         flop_per_meme = FLOP_PER_MEME if not args.tiny else plan.gemm_flops / args.batch

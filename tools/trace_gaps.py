@@ -3,8 +3,8 @@ import csv, glob, sys, collections, re
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))]
 rows.sort()
-# steps are delimited by adam_kernel
-ends = [e for s, e, n in rows if 'adam_kernel' in n]
+# steps are delimited by the loss kernel (one per step)
+ends = [e for s, e, n in rows if 'ce_kernel' in n]
 steps = []
 for a, b in zip(ends[:-1], ends[1:]):
     steps.append([(s, e, n) for s, e, n in rows if s >= a and e <= b])
