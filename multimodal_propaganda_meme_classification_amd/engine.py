@@ -249,6 +249,22 @@ class Engine:
               lane=lane)
         plan._ln_jobs.setdefault(D, []).append((part, self.g(gname), self.g(bname)))
 
+    def before_backward(self, plan: Plan):
+        """Each plan re-zeroes the word-embedding gradient rows IT touched last time (the table gradient is dense,
+        only touched rows are ever non-zero).  When the previous backward ran under a different plan (another
+        batch size / sequence length), clear that plan's rows first so no stale row survives the switch."""
+        last = getattr(self, "_last_bwd_plan", None)
+        if last is not None and last is not plan:
+            gword = self.g("bert.embeddings.word_embeddings.weight")
+            for key in ("prev_ids_all", "prev_ids"):
+                prev = last.buf.get(key)
+                if prev is not None:
+                    st = self.lib.mh_zero_rows_f32(prev.data_ptr(), gword.data_ptr(), prev.numel(), self.cfg.text.hidden,
+                                                   self.cfg.text.vocab_size, torch.cuda.current_stream().cuda_stream)
+                    _lib.check(st, "mh_zero_rows_f32")
+                    prev.zero_()
+        self._last_bwd_plan = plan
+
     # ---- plan ----------------------------------------------------------------------------------------------
     def plan(self, B: int, S: int, training: bool = True, gather_world: int = 0) -> Plan:
         """Plans differ between train and eval only when some dropout probability is non-zero.

@@ -316,6 +316,7 @@ class MultimodalClassifier(nn.Module):
         return plan
 
     def _run_backward(self, plan: Plan, hook=None):
+        self._get_engine().before_backward(plan)
         stream = torch.cuda.current_stream().cuda_stream
         for seg in plan.bwd:
             seg.run(stream)
@@ -589,6 +590,7 @@ class GraphedStep:
         opt._step += 1
         opt._write_hyper()
         self.model._advance_rng(self.plan)
+        self.model._get_engine().before_backward(self.plan)
         if not self.use_graph:
             self._run_eager()
         else:

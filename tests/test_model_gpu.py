@@ -164,6 +164,28 @@ def test_optimizer_in_backward_equals_plain_step(pkg):
         assert torch.equal(m1.flat_shadow, m2.flat_shadow)
 
 
+def test_switching_batch_shapes_leaves_no_stale_embedding_rows(pkg):
+    """The dense word-embedding gradient is re-zeroed only on touched rows; alternating plans (batch sizes)
+    must not leave rows of the previous batch behind."""
+    O = _oracle()
+    cfg = O.tiny_config("cls")
+    model, params = _make(pkg, O, cfg, 3)
+    model.train()
+    a = O.synthetic_batch(cfg, 6, 16, seed=1)
+    b = O.synthetic_batch(cfg, 2, 9, seed=2)
+    for _ in range(2):
+        for batch in (a, b):
+            text, image, mask, labels = batch
+            model.forward_backward(text.cuda(), image.cuda(), mask.cuda(), labels.cuda())
+            torch.cuda.synchronize()
+            gw = dict(model.named_parameters())["bert.embeddings.word_embeddings.weight"].grad
+            touched = torch.zeros(cfg.text.vocab_size, dtype=torch.bool)
+            touched[text.unique()] = True
+            touched[cfg.text.pad_token_id] = False
+            assert float(gw[~touched.cuda()].abs().max()) == 0.0
+            assert float(gw[touched.cuda()].abs().sum()) > 0.0
+
+
 def test_ragged_and_edge_inputs(pkg):
     """All-ones mask, a single-valid-token row, batch 1, and a sequence length that is not a
     multiple of any tile: logits within 1e-3 of the oracle."""

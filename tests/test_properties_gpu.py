@@ -1,0 +1,102 @@
+"""Size-independent properties of the hot path at BASELINE's full size (config 3, batch 32, S = 128), where the
+CPU oracle would take minutes per check:
+  * batch independence: a meme's logits do not depend on its batch-mates (no BatchNorm on this path);
+  * data-parallel additivity: the gradient of a batch is the sum of the gradients of its shards
+    (what the RCCL all-reduce relies on), with 1/world folded into the mean loss;
+  * the analytic gradient matches a central finite difference of the loss along a random direction;
+  * an Adam step with zero gradient and zero state is the identity; run-to-run determinism (no atomics).
+GPU box only."""
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import multimodal_propaganda_meme_classification_amd as pkg
+    cfg = pkg.ModelConfig()
+    cfg.compute_dtype = "fp16"
+    model = pkg.MultimodalClassifier.from_config(cfg, device="cuda", seed=123)
+    g = torch.Generator().manual_seed(5)
+    B, S = 32, 128
+    image = torch.randn((B, 3, 224, 224), generator=g).cuda()
+    lens = torch.randint(8, S + 1, (B,), generator=g)
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    text = (torch.randint(5, 64000, (B, S), generator=g) * mask)
+    text[:, 0] = 2
+    labels = (torch.rand(B, generator=g) < 0.28).long()
+    return pkg, model, text.cuda(), image, mask.cuda(), labels.cuda()
+
+
+def test_batch_independence_full_size(env):
+    pkg, model, text, image, mask, labels = env
+    model.eval()
+    with torch.no_grad():
+        full = model(text, image, mask).clone()
+        part = model(text[8:12].contiguous(), image[8:12].contiguous(), mask[8:12].contiguous()).clone()
+    assert full.shape == (32, 2) and torch.isfinite(full).all()
+    assert float((full[8:12] - part).abs().max()) <= 2e-4, float((full[8:12] - part).abs().max())
+
+
+def test_gradient_is_additive_over_shards(env):
+    pkg, model, text, image, mask, labels = env
+    model.train()
+    model.forward_backward(text, image, mask, labels)
+    g_full = model.flat_grads.clone()
+    model.forward_backward(text, image, mask, labels)
+    assert torch.equal(g_full, model.flat_grads), "backward is not run-to-run deterministic"
+    acc = torch.zeros_like(g_full)
+    for r in range(2):                       # two "ranks" of 16 memes each
+        sl = slice(16 * r, 16 * (r + 1))
+        model.forward_backward(text[sl].contiguous(), image[sl].contiguous(), mask[sl].contiguous(), labels[sl].contiguous())
+        acc += model.flat_grads
+    acc *= 0.5                               # mean over the global batch = sum of shard means / world
+    num = float((acc - g_full).norm()) / float(g_full.norm())
+    assert num <= 2e-3, num
+
+
+def test_directional_finite_difference_full_size(env):
+    pkg, model, text, image, mask, labels = env
+    model.train()
+    loss0, _, _ = model.forward_backward(text, image, mask, labels)
+    g = model.flat_grads.clone()
+    # perturb the fp32 head + the last encoder layers' matrices along the (normalised) gradient direction
+    lay = model.layout
+    a, b = lay.layer_ranges[0][1], lay.layer_ranges[0][2]            # last layer pair's matrices
+    h0 = lay.spec["bert_fc.weight"].offset
+    h1 = lay.spec["output_fc.bias"].offset + 4
+    d = torch.zeros_like(g)
+    d[a:b] = g[a:b]
+    d[h0:h1] = g[h0:h1]
+    d /= d.norm()
+    expect = float((g * d).sum())
+    eps = 2e-2
+    p0 = model.flat_params.clone()
+    vals = []
+    for sgn in (+1, -1):
+        with torch.no_grad():
+            model.flat_params.copy_(p0 + sgn * eps * d)
+        model.mark_weights_changed()
+        model.eval()
+        with torch.no_grad():
+            z = model(text, image, mask)
+        vals.append(float(torch.nn.functional.cross_entropy(z, labels)))
+    with torch.no_grad():
+        model.flat_params.copy_(p0)
+    model.mark_weights_changed()
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - expect) <= 0.03 * abs(expect) + 1e-4, (fd, expect)
+
+
+def test_adam_identity_on_zero_gradient(env):
+    pkg, model, text, image, mask, labels = env
+    opt = pkg.Adam(model.parameters(), lr=1e-3, model=model)
+    p0 = model.flat_params.clone()
+    model.flat_grads.zero_()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(p0, model.flat_params)
+    assert torch.equal(model.flat_shadow, model.flat_params[:model.layout.n_shadow].to(model.flat_shadow.dtype))
