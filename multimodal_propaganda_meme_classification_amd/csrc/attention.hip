@@ -241,36 +241,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
     }
 }
 
-// delta[b][h][s] = sum_d dout * out
-__global__ __launch_bounds__(256) void attn_delta_kernel(const h16* __restrict__ out,
-                                                         const h16* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int S, int H) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;  // (b, s, h)
-    if (idx >= B * S * H) return;
-    const int hh = idx % H, bs = idx / H, s = bs % S, b = bs / S;
-    const h16* o = out + (size_t)idx * HD;
-    const h16* d = dout + (size_t)idx * HD;
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        Pack8 x, y;
-        x.v = *(const i32x4*)(o + c * 8);
-        y.v = *(const i32x4*)(d + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += mh_bf2f(x.e[e]) * mh_bf2f(y.e[e]);
-    }
-    delta[((size_t)b * H + hh) * S + s] = acc;
-}
-
 // ----------------------------------------------------------------------------------------------
 // backward, dQ:  one wave = 32 queries at a time, sweep key tiles (resident K/V when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
 template <int NW, int NT_RES, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restrict__ qkv,
                                                               const int64_t* __restrict__ key_mask,
+                                                              const h16* __restrict__ out,
                                                               const h16* __restrict__ dout,
                                                               const float* __restrict__ lse,
-                                                              const float* __restrict__ delta,
+                                                              float* __restrict__ delta,
                                                               h16* __restrict__ dqkv, int B, int S, int H,
                                                               const uint32_t* __restrict__ rng, float drop_p,
                                                               uint32_t drop_stream) {
@@ -322,10 +302,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
         h16x8 qf[4], dof[4];
         load_rows_frag(qb, pitch, wq0, S, lane, qf);
         load_rows_frag(dob, (size_t)H * HD, wq0, S, lane, dof);
-        float lse2 = 0.f, dl = 0.f;
+        // delta = rowsum(dO o O), computed here (each lane holds half of its query's 64 dims) and published for the
+        // dK/dV kernel that follows on the same stream
+        float dl = 0.f;
+        {
+            h16x8 of[4];
+            load_rows_frag(out + (size_t)b * S * H * HD + hh * HD, (size_t)H * HD, wq0, S, lane, of);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)dof[s4][j] * (float)of[s4][j];
+            dl += __shfl_xor(dl, 32, 64);
+        }
+        float lse2 = 0.f;
         if (q < S) {
             lse2 = lse[((size_t)b * H + hh) * S + q] * LOG2E;
-            dl = delta[((size_t)b * H + hh) * S + q];
+            if (h == 0) delta[((size_t)b * H + hh) * S + q] = dl;
         }
         f32x16 dq[2];
 #pragma unroll
@@ -577,10 +569,8 @@ extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void*
     if (!qkv || !out || !dout || !lse || !delta || !dqkv) return MH_EINVAL;
     if (B < 1 || S < 1 || H < 1 || drop_p < 0.f || drop_p >= 1.f) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int n = B * S * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const h16*)out,
-                       (const h16*)dout, delta, B, S, H);
     const h16* q = (const h16*)qkv;
+    const h16* O = (const h16*)out;
     const h16* dO = (const h16*)dout;
     h16* dq = (h16*)dqkv;
     const bool dr = rng && drop_p > 0.f;
@@ -588,17 +578,17 @@ extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void*
     if (S <= 128 && S <= rmax) {
         constexpr int L1 = 3 * 2 * IMG + 2 * TILE * 4 + 64, L2 = 4 * 2 * IMG + 2 * 2 * TILE * 4;
         const dim3 grid(split_for(S), B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, L1, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
         ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 2, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
     } else if (S <= 256 && S <= rmax) {
         constexpr int L1 = 3 * 4 * IMG + 4 * TILE * 4 + 64, L2 = 4 * 4 * IMG + 2 * 4 * TILE * 4;
         const dim3 grid(split_for(S), B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, L1, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
         ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 4, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
     } else {
         constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
         const dim3 grid((S + 127) / 128, B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 0, grid, L1, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 0, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
         ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
     }
     return mh_launch_status();
