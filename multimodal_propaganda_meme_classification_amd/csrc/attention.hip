@@ -523,6 +523,22 @@ int bwd_resident_max() {
     }
     return v;
 }
+bool seven_waves() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MEMEHIP_ATTN_SEVEN_WAVES");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+bool fwd_seven_waves() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MEMEHIP_ATTN_FWD_SEVEN_WAVES");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
 int split_for(int S) {
     const int tiles32 = (S + 31) / 32;
     return tiles32 > 4 ? 2 : 1;
@@ -553,6 +569,9 @@ extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, 
     if (S <= 128) {
         constexpr int L = 2 * 2 * IMG + 2 * TILE * 4 + 64;
         ATTN_LAUNCH(attn_fwd_kernel, 4, 2, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
+    } else if (S <= 224 && fwd_seven_waves()) {
+        constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
+        ATTN_LAUNCH(attn_fwd_kernel, 7, 4, dim3(1, B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
     } else if (S <= 256) {
         constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
         ATTN_LAUNCH(attn_fwd_kernel, 4, 4, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
@@ -585,6 +604,12 @@ extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void*
         const dim3 grid(split_for(S), B * H);
         ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
         ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 4, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+    } else if (S > 128 && S <= 224 && seven_waves()) {
+        // ViT-B/16 (197 tokens = 7 tiles of 32): one 7-wave workgroup per head, every wave busy, K/V (Q/dO) streamed once
+        constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
+        const dim3 grid(1, B * H);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 7, 0, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 7, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
     } else {
         constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
         const dim3 grid((S + 127) / 128, B * H);
