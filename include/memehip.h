@@ -109,6 +109,20 @@ int mh_layernorm_bwd(const void* dy /*bf16*/, const void* x /*bf16*/, const floa
                      void* dx /*bf16*/, float* part /*[2][n_part][D]*/, int n_part, int rows, int D,
                      void* dx_drop /*bf16 or NULL: dx * dropout-mask/(1-p) of the Linear output that fed this LN*/,
                      const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream);
+/* Grouped forms: several LayerNorms of the same width D in ONE launch (the two towers' LayerNorms
+ * sit at the same point of the lockstep layer schedule; each is too small to fill 256 CUs alone). */
+#define MH_LN_MAX_JOBS 4
+typedef struct MhLnFwdJob {
+    const void* x; const float* gamma; const float* beta; void* y; float* y_f32; float* mean; float* rstd;
+    int32_t rows; float eps;
+} MhLnFwdJob;
+typedef struct MhLnBwdJob {
+    const void* dy; const void* x; const float* gamma; const float* mean; const float* rstd;
+    const void* dx_add; void* dx; float* part; void* dx_drop; const uint32_t* rng;
+    int32_t n_part; int32_t rows; float drop_p; uint32_t drop_stream;
+} MhLnBwdJob;
+int mh_layernorm_fwd_grouped(const MhLnFwdJob* jobs, int n_jobs, int D, mh_stream_t stream);
+int mh_layernorm_bwd_grouped(const MhLnBwdJob* jobs, int n_jobs, int D, mh_stream_t stream);
 /* batched finish of the partial column sums: for every job, out0[d] = sum_i part[0][i][d] and
  * out1[d] = sum_i part[1][i][d] (fixed order => bitwise reproducible); NULL outputs are skipped. */
 #define MH_COLSUM_MAX_JOBS 64

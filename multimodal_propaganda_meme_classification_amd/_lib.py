@@ -19,6 +19,7 @@ MH_GEMM_GELU = 1
 MH_GEMM_OUT_F32 = 2
 MH_GEMM_ACCUM = 4
 MH_COLSUM_MAX_JOBS = 64
+MH_LN_MAX_JOBS = 4
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -36,6 +37,16 @@ class MhColsumJob(C.Structure):
     _fields_ = [("part", c_void_p), ("out0", c_void_p), ("out1", c_void_p)]
 
 
+class MhLnFwdJob(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("x", "gamma", "beta", "y", "y_f32", "mean", "rstd")] + \
+               [("rows", C.c_int32), ("eps", C.c_float)]
+
+
+class MhLnBwdJob(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("dy", "x", "gamma", "mean", "rstd", "dx_add", "dx", "part", "dx_drop", "rng")] + \
+               [("n_part", C.c_int32), ("rows", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32)]
+
+
 class MhHeadParams(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("Wt", "bt", "Wi", "bi", "Wf", "bf_", "Wo", "bo")]
 
@@ -50,6 +61,8 @@ _PROTOS = {
     "mh_gemm_set_variant": [c_int],
     "mh_layernorm_fwd": [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p],
     "mh_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_layernorm_fwd_grouped": [C.POINTER(MhLnFwdJob), c_int, c_int, c_void_p],
+    "mh_layernorm_bwd_grouped": [C.POINTER(MhLnBwdJob), c_int, c_int, c_void_p],
     "mh_colsum_partials_f32": [C.POINTER(MhColsumJob), c_int, c_int, c_int, c_float, c_void_p],
     "mh_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_attn_bwd": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],

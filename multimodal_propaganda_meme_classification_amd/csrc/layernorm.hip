@@ -49,13 +49,29 @@ MH_DEV void store_row(h16* __restrict__ p, int D, int lane, const float (&v)[NCH
     }
 }
 
+struct LnFwdGroup {
+    int n;
+    int start[MH_LN_MAX_JOBS + 1];      // first workgroup of each job
+    MhLnFwdJob job[MH_LN_MAX_JOBS];
+};
+
+// grouped launch: workgroups [start[j], start[j+1]) normalise job j's rows, 4 rows (waves) per workgroup
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const h16* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, h16* __restrict__ y,
-                                                     float* __restrict__ y32, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int rows, int D, float eps) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp, int D) {
+    int j = 0;
+    while (j + 1 < grp.n && (int)blockIdx.x >= grp.start[j + 1]) ++j;
+    const MhLnFwdJob& jb = grp.job[j];
+    const h16* __restrict__ x = (const h16*)jb.x;
+    const float* __restrict__ gamma = jb.gamma;
+    const float* __restrict__ beta = jb.beta;
+    h16* __restrict__ y = (h16*)jb.y;
+    float* __restrict__ y32 = jb.y_f32;
+    float* __restrict__ mean = jb.mean;
+    float* __restrict__ rstd = jb.rstd;
+    const int rows = jb.rows;
+    const float eps = jb.eps;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = ((int)blockIdx.x - grp.start[j]) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float v[NCH][8], g[NCH][8], b[NCH][8];
     load_row<NCH>(x + (size_t)row * D, D, lane, v);
@@ -99,16 +115,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const h16* __restrict__ x, 
     }
 }
 
+struct LnBwdGroup {
+    int n;
+    int start[MH_LN_MAX_JOBS + 1];      // first workgroup of each job (job j owns n_part_j workgroups)
+    MhLnBwdJob job[MH_LN_MAX_JOBS];
+};
+
 template <int NCH, bool DROP>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const h16* __restrict__ dy, const h16* __restrict__ x,
-                                                     const float* __restrict__ gamma,
-                                                     const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd,
-                                                     const h16* __restrict__ dx_add, h16* __restrict__ dx,
-                                                     float* __restrict__ part, int n_part, int rows, int D,
-                                                     h16* __restrict__ dx_drop, const uint32_t* __restrict__ rng,
-                                                     float drop_p, uint32_t drop_stream) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp, int D) {
     __shared__ float red[4][64 * 8];
+    int j = 0;
+    while (j + 1 < grp.n && (int)blockIdx.x >= grp.start[j + 1]) ++j;
+    const MhLnBwdJob& jb = grp.job[j];
+    const h16* __restrict__ dy = (const h16*)jb.dy;
+    const h16* __restrict__ x = (const h16*)jb.x;
+    const float* __restrict__ gamma = jb.gamma;
+    const float* __restrict__ mean = jb.mean;
+    const float* __restrict__ rstd = jb.rstd;
+    const h16* __restrict__ dx_add = (const h16*)jb.dx_add;
+    h16* __restrict__ dx = (h16*)jb.dx;
+    float* __restrict__ part = jb.part;
+    h16* __restrict__ dx_drop = (h16*)jb.dx_drop;
+    const int n_part = jb.n_part, rows = jb.rows;
+    const int blk = (int)blockIdx.x - grp.start[j];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float g[NCH][8], dg[NCH][8], db[NCH][8];
     load_row_f32<NCH>(gamma, D, lane, g);
@@ -117,8 +146,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16* __restrict__ dy,
 #pragma unroll
         for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
     const float invD = 1.0f / (float)D;
-    const DropCtx drop = mh_drop_ctx(DROP ? rng : nullptr, drop_p, drop_stream);
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const bool dropj = DROP && dx_drop != nullptr;      // per job: only some jobs of a group carry a dropout site
+    const DropCtx drop = mh_drop_ctx(dropj ? jb.rng : nullptr, jb.drop_p, jb.drop_stream);
+    for (int row = blk * 4 + wave; row < rows; row += n_part * 4) {
         float xv[NCH][8], dv[NCH][8];
         load_row<NCH>(x + (size_t)row * D, D, lane, xv);
         load_row<NCH>(dy + (size_t)row * D, D, lane, dv);
@@ -155,7 +185,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16* __restrict__ dy,
                 for (int e = 0; e < 8; ++e) dv[i][e] = rs * (dv[i][e] * g[i][e] - c1 - xv[i][e] * c2);
         }
         store_row<NCH>(dx + (size_t)row * D, D, lane, dv);
-        if (DROP) {    // gradient w.r.t. the dropped Linear output that fed this LayerNorm: dx * mask / (1 - p)
+        if (DROP && dropj) {    // gradient w.r.t. the dropped Linear output that fed this LayerNorm: dx * mask / (1 - p)
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c = (lane + 64 * i) * 8;
@@ -167,8 +197,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const h16* __restrict__ dy,
     }
     // cross-wave reduce of the column partials, one chunk slot at a time (8 KB of LDS: a workgroup must fit
     // beside two 64-KB GEMM workgroups when the weight-gradient GEMMs run on the side stream)
-    float* pg = part + (size_t)blockIdx.x * D;
-    float* pb = part + (size_t)n_part * D + (size_t)blockIdx.x * D;
+    float* pg = part + (size_t)blk * D;
+    float* pb = part + (size_t)n_part * D + (size_t)blk * D;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -225,13 +255,57 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs j
         else hipLaunchKernelGGL((NAME<8>), __VA_ARGS__);                \
     } while (0)
 
+extern "C" int mh_layernorm_fwd_grouped(const MhLnFwdJob* jobs, int n_jobs, int D, mh_stream_t stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > MH_LN_MAX_JOBS) return MH_EINVAL;
+    if (D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
+    LnFwdGroup g;
+    g.n = n_jobs;
+    int blocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const MhLnFwdJob& jb = jobs[i];
+        if (!jb.x || !jb.gamma || !jb.beta || !jb.y) return MH_EINVAL;
+        if (jb.rows < 1) return MH_ESHAPE;
+        g.job[i] = jb;
+        g.start[i] = blocks;
+        blocks += (jb.rows + 3) / 4;
+    }
+    for (int i = n_jobs; i <= MH_LN_MAX_JOBS; ++i) g.start[i] = blocks;
+    hipStream_t s = (hipStream_t)stream;
+    LN_DISPATCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, s, g, D);
+    return mh_launch_status();
+}
+
 extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* y_f32,
                                 float* mean, float* rstd, int rows, int D, float eps, mh_stream_t stream) {
-    if (!x || !gamma || !beta || !y) return MH_EINVAL;
-    if (rows < 1 || D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
+    MhLnFwdJob jb = {x, gamma, beta, y, y_f32, mean, rstd, rows, eps};
+    return mh_layernorm_fwd_grouped(&jb, 1, D, stream);
+}
+
+extern "C" int mh_layernorm_bwd_grouped(const MhLnBwdJob* jobs, int n_jobs, int D, mh_stream_t stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > MH_LN_MAX_JOBS) return MH_EINVAL;
+    if (D < 8 || (D % 8) || D > 2048) return MH_ESHAPE;   // backward: D <= 2048
+    LnBwdGroup g;
+    g.n = n_jobs;
+    int blocks = 0;
+    bool dr = false;
+    for (int i = 0; i < n_jobs; ++i) {
+        const MhLnBwdJob& jb = jobs[i];
+        if (!jb.dy || !jb.x || !jb.gamma || !jb.mean || !jb.rstd || !jb.dx || !jb.part) return MH_EINVAL;
+        if (jb.rows < 1 || jb.n_part < 1) return MH_ESHAPE;
+        if (jb.dx_drop && !(jb.rng && jb.drop_p > 0.f)) return MH_EINVAL;
+        dr = dr || jb.dx_drop != nullptr;
+        g.job[i] = jb;
+        g.start[i] = blocks;
+        blocks += jb.n_part;
+    }
+    for (int i = n_jobs; i <= MH_LN_MAX_JOBS; ++i) g.start[i] = blocks;
     hipStream_t s = (hipStream_t)stream;
-    LN_DISPATCH(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const h16*)x, gamma, beta, (h16*)y, y_f32,
-                mean, rstd, rows, D, eps);
+    const int nch = (D / 8 + 63) / 64;
+#define LN_BWD_ARGS dim3(blocks), dim3(256), 0, s, g, D
+    if (nch <= 1) { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<1, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), LN_BWD_ARGS); }
+    else if (nch <= 2) { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<2, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<2, false>), LN_BWD_ARGS); }
+    else { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<4, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<4, false>), LN_BWD_ARGS); }
+#undef LN_BWD_ARGS
     return mh_launch_status();
 }
 
@@ -239,21 +313,8 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
                                 const float* rstd, const void* dx_add, void* dx, float* part, int n_part, int rows,
                                 int D, void* dx_drop, const uint32_t* rng, float drop_p, uint32_t drop_stream,
                                 mh_stream_t stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || !part) return MH_EINVAL;
-    if (rows < 1 || n_part < 1 || D < 8 || (D % 8) || D > 2048) return MH_ESHAPE;   // backward: D <= 2048
-    hipStream_t s = (hipStream_t)stream;
-    {
-        const int nch = (D / 8 + 63) / 64;
-#define LN_BWD_ARGS dim3(n_part), dim3(256), 0, s, (const h16*)dy, (const h16*)x, gamma, mean, rstd, \
-                    (const h16*)dx_add, (h16*)dx, part, n_part, rows, D, (h16*)dx_drop, rng, drop_p, drop_stream
-        const bool dr = dx_drop && rng && drop_p > 0.f;
-        if (dx_drop && !dr) return MH_EINVAL;
-        if (nch <= 1) { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<1, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), LN_BWD_ARGS); }
-        else if (nch <= 2) { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<2, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<2, false>), LN_BWD_ARGS); }
-        else { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<4, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<4, false>), LN_BWD_ARGS); }
-#undef LN_BWD_ARGS
-    }
-    return mh_launch_status();
+    MhLnBwdJob jb = {dy, x, gamma, mean, rstd, dx_add, dx, part, dx_drop, rng, n_part, rows, drop_p, drop_stream};
+    return mh_layernorm_bwd_grouped(&jb, 1, D, stream);
 }
 
 extern "C" int mh_colsum_partials_f32(const MhColsumJob* jobs, int n_jobs, int n_part, int D, float scale,

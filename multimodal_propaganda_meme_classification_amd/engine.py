@@ -22,7 +22,8 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhColsumJob, MhGemmProblem, MhHeadGrads, MhHeadParams
+from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhColsumJob, MhGemmProblem, MhHeadGrads, MhHeadParams,
+                   MhLnBwdJob, MhLnFwdJob)
 from .config import Layout, ModelConfig
 
 BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
@@ -235,19 +236,58 @@ class Engine:
         return dict(A=dy, B=x, C=dw, M=N_out, N=K_in, K=T, lda=N_out, ldb=K_in, ldc=K_in, rowsum=db,
                     alpha=1.0 / self.gscale)
 
-    def _ln_fwd(self, seg, x, gname, bname, y, mean, rstd, rows, D, eps, y32=None, lane=0):
-        seg.c("mh_layernorm_fwd", _ptr(x), _ptr(self.p(gname)), _ptr(self.p(bname)), _ptr(y), _ptr(y32), _ptr(mean),
-              _ptr(rstd), rows, D, float(eps), lane=lane)
+    @staticmethod
+    def _ln_groups(by_d):
+        import os
+        if os.environ.get("MEMEHIP_LN_GROUP", "1") == "0":      # A/B switch: one launch per LayerNorm
+            return [(D, [j]) for D, js in by_d.items() for j in js]
+        return list(by_d.items())
 
-    def _ln_bwd(self, plan, seg, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None, lane=0, dx_drop=None,
-                drop=None):
+    def _ln_fwd_job(self, x, gname, bname, y, mean, rstd, rows, D, eps, y32=None):
+        return dict(x=x, gamma=self.p(gname), beta=self.p(bname), y=y, y32=y32, mean=mean, rstd=rstd, rows=rows, D=D,
+                    eps=float(eps))
+
+    def _ln_fwd(self, plan: Plan, seg: Segment, jobs: List[Optional[dict]]):
+        """LayerNorms that sit at the same point of the lockstep schedule go out as ONE grouped launch per width."""
+        by_d: Dict[int, List[dict]] = {}
+        for j in jobs:
+            if j is not None:
+                by_d.setdefault(j["D"], []).append(j)
+        for D, js in self._ln_groups(by_d):
+            assert len(js) <= _lib.MH_LN_MAX_JOBS
+            arr = (MhLnFwdJob * len(js))()
+            for e, j in zip(arr, js):
+                assert j["x"].numel() >= j["rows"] * D and j["y"].numel() >= j["rows"] * D
+                e.x, e.gamma, e.beta, e.y, e.y_f32 = _ptr(j["x"]), _ptr(j["gamma"]), _ptr(j["beta"]), _ptr(j["y"]), _ptr(j["y32"])
+                e.mean, e.rstd, e.rows, e.eps = _ptr(j["mean"]), _ptr(j["rstd"]), j["rows"], j["eps"]
+            plan.keep.append(arr)
+            seg.c("mh_layernorm_fwd_grouped", arr, len(js), D)
+
+    def _ln_bwd_job(self, plan, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None, dx_drop=None, drop=None):
         part = torch.empty((2, LN_PARTS, D), dtype=F32, device=self.dev)
         plan.buf[f"lnpart.{gname}"] = part
-        rng, p_, sid = drop if (drop is not None and dx_drop is not None) else (None, 0.0, 0)
-        seg.c("mh_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(self.p(gname)), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
-              _ptr(part), LN_PARTS, rows, D, _ptr(dx_drop) if rng is not None else None, rng, float(p_), int(sid),
-              lane=lane)
         plan._ln_jobs.setdefault(D, []).append((part, self.g(gname), self.g(bname)))
+        rng, p_, sid = drop if (drop is not None and dx_drop is not None) else (None, 0.0, 0)
+        return dict(dy=dy, x=x, gamma=self.p(gname), mean=mean, rstd=rstd, dx_add=dx_add, dx=dx, part=part,
+                    dx_drop=dx_drop if rng is not None else None, rng=rng, p=float(p_), sid=int(sid), rows=rows, D=D)
+
+    def _ln_bwd(self, plan: Plan, seg: Segment, jobs: List[Optional[dict]]):
+        by_d: Dict[int, List[dict]] = {}
+        for j in jobs:
+            if j is not None:
+                by_d.setdefault(j["D"], []).append(j)
+        for D, js in self._ln_groups(by_d):
+            assert len(js) <= _lib.MH_LN_MAX_JOBS
+            arr = (MhLnBwdJob * len(js))()
+            for e, j in zip(arr, js):
+                n = j["rows"] * D
+                assert j["dy"].numel() >= n and j["x"].numel() >= n and j["dx"].numel() >= n
+                assert j["dx_add"] is None or j["dx_add"].numel() >= n
+                e.dy, e.x, e.gamma, e.mean, e.rstd = _ptr(j["dy"]), _ptr(j["x"]), _ptr(j["gamma"]), _ptr(j["mean"]), _ptr(j["rstd"])
+                e.dx_add, e.dx, e.part, e.dx_drop, e.rng = _ptr(j["dx_add"]), _ptr(j["dx"]), _ptr(j["part"]), _ptr(j["dx_drop"]), j["rng"]
+                e.n_part, e.rows, e.drop_p, e.drop_stream = LN_PARTS, j["rows"], j["p"], j["sid"]
+            plan.keep.append(arr)
+            seg.c("mh_layernorm_bwd_grouped", arr, len(js), D)
 
     def before_backward(self, plan: Plan):
         """Each plan re-zeroes the word-embedding gradient rows IT touched last time (the table gradient is dense,
@@ -346,31 +386,41 @@ class Engine:
         xf32 = alloc("i.xf32", (Ti, Di), F32)
         tl: List[dict] = []   # per-layer saved activations, text
         il: List[dict] = []
+        for l in range(Lt):
+            tl.append(dict(qkv=alloc(f"t{l}.qkv", (Tt, 3 * Dt)), ctx=alloc(f"t{l}.ctx", (Tt, Dt)),
+                           lse=alloc(f"t{l}.lse", (B, Ht, S), F32), a=alloc(f"t{l}.a", (Tt, Dt)),
+                           y=alloc(f"t{l}.y", (Tt, Dt)), m1=alloc(f"t{l}.m1", (Tt,), F32), r1=alloc(f"t{l}.r1", (Tt,), F32),
+                           h=alloc(f"t{l}.h", (Tt, It)), g=alloc(f"t{l}.g", (Tt, It)), f=alloc(f"t{l}.f", (Tt, Dt)),
+                           m2=alloc(f"t{l}.m2", (Tt,), F32), r2=alloc(f"t{l}.r2", (Tt,), F32)))
+            xt.append(alloc(f"t.x{l + 1}", (Tt, Dt)))
+        for l in range(Li):
+            il.append(dict(u=alloc(f"i{l}.u", (Ti, Di)), m1=alloc(f"i{l}.m1", (Ti,), F32), r1=alloc(f"i{l}.r1", (Ti,), F32),
+                           qkv=alloc(f"i{l}.qkv", (Ti, 3 * Di)), ctx=alloc(f"i{l}.ctx", (Ti, Di)),
+                           lse=alloc(f"i{l}.lse", (B, Hi, Nt), F32), xp=alloc(f"i{l}.xp", (Ti, Di)),
+                           w=alloc(f"i{l}.w", (Ti, Di)), m2=alloc(f"i{l}.m2", (Ti,), F32), r2=alloc(f"i{l}.r2", (Ti,), F32),
+                           h=alloc(f"i{l}.h", (Ti, Ii)), g=alloc(f"i{l}.g", (Ti, Ii))))
+            xi.append(alloc(f"i.x{l + 1}", (Ti, Di)))
+        xf = alloc("i.xf", (Ti, Di))
+        mf, rf = alloc("i.mf", (Ti,), F32), alloc("i.rf", (Ti,), F32)
+
+        def img_ln1(l):
+            """The ViT block's pre-attention LayerNorm of layer l; past the last layer, the final ViT LayerNorm.
+            It is issued together with the text tower's LayerNorm that closes layer l-1 (one grouped launch)."""
+            if l < Li:
+                LI = f"{IMG}encoder.layer.{l}."
+                return self._ln_fwd_job(xi[l], LI + "layernorm_before.weight", LI + "layernorm_before.bias", il[l]["u"],
+                                        il[l]["m1"], il[l]["r1"], Ti, Di, v.ln_eps)
+            if l == Li:
+                return self._ln_fwd_job(xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", xf, mf, rf, Ti, Di,
+                                        v.ln_eps, y32=xf32)
+            return None
+
+        self._ln_fwd(pl, f, [img_ln1(0)])
         for l in range(max(Lt, Li)):
             has_t, has_i = l < Lt, l < Li
             LT, LI = f"{TXT}encoder.layer.{l}.", f"{IMG}encoder.layer.{l}."
-            if has_t:
-                a = dict(qkv=alloc(f"t{l}.qkv", (Tt, 3 * Dt)), ctx=alloc(f"t{l}.ctx", (Tt, Dt)),
-                         lse=alloc(f"t{l}.lse", (B, Ht, S), F32), a=alloc(f"t{l}.a", (Tt, Dt)),
-                         y=alloc(f"t{l}.y", (Tt, Dt)), m1=alloc(f"t{l}.m1", (Tt,), F32), r1=alloc(f"t{l}.r1", (Tt,), F32),
-                         h=alloc(f"t{l}.h", (Tt, It)), g=alloc(f"t{l}.g", (Tt, It)), f=alloc(f"t{l}.f", (Tt, Dt)),
-                         m2=alloc(f"t{l}.m2", (Tt,), F32), r2=alloc(f"t{l}.r2", (Tt,), F32))
-                tl.append(a)
-                xt.append(alloc(f"t.x{l + 1}", (Tt, Dt)))
-            if has_i:
-                b_ = dict(u=alloc(f"i{l}.u", (Ti, Di)), m1=alloc(f"i{l}.m1", (Ti,), F32), r1=alloc(f"i{l}.r1", (Ti,), F32),
-                          qkv=alloc(f"i{l}.qkv", (Ti, 3 * Di)), ctx=alloc(f"i{l}.ctx", (Ti, Di)),
-                          lse=alloc(f"i{l}.lse", (B, Hi, Nt), F32), xp=alloc(f"i{l}.xp", (Ti, Di)),
-                          w=alloc(f"i{l}.w", (Ti, Di)), m2=alloc(f"i{l}.m2", (Ti,), F32), r2=alloc(f"i{l}.r2", (Ti,), F32),
-                          h=alloc(f"i{l}.h", (Ti, Ii)), g=alloc(f"i{l}.g", (Ti, Ii)))
-                il.append(b_)
-                xi.append(alloc(f"i.x{l + 1}", (Ti, Di)))
-                # (forked before the previous layer's closing text LayerNorm, see the end of the loop body)
-                if l == 0:
-                    f.fork()
-                self._ln_fwd(f, xi[l], LI + "layernorm_before.weight", LI + "layernorm_before.bias", b_["u"], b_["m1"],
-                             b_["r1"], Ti, Di, v.ln_eps, lane=2)
-            f.join()
+            a = tl[l] if has_t else None
+            b_ = il[l] if has_i else None
             # QKV
             pr = []
             if has_t:
@@ -397,14 +447,11 @@ class Engine:
                 pr.append(self._fwd_prob(b_["ctx"], self.w(LI + "attention.output.dense.weight"), b_["xp"], Ti, Di, Di,
                                          bias=self.p(LI + "attention.output.dense.bias"), residual=xi[l]))
             self._gemm(pl, f, pr, False, False)
-            f.fork()
-            if has_i:
-                self._ln_fwd(f, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["w"], b_["m2"],
-                             b_["r2"], Ti, Di, v.ln_eps, lane=2)
-            if has_t:
-                self._ln_fwd(f, a["a"], LT + "attention.output.LayerNorm.weight", LT + "attention.output.LayerNorm.bias",
-                             a["y"], a["m1"], a["r1"], Tt, Dt, t.ln_eps)
-            f.join()
+            self._ln_fwd(pl, f, [
+                self._ln_fwd_job(a["a"], LT + "attention.output.LayerNorm.weight", LT + "attention.output.LayerNorm.bias",
+                                 a["y"], a["m1"], a["r1"], Tt, Dt, t.ln_eps) if has_t else None,
+                self._ln_fwd_job(b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["w"], b_["m2"],
+                                 b_["r2"], Ti, Di, v.ln_eps) if has_i else None])
             # FFN up + GELU (pre-activation kept for the backward)
             pr = []
             if has_t:
@@ -424,16 +471,11 @@ class Engine:
                 pr.append(self._fwd_prob(b_["g"], self.w(LI + "output.dense.weight"), xi[l + 1], Ti, Di, Ii,
                                          bias=self.p(LI + "output.dense.bias"), residual=b_["xp"]))
             self._gemm(pl, f, pr, False, False)
-            f.fork()      # the next layer's image LayerNorm (lane 2) runs beside this text LayerNorm
-            if has_t:
-                self._ln_fwd(f, a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", xt[l + 1], a["m2"],
-                             a["r2"], Tt, Dt, t.ln_eps, y32=xt_last32 if l == Lt - 1 else None)
-        # final ViT LayerNorm
-        xf = alloc("i.xf", (Ti, Di))
-        mf, rf = alloc("i.mf", (Ti,), F32), alloc("i.rf", (Ti,), F32)
-        self._ln_fwd(f, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", xf, mf, rf, Ti, Di, v.ln_eps, y32=xf32,
-                     lane=2)
-        f.join()
+            # the text LayerNorm closing this layer + the image LayerNorm opening the next (or the final ViT one)
+            self._ln_fwd(pl, f, [
+                self._ln_fwd_job(a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", xt[l + 1], a["m2"],
+                                 a["r2"], Tt, Dt, t.ln_eps, y32=xt_last32 if l == Lt - 1 else None) if has_t else None,
+                img_ln1(l + 1) if has_i else None])
 
         # head
         pool_index = 0 if cfg.pool == "cls" else S - 1
@@ -477,14 +519,15 @@ class Engine:
         s.c("mh_head_bwd", C.byref(hp), C.byref(hg), _ptr(dlogits), _ptr(pooled), _ptr(feat), _ptr(fused), _ptr(dfeat),
             _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale),
             *site_args(p_head, 7))
-        self._ln_bwd(pl, s, dXf, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", mf, rf, dXi[0], Ti, Di)
-
         # backward temporaries, one set per layer parity
-        T_ = [dict(df=alloc(f"t.df{i}", (Tt, Dt)), dh=alloc(f"t.dh{i}", (Tt, It)), da=alloc(f"t.da{i}", (Tt, Dt)),
+        T_ = [dict(dh=alloc(f"t.dh{i}", (Tt, It)), da=alloc(f"t.da{i}", (Tt, Dt)),
                    dqkv=alloc(f"t.dqkv{i}", (Tt, 3 * Dt)),
-                   dfm=alloc(f"t.dfm{i}", (Tt, Dt)) if p_h > 0 else None,     # df / da times the dropout mask of the
-                   dam=alloc(f"t.dam{i}", (Tt, Dt)) if p_h > 0 else None)     # Linear output that fed the LayerNorm
-              for i in range(2)]
+                   dam=alloc(f"t.dam{i}", (Tt, Dt)) if p_h > 0 else None)     # da times the dropout mask of the Linear
+              for i in range(2)]                                              # output that fed the LayerNorm
+        # df (gradient at the FFN output) is written one segment EARLY, by the LayerNorm backward grouped into the
+        # end of the layer above: rotation of three, so the side-stream GEMMs of layer l+1 never see it overwritten
+        DF_ = [dict(df=alloc(f"t.df{i}", (Tt, Dt)), dfm=alloc(f"t.dfm{i}", (Tt, Dt)) if p_h > 0 else None)
+               for i in range(3)]
         I_ = [dict(dh=alloc(f"i.dh{i}", (Ti, Ii)), dxp=alloc(f"i.dxp{i}", (Ti, Di)),
                    dqkv=alloc(f"i.dqkv{i}", (Ti, 3 * Di))) for i in range(2)]
         t_dy, t_dctx = alloc("t.dy", (Tt, Dt)), alloc("t.dctx", (Tt, Dt))
@@ -492,21 +535,35 @@ class Engine:
         i_dw, i_dctx, i_du = alloc("i.dw", (Ti, Di)), alloc("i.dctx", (Ti, Di)), alloc("i.du", (Ti, Di))
         i_delta = alloc("i.delta", (B, Hi, Nt), F32)
 
+        def text_ln2_bwd(l, ct_):
+            """Backward of the LayerNorm that closes text layer l (incoming gradient dXt[ct_]).  Issued at the END of
+            the segment above, grouped with the image tower's LayerNorm there."""
+            if not (0 <= l < Lt):
+                return None
+            LT_ = f"{TXT}encoder.layer.{l}."
+            return self._ln_bwd_job(pl, dXt[ct_], tl[l]["f"], LT_ + "output.LayerNorm.weight", LT_ + "output.LayerNorm.bias",
+                                    tl[l]["m2"], tl[l]["r2"], DF_[l % 3]["df"], Tt, Dt,
+                                    dx_drop=DF_[l % 3]["dfm"] if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 3))
+
+        nl = max(Lt, Li)
+        self._ln_bwd(pl, s, [
+            self._ln_bwd_job(pl, dXf, xi[Li], IMG + "layernorm.weight", IMG + "layernorm.bias", mf, rf, dXi[0], Ti, Di),
+            text_ln2_bwd(nl - 1, 0) if Lt == nl else None])
+
+        t_dpre = alloc("t.dpre", (Tt, Dt))
         ct, ci = 0, 0   # current ping-pong index of the incoming gradient
-        for l in range(max(Lt, Li) - 1, -1, -1):
+        for l in range(nl - 1, -1, -1):
             has_t, has_i = l < Lt, l < Li
             LT, LI = f"{TXT}encoder.layer.{l}.", f"{IMG}encoder.layer.{l}."
             s = seg(f"bwd_layer_{l}")
             s.wait(f"bwd_layer_{l + 2}")
             a = tl[l] if has_t else None
             b_ = il[l] if has_i else None
-            t_df, t_dh, t_da, t_dqkv = (T_[l & 1][k] for k in ("df", "dh", "da", "dqkv"))
-            t_dfm = T_[l & 1]["dfm"] if p_h > 0 else t_df      # gradient w.r.t. the (dropped) FFN output dense
+            t_dh, t_da, t_dqkv = (T_[l & 1][k] for k in ("dh", "da", "dqkv"))
+            t_df = DF_[l % 3]["df"]
+            t_dfm = DF_[l % 3]["dfm"] if p_h > 0 else t_df     # gradient w.r.t. the (dropped) FFN output dense
             t_dam = T_[l & 1]["dam"] if p_h > 0 else t_da      # gradient w.r.t. the (dropped) attention output dense
             i_dh, i_dxp, i_dqkv = (I_[l & 1][k] for k in ("dh", "dxp", "dqkv"))
-            if has_t:   # through the output LayerNorm
-                self._ln_bwd(pl, s, dXt[ct], a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", a["m2"],
-                             a["r2"], t_df, Tt, Dt, dx_drop=t_dfm if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 3))
             # d gelu_in = (d_out @ W2) * gelu'(h)
             pr = []
             if has_t:
@@ -521,15 +578,12 @@ class Engine:
             if has_i:
                 pr.append(self._dgrad_prob(i_dh, self.w(LI + "intermediate.dense.weight"), i_dw, Ti, Ii, Di))
             self._gemm(pl, s, pr, False, True)
-            s.fork()
-            if has_i:
-                self._ln_bwd(pl, s, i_dw, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["m2"],
-                             b_["r2"], i_dxp, Ti, Di, dx_add=dXi[ci], lane=2)
-            if has_t:
-                self._ln_bwd(pl, s, t_dy, a["a"], LT + "attention.output.LayerNorm.weight",
-                             LT + "attention.output.LayerNorm.bias", a["m1"], a["r1"], t_da, Tt, Dt,
-                             dx_drop=t_dam if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 2))
-            s.join()
+            self._ln_bwd(pl, s, [
+                self._ln_bwd_job(pl, t_dy, a["a"], LT + "attention.output.LayerNorm.weight",
+                                 LT + "attention.output.LayerNorm.bias", a["m1"], a["r1"], t_da, Tt, Dt,
+                                 dx_drop=t_dam if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 2)) if has_t else None,
+                self._ln_bwd_job(pl, i_dw, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["m2"],
+                                 b_["r2"], i_dxp, Ti, Di, dx_add=dXi[ci]) if has_i else None])
             # through the attention output projection
             pr = []
             if has_t:
@@ -553,9 +607,20 @@ class Engine:
             if has_i:
                 pr.append(self._dgrad_prob(i_dqkv, self.w(LI + "attention.attention.query.weight", 3), i_du, Ti, 3 * Di, Di))
             self._gemm(pl, s, pr, False, True)
-            if has_i:
-                self._ln_bwd(pl, s, i_du, xi[l], LI + "layernorm_before.weight", LI + "layernorm_before.bias", b_["m1"],
-                             b_["r1"], dXi[(ci + 1) % 3], Ti, Di, dx_add=i_dxp)
+            # the image LayerNorm that opens this layer + the text LayerNorm that closes the layer below (at layer 0:
+            # the text embedding LayerNorm), one grouped launch
+            ct_next = (ct + 1) % 3 if has_t else ct
+            if l >= 1:
+                t_job = text_ln2_bwd(l - 1, ct_next)
+            else:
+                if p_h > 0:     # gradient w.r.t. the dropped embedding output -> w.r.t. the LayerNorm output
+                    s.c("mh_dropout_apply", _ptr(dXt[ct_next]), Tt * Dt, rng_t.data_ptr(), float(p_h), 1)
+                t_job = self._ln_bwd_job(pl, dXt[ct_next], pre0, TXT + "embeddings.LayerNorm.weight",
+                                         TXT + "embeddings.LayerNorm.bias", m0, r0, t_dpre, Tt, Dt)
+            self._ln_bwd(pl, s, [
+                t_job,
+                self._ln_bwd_job(pl, i_du, xi[l], LI + "layernorm_before.weight", LI + "layernorm_before.bias", b_["m1"],
+                                 b_["r1"], dXi[(ci + 1) % 3], Ti, Di, dx_add=i_dxp) if has_i else None])
             # weight gradients (+ bias gradients as row sums): one grouped launch per tower.  Measured on
             # MI355X: the 4+4 problems in ONE launch (864 tiles = 1.7 waves of 512 resident workgroups)
             # take 254 us, the two 432-tile launches back to back 215 us.
@@ -582,11 +647,6 @@ class Engine:
 
         # embeddings
         s = seg("bwd_embed")
-        t_dpre = alloc("t.dpre", (Tt, Dt))
-        if p_h > 0:     # gradient w.r.t. the dropped embedding output -> w.r.t. the LayerNorm output
-            s.c("mh_dropout_apply", _ptr(dXt[ct]), Tt * Dt, rng_t.data_ptr(), float(p_h), 1)
-        self._ln_bwd(pl, s, dXt[ct], pre0, TXT + "embeddings.LayerNorm.weight", TXT + "embeddings.LayerNorm.bias", m0, r0,
-                     t_dpre, Tt, Dt)
         gword = self.g(TXT + "embeddings.word_embeddings.weight")
         gtype0 = self.g(TXT + "embeddings.token_type_embeddings.weight")[:Dt] if t.type_vocab > 0 else None
         gpos = self.g(TXT + "embeddings.position_embeddings.weight")
