@@ -30,7 +30,8 @@ class MhGemmProblem(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
                 ("flags", C.c_int32), ("alpha", C.c_float),
-                ("drop_rng", c_void_p), ("drop_p", C.c_float), ("drop_stream", C.c_uint32)]
+                ("drop_rng", c_void_p), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
+                ("rows_dev", c_void_p), ("drop_rows", c_void_p)]
 
 
 class MhColsumJob(C.Structure):
@@ -39,12 +40,13 @@ class MhColsumJob(C.Structure):
 
 class MhLnFwdJob(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "gamma", "beta", "y", "y_f32", "mean", "rstd")] + \
-               [("rows", C.c_int32), ("eps", C.c_float)]
+               [("rows", C.c_int32), ("eps", C.c_float), ("rows_dev", c_void_p)]
 
 
 class MhLnBwdJob(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("dy", "x", "gamma", "mean", "rstd", "dx_add", "dx", "part", "dx_drop", "rng")] + \
-               [("n_part", C.c_int32), ("rows", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32)]
+               [("n_part", C.c_int32), ("rows", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
+                ("rows_dev", c_void_p), ("drop_rows", c_void_p)]
 
 
 class MhHeadParams(C.Structure):
@@ -66,6 +68,11 @@ _PROTOS = {
     "mh_colsum_partials_f32": [C.POINTER(MhColsumJob), c_int, c_int, c_int, c_float, c_void_p],
     "mh_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_attn_bwd": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_attn_fwd_packed": [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_attn_bwd_packed": [c_void_p] * 9 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_pack_plan": [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p],
+    "mh_pack_rows": [c_void_p] * 4 + [c_int, c_int, c_void_p],
+    "mh_unpack_rows": [c_void_p] * 3 + [c_int, c_int, c_void_p],
     "mh_bert_embed_fwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_dropout_apply": [c_void_p, c_int64, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_dropout_mask_u8": [c_void_p, c_int64, c_void_p, c_float, C.c_uint32, c_void_p],
@@ -74,8 +81,8 @@ _PROTOS = {
     "mh_patchify": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
     "mh_vit_assemble_fwd": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
     "mh_vit_assemble_bwd": [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p],
-    "mh_head_fwd": [C.POINTER(MhHeadParams), c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_float, C.c_uint32, c_void_p],
-    "mh_head_bwd": [C.POINTER(MhHeadParams), C.POINTER(MhHeadGrads)] + [c_void_p] * 8 + [c_int] * 8 + [c_float, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_head_fwd": [C.POINTER(MhHeadParams), c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_float, C.c_uint32, c_void_p, c_void_p],
+    "mh_head_bwd": [C.POINTER(MhHeadParams), C.POINTER(MhHeadGrads)] + [c_void_p] * 8 + [c_int] * 8 + [c_float, c_void_p, c_float, C.c_uint32, c_void_p, c_void_p],
     "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
     "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],

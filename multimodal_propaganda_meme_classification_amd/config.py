@@ -64,6 +64,8 @@ class ModelConfig:
     # the static counterpart of the GradScaler in Multimodal_example_task2C.py:60-64,712-717)
     compute_dtype: str = "bf16"
     grad_stream_scale: float = 0.0      # 0 = automatic: 1 for bf16, 8192 for fp16
+    pack_text: bool = True              # padding-free text tower: positions with attention_mask == 0 are never computed
+                                        # (they influence neither logits nor gradients); False = dense [B,S] rows
     head_dropout: float = 0.0           # nn.Dropout(0.3) on the pooled text features (...task2C.txt:160); the
                                         # parity / measurement plan runs every dropout at p = 0
 
@@ -76,7 +78,8 @@ class ModelConfig:
     def from_dict(d: dict) -> "ModelConfig":
         return ModelConfig(text=TextConfig(**d["text"]), image=ImageConfig(**d["image"]), proj=d["proj"],
                            num_classes=d["num_classes"], pool=d["pool"], compute_dtype=d.get("compute_dtype", "bf16"),
-                           grad_stream_scale=d.get("grad_stream_scale", 0.0), head_dropout=d.get("head_dropout", 0.0))
+                           grad_stream_scale=d.get("grad_stream_scale", 0.0), head_dropout=d.get("head_dropout", 0.0),
+                           pack_text=d.get("pack_text", True))
 
     @property
     def stream_scale(self) -> float:

@@ -117,7 +117,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
                                                            const int64_t* __restrict__ key_mask,
                                                            h16* __restrict__ out, float* __restrict__ lse,
                                                            int B, int S, int H, const uint32_t* __restrict__ rng,
-                                                           float drop_p, uint32_t drop_stream) {
+                                                           float drop_p, uint32_t drop_stream,
+                                                           const int32_t* __restrict__ cu,
+                                                           const int32_t* __restrict__ row_map) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,19 +132,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
-    const h16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    // packed token stream: this sequence's rows are cu[b] .. cu[b+1]-1 (Sb of them); dense: b*S .. b*S+S-1
+    const size_t r0 = cu ? (size_t)cu[b] : (size_t)b * S;
+    const int Sb = cu ? cu[b + 1] - cu[b] : S;
+    // position of local row i in the unpacked sequence (dropout mask index only)
+    auto pos = [&](int i) -> uint64_t { return (row_map && i < Sb) ? (uint64_t)(row_map[r0 + i] - b * S) : (uint64_t)i; };
+    const h16* qb = qkv + r0 * pitch + hh * HD;
     const h16* kb = qb + (size_t)H * HD;
     const h16* vb = qb + (size_t)2 * H * HD;
     const float c = 0.125f * LOG2E;  // 1/sqrt(64) folded with log2(e)
-    const int ntiles = (S + TILE - 1) / TILE;
+    const int ntiles = (Sb + TILE - 1) / TILE;
 
     auto stage = [&](int t, int slot) {
-        stage_tile<NT>(kb, pitch, t * TILE, S, tid, k_img + slot * IMG, nullptr);
-        stage_tile<NT>(vb, pitch, t * TILE, S, tid, nullptr, v_img + slot * IMG);
+        stage_tile<NT>(kb, pitch, t * TILE, Sb, tid, k_img + slot * IMG, nullptr);
+        stage_tile<NT>(vb, pitch, t * TILE, Sb, tid, nullptr, v_img + slot * IMG);
         if (tid < TILE) {   // wave 0, all 64 lanes
             const int key = t * TILE + tid;
             float bias = NEG_BIG;
-            if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) bias = 0.f;
+            if (key < Sb && (!key_mask || key_mask[r0 + key] != 0)) bias = 0.f;
             kbias[slot * TILE + tid] = bias;
             const unsigned long long bal = __ballot(bias == 0.f);
             if (tid == 0) {
@@ -156,12 +163,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
         __syncthreads();
     }
 
-    for (int qt = blockIdx.x * NW + wave; (NT_RES > 0) ? (qt * 32 < S) : (qt == (int)blockIdx.x * NW + wave);
+    for (int qt = blockIdx.x * NW + wave; (NT_RES > 0) ? (qt * 32 < Sb) : (qt == (int)blockIdx.x * NW + wave);
          qt += NW * gridDim.x) {
         const int wq0 = qt * 32;
-        const bool active = wq0 < S;
+        const bool active = wq0 < Sb;
         h16x8 qf[4];
-        load_rows_frag(qb, pitch, wq0, S, lane, qf);
+        load_rows_frag(qb, pitch, wq0, Sb, lane, qf);
         f32x16 o[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -214,10 +221,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
                 }
                 l = l * alpha + ps;
                 if (DROP && drop.on) {   // O = drop(P) V: the normaliser l keeps every key, only the PV operand is masked
-                    const uint64_t rowbase = (((uint64_t)bh * S) + (uint64_t)(wq0 + (lane & 31))) * (uint64_t)S;
+                    const uint64_t rowbase = (((uint64_t)bh * S) + pos(wq0 + (lane & 31))) * (uint64_t)S;
 #pragma unroll
                     for (int g = 0; g < 16; ++g)
-                        st[g] *= mh_drop_mul(drop, rowbase + (uint64_t)(t * TILE + sub * 32 + acc_row(g, h)));
+                        st[g] *= mh_drop_mul(drop, rowbase + pos(t * TILE + sub * 32 + acc_row(g, h)));
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -235,9 +242,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
         if (!active) continue;
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
-        store_rows_from_T(out + (size_t)b * S * H * HD + hh * HD, (size_t)H * HD, wq0, S, lane, o, inv);
+        store_rows_from_T(out + r0 * H * HD + hh * HD, (size_t)H * HD, wq0, Sb, lane, o, inv);
         const int q = wq0 + (lane & 31);
-        if (h == 0 && q < S) lse[((size_t)b * H + hh) * S + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
+        if (h == 0 && q < Sb) lse[((size_t)b * H + hh) * S + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
     }
 }
 
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
                                                               float* __restrict__ delta,
                                                               h16* __restrict__ dqkv, int B, int S, int H,
                                                               const uint32_t* __restrict__ rng, float drop_p,
-                                                              uint32_t drop_stream) {
+                                                              uint32_t drop_stream, const int32_t* __restrict__ cu,
+                                                              const int32_t* __restrict__ row_map) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -267,20 +275,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
-    const h16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    // packed token stream: this sequence's rows are cu[b] .. cu[b+1]-1 (Sb of them); dense: b*S .. b*S+S-1
+    const size_t r0 = cu ? (size_t)cu[b] : (size_t)b * S;
+    const int Sb = cu ? cu[b + 1] - cu[b] : S;
+    // position of local row i in the unpacked sequence (dropout mask index only)
+    auto pos = [&](int i) -> uint64_t { return (row_map && i < Sb) ? (uint64_t)(row_map[r0 + i] - b * S) : (uint64_t)i; };
+    const h16* qb = qkv + r0 * pitch + hh * HD;
     const h16* kb = qb + (size_t)H * HD;
     const h16* vb = qb + (size_t)2 * H * HD;
-    const h16* dob = dout + (size_t)b * S * H * HD + hh * HD;
+    const h16* dob = dout + r0 * H * HD + hh * HD;
     const float c = 0.125f * LOG2E;
-    const int ntiles = (S + TILE - 1) / TILE;
+    const int ntiles = (Sb + TILE - 1) / TILE;
 
     auto stage = [&](int t, int slot) {
-        stage_tile<NT>(kb, pitch, t * TILE, S, tid, k_img + slot * IMG, kt_img + slot * IMG);
-        stage_tile<NT>(vb, pitch, t * TILE, S, tid, v_img + slot * IMG, nullptr);
+        stage_tile<NT>(kb, pitch, t * TILE, Sb, tid, k_img + slot * IMG, kt_img + slot * IMG);
+        stage_tile<NT>(vb, pitch, t * TILE, Sb, tid, v_img + slot * IMG, nullptr);
         if (tid < TILE) {
             const int key = t * TILE + tid;
             float bias = NEG_BIG;
-            if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) bias = 0.f;
+            if (key < Sb && (!key_mask || key_mask[r0 + key] != 0)) bias = 0.f;
             kbias[slot * TILE + tid] = bias;
             const unsigned long long bal = __ballot(bias == 0.f);
             if (tid == 0) {
@@ -294,20 +307,20 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
         __syncthreads();
     }
 
-    for (int qt = blockIdx.x * NW + wave; (NT_RES > 0) ? (qt * 32 < S) : (qt == (int)blockIdx.x * NW + wave);
+    for (int qt = blockIdx.x * NW + wave; (NT_RES > 0) ? (qt * 32 < Sb) : (qt == (int)blockIdx.x * NW + wave);
          qt += NW * gridDim.x) {
         const int wq0 = qt * 32;
-        const bool active = wq0 < S;
+        const bool active = wq0 < Sb;
         const int q = wq0 + (lane & 31);
         h16x8 qf[4], dof[4];
-        load_rows_frag(qb, pitch, wq0, S, lane, qf);
-        load_rows_frag(dob, (size_t)H * HD, wq0, S, lane, dof);
+        load_rows_frag(qb, pitch, wq0, Sb, lane, qf);
+        load_rows_frag(dob, (size_t)H * HD, wq0, Sb, lane, dof);
         // delta = rowsum(dO o O), computed here (each lane holds half of its query's 64 dims) and published for the
         // dK/dV kernel that follows on the same stream
         float dl = 0.f;
         {
             h16x8 of[4];
-            load_rows_frag(out + (size_t)b * S * H * HD + hh * HD, (size_t)H * HD, wq0, S, lane, of);
+            load_rows_frag(out + r0 * H * HD + hh * HD, (size_t)H * HD, wq0, Sb, lane, of);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
             dl += __shfl_xor(dl, 32, 64);
         }
         float lse2 = 0.f;
-        if (q < S) {
+        if (q < Sb) {
             lse2 = lse[((size_t)b * H + hh) * S + q] * LOG2E;
             if (h == 0) delta[((size_t)b * H + hh) * S + q] = dl;
         }
@@ -357,8 +370,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
                         const float p = __builtin_amdgcn_exp2f(st[g] * c + kb4[e] - lse2);
                         float dpg = dp[g];
                         if (DROP && drop.on)   // dP = dP_drop * mask / (1 - p)
-                            dpg *= mh_drop_mul(drop, ((uint64_t)bh * S + (uint64_t)q) * (uint64_t)S +
-                                                         (uint64_t)(t * TILE + sub * 32 + acc_row(g, h)));
+                            dpg *= mh_drop_mul(drop, ((uint64_t)bh * S + pos(q)) * (uint64_t)S +
+                                                         pos(t * TILE + sub * 32 + acc_row(g, h)));
                         st[g] = p * (dpg - dl);  // dS^T (unscaled)
                     }
                 }
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
             }
         }
         if (!active) continue;
-        store_rows_from_T(dqkv + (size_t)b * S * pitch + hh * HD, pitch, wq0, S, lane, dq, 0.125f);
+        store_rows_from_T(dqkv + r0 * pitch + hh * HD, pitch, wq0, Sb, lane, dq, 0.125f);
     }
 }
 
@@ -387,7 +400,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
                                                                const float* __restrict__ delta,
                                                                h16* __restrict__ dqkv, int B, int S, int H,
                                                                const uint32_t* __restrict__ rng, float drop_p,
-                                                               uint32_t drop_stream) {
+                                                               uint32_t drop_stream, const int32_t* __restrict__ cu,
+                                                               const int32_t* __restrict__ row_map) {
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -402,21 +416,26 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
-    const h16* qb = qkv + (size_t)b * S * pitch + hh * HD;
+    // packed token stream: this sequence's rows are cu[b] .. cu[b+1]-1 (Sb of them); dense: b*S .. b*S+S-1
+    const size_t r0 = cu ? (size_t)cu[b] : (size_t)b * S;
+    const int Sb = cu ? cu[b + 1] - cu[b] : S;
+    // position of local row i in the unpacked sequence (dropout mask index only)
+    auto pos = [&](int i) -> uint64_t { return (row_map && i < Sb) ? (uint64_t)(row_map[r0 + i] - b * S) : (uint64_t)i; };
+    const h16* qb = qkv + r0 * pitch + hh * HD;
     const h16* kb = qb + (size_t)H * HD;
     const h16* vb = qb + (size_t)2 * H * HD;
-    const h16* dob = dout + (size_t)b * S * H * HD + hh * HD;
+    const h16* dob = dout + r0 * H * HD + hh * HD;
     const float c = 0.125f * LOG2E;
-    const int ntiles = (S + TILE - 1) / TILE;
+    const int ntiles = (Sb + TILE - 1) / TILE;
 
     auto stage = [&](int t, int slot) {
-        stage_tile<NT>(qb, pitch, t * TILE, S, tid, q_img + slot * IMG, qt_img + slot * IMG);
-        stage_tile<NT>(dob, (size_t)H * HD, t * TILE, S, tid, do_img + slot * IMG, dot_img + slot * IMG);
+        stage_tile<NT>(qb, pitch, t * TILE, Sb, tid, q_img + slot * IMG, qt_img + slot * IMG);
+        stage_tile<NT>(dob, (size_t)H * HD, t * TILE, Sb, tid, do_img + slot * IMG, dot_img + slot * IMG);
         for (int i = tid; i < TILE; i += NT) {
             const int qq = t * TILE + i;
             // rows past S: lse = +big makes P = exp2(-big) = 0, so they add nothing
-            lse_t[slot * TILE + i] = qq < S ? lse[((size_t)b * H + hh) * S + qq] * LOG2E : 1.0e30f;
-            dl_t[slot * TILE + i] = qq < S ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
+            lse_t[slot * TILE + i] = qq < Sb ? lse[((size_t)b * H + hh) * S + qq] * LOG2E : 1.0e30f;
+            dl_t[slot * TILE + i] = qq < Sb ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
         }
     };
     if (NT_RES > 0) {
@@ -424,16 +443,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
         __syncthreads();
     }
 
-    for (int kt = blockIdx.x * NW + wave; (NT_RES > 0) ? (kt * 32 < S) : (kt == (int)blockIdx.x * NW + wave);
+    for (int kt = blockIdx.x * NW + wave; (NT_RES > 0) ? (kt * 32 < Sb) : (kt == (int)blockIdx.x * NW + wave);
          kt += NW * gridDim.x) {
         const int wk0 = kt * 32;
-        const bool active = wk0 < S;
+        const bool active = wk0 < Sb;
         const int key = wk0 + (lane & 31);
         h16x8 kf[4], vf[4];
-        load_rows_frag(kb, pitch, wk0, S, lane, kf);
-        load_rows_frag(vb, pitch, wk0, S, lane, vf);
+        load_rows_frag(kb, pitch, wk0, Sb, lane, kf);
+        load_rows_frag(vb, pitch, wk0, Sb, lane, vf);
         float kbias = NEG_BIG;
-        if (key < S && (!key_mask || key_mask[(size_t)b * S + key] != 0)) kbias = 0.f;
+        if (key < Sb && (!key_mask || key_mask[r0 + key] != 0)) kbias = 0.f;
         f32x16 dk[2], dv[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
             const float* dt_ = dl_t + slot * TILE;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-                if (t * TILE + sub * 32 >= S) continue;   // query rows past S
+                if (t * TILE + sub * 32 >= Sb) continue;   // query rows past the sequence
                 f32x16 st, dp;  // rows = queries (register), cols = keys (lane)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
@@ -480,8 +499,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
                         const float p = __builtin_amdgcn_exp2f(st[g] * c + kbias - l4[e]);
                         float mul = 1.f;
                         if (DROP && drop.on)
-                            mul = mh_drop_mul(drop, ((uint64_t)bh * S + (uint64_t)(t * TILE + sub * 32 + 8 * g4 + 4 * h + e)) *
-                                                            (uint64_t)S + (uint64_t)key);
+                            mul = mh_drop_mul(drop, ((uint64_t)bh * S + pos(t * TILE + sub * 32 + 8 * g4 + 4 * h + e)) *
+                                                            (uint64_t)S + pos(key));
                         pp[g] = p * mul;                     // drop(P): what multiplied V in the forward
                         st[g] = p * (dp[g] * mul - d4[e]);   // dS (unscaled)
                     }
@@ -499,10 +518,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
             }
         }
         if (!active) continue;
-        h16* dkb = dqkv + (size_t)b * S * pitch + (size_t)H * HD + hh * HD;
-        h16* dvb = dqkv + (size_t)b * S * pitch + (size_t)2 * H * HD + hh * HD;
-        store_rows_from_T(dkb, pitch, wk0, S, lane, dk, 0.125f);
-        store_rows_from_T(dvb, pitch, wk0, S, lane, dv, 1.0f);
+        h16* dkb = dqkv + r0 * pitch + (size_t)H * HD + hh * HD;
+        h16* dvb = dqkv + r0 * pitch + (size_t)2 * H * HD + hh * HD;
+        store_rows_from_T(dkb, pitch, wk0, Sb, lane, dk, 0.125f);
+        store_rows_from_T(dvb, pitch, wk0, Sb, lane, dv, 1.0f);
     }
 }
 
@@ -559,8 +578,9 @@ int split_for(int S) {
         }                                                                                                \
     } while (0)
 
-extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int B, int S,
-                           int H, const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream) {
+static int attn_fwd_impl(const void* qkv, const int64_t* key_mask, void* out, float* lse, const int32_t* cu,
+                         const int32_t* row_map, int B, int S, int H, const uint32_t* rng, float drop_p,
+                         uint32_t drop_stream, mh_stream_t stream) {
     if (!qkv || !out || !lse) return MH_EINVAL;
     if (B < 1 || S < 1 || H < 1 || drop_p < 0.f || drop_p >= 1.f) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -568,23 +588,34 @@ extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, 
     const bool dr = rng && drop_p > 0.f;
     if (S <= 128) {
         constexpr int L = 2 * 2 * IMG + 2 * TILE * 4 + 64;
-        ATTN_LAUNCH(attn_fwd_kernel, 4, 2, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_fwd_kernel, 4, 2, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream, cu, row_map);
     } else if (S <= 224 && fwd_seven_waves()) {
         constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
-        ATTN_LAUNCH(attn_fwd_kernel, 7, 4, dim3(1, B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_fwd_kernel, 7, 4, dim3(1, B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream, cu, row_map);
     } else if (S <= 256) {
         constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
-        ATTN_LAUNCH(attn_fwd_kernel, 4, 4, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_fwd_kernel, 4, 4, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream, cu, row_map);
     } else {
         constexpr int L = 2 * IMG + TILE * 4 + 64;
-        ATTN_LAUNCH(attn_fwd_kernel, 4, 0, dim3((S + 127) / 128, B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_fwd_kernel, 4, 0, dim3((S + 127) / 128, B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream, cu, row_map);
     }
     return mh_launch_status();
 }
 
-extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
-                           const float* lse, float* delta, void* dqkv, int B, int S, int H, const uint32_t* rng,
-                           float drop_p, uint32_t drop_stream, mh_stream_t stream) {
+extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int B, int S,
+                           int H, const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream) {
+    return attn_fwd_impl(qkv, key_mask, out, lse, nullptr, nullptr, B, S, H, rng, drop_p, drop_stream, stream);
+}
+extern "C" int mh_attn_fwd_packed(const void* qkv, const int64_t* key_mask, void* out, float* lse, const int32_t* cu,
+                                  const int32_t* row_map, int B, int S, int H, const uint32_t* rng, float drop_p,
+                                  uint32_t drop_stream, mh_stream_t stream) {
+    if (!cu) return MH_EINVAL;
+    return attn_fwd_impl(qkv, key_mask, out, lse, cu, row_map, B, S, H, rng, drop_p, drop_stream, stream);
+}
+
+static int attn_bwd_impl(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
+                         const float* lse, float* delta, void* dqkv, const int32_t* cu, const int32_t* row_map, int B,
+                         int S, int H, const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream) {
     if (!qkv || !out || !dout || !lse || !delta || !dqkv) return MH_EINVAL;
     if (B < 1 || S < 1 || H < 1 || drop_p < 0.f || drop_p >= 1.f) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -597,24 +628,39 @@ extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void*
     if (S <= 128 && S <= rmax) {
         constexpr int L1 = 3 * 2 * IMG + 2 * TILE * 4 + 64, L2 = 4 * 2 * IMG + 2 * 2 * TILE * 4;
         const dim3 grid(split_for(S), B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
-        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 2, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 2, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
     } else if (S <= 256 && S <= rmax) {
         constexpr int L1 = 3 * 4 * IMG + 4 * TILE * 4 + 64, L2 = 4 * 4 * IMG + 2 * 4 * TILE * 4;
         const dim3 grid(split_for(S), B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
-        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 4, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 4, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
     } else if (S > 128 && S <= 224 && seven_waves()) {
         // ViT-B/16 (197 tokens = 7 tiles of 32): one 7-wave workgroup per head, every wave busy, K/V (Q/dO) streamed once
         constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
         const dim3 grid(1, B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 7, 0, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
-        ATTN_LAUNCH(attn_bwd_dkv_kernel, 7, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 7, 0, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 7, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
     } else {
         constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
         const dim3 grid((S + 127) / 128, B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 0, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
-        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 0, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
     }
     return mh_launch_status();
+}
+
+extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
+                           const float* lse, float* delta, void* dqkv, int B, int S, int H, const uint32_t* rng,
+                           float drop_p, uint32_t drop_stream, mh_stream_t stream) {
+    return attn_bwd_impl(qkv, key_mask, out, dout, lse, delta, dqkv, nullptr, nullptr, B, S, H, rng, drop_p, drop_stream,
+                         stream);
+}
+extern "C" int mh_attn_bwd_packed(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
+                                  const float* lse, float* delta, void* dqkv, const int32_t* cu, const int32_t* row_map,
+                                  int B, int S, int H, const uint32_t* rng, float drop_p, uint32_t drop_stream,
+                                  mh_stream_t stream) {
+    if (!cu) return MH_EINVAL;
+    return attn_bwd_impl(qkv, key_mask, out, dout, lse, delta, dqkv, cu, row_map, B, S, H, rng, drop_p, drop_stream,
+                         stream);
 }

@@ -359,3 +359,132 @@ extern "C" int mh_dropout_mask_u8(uint8_t* out, int64_t n, const uint32_t* rng, 
                        rng, p, stream_id);
     return mh_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Padding-free text tower: row bookkeeping from the attention mask (see include/memehip.h: mh_pack_plan).
+// One workgroup of 16 waves; a wave owns sequences w, w+16, ... and walks 64 positions per step
+// (ballot + popcount), so the two passes cost ~S/64 dependent steps each.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(1024) void pack_plan_kernel(const int64_t* __restrict__ mask, int B, int S, int pool,
+                                                         int32_t* __restrict__ cu, int32_t* __restrict__ row_map,
+                                                         int32_t* __restrict__ inv_map, int64_t* __restrict__ pmask,
+                                                         int32_t* __restrict__ pool_rows, int32_t* __restrict__ n_rows) {
+    __shared__ int cnt[1024];
+    __shared__ int start[1025];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pass 1: rows kept per sequence (mask != 0, or the pooled position)
+    for (int b = wave; b < B; b += 16) {
+        int c = 0;
+        for (int i0 = 0; i0 < S; i0 += 64) {
+            const int i = i0 + lane;
+            const bool keep = i < S && (mask[(size_t)b * S + i] != 0 || i == pool);
+            c += __popcll(__ballot(keep));
+        }
+        if (lane == 0) cnt[b] = c;
+    }
+    __syncthreads();
+    // exclusive scan over B <= 1024 counts: wave 0, 16 entries per lane
+    if (wave == 0) {
+        int loc[16], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = lane * 16 + j;
+            loc[j] = b < B ? cnt[b] : 0;
+            sum += loc[j];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = lane * 16 + j;
+            if (b <= B) start[b] = run;     // b == B: the total
+            run += loc[j];
+        }
+        if (lane == 63 && B == 1024) start[1024] = incl;
+    }
+    __syncthreads();
+    const int n = start[B];
+    for (int b = threadIdx.x; b <= B; b += 1024) cu[b] = start[b];
+    if (threadIdx.x == 0) *n_rows = n;
+    // pass 2: scatter
+    for (int b = wave; b < B; b += 16) {
+        int r = start[b];
+        for (int i0 = 0; i0 < S; i0 += 64) {
+            const int i = i0 + lane;
+            const int64_t mv = i < S ? mask[(size_t)b * S + i] : 0;
+            const bool keep = i < S && (mv != 0 || i == pool);
+            const unsigned long long bal = __ballot(keep);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep) {
+                const int pr = r + before;
+                row_map[pr] = b * S + i;
+                pmask[pr] = mv != 0 ? 1 : 0;
+                if (i == pool) pool_rows[b] = pr;
+            }
+            if (i < S) inv_map[(size_t)b * S + i] = keep ? r + before : -1;
+            r += __popcll(bal);
+        }
+    }
+    for (int r = n + threadIdx.x; r < B * S; r += 1024) {
+        row_map[r] = -1;
+        pmask[r] = 0;
+    }
+}
+
+// wave per row, 16-B chunks
+__global__ __launch_bounds__(256) void pack_rows_kernel(const h16* __restrict__ src, const int32_t* __restrict__ row_map,
+                                                        const int32_t* __restrict__ n_rows, h16* __restrict__ dst,
+                                                        int max_rows, int D) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= max_rows || r >= *n_rows) return;
+    const int d = row_map[r];
+    for (int c = lane * 8; c < D; c += 512)
+        *(i32x4*)(dst + (size_t)r * D + c) = *(const i32x4*)(src + (size_t)d * D + c);
+}
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const h16* __restrict__ src, const int32_t* __restrict__ inv_map,
+                                                          h16* __restrict__ dst, int max_rows, int D) {
+    const int d = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (d >= max_rows) return;
+    const int r = inv_map[d];
+    for (int c = lane * 8; c < D; c += 512) {
+        i32x4 v = {0, 0, 0, 0};
+        if (r >= 0) v = *(const i32x4*)(src + (size_t)r * D + c);
+        *(i32x4*)(dst + (size_t)d * D + c) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int mh_pack_plan(const int64_t* mask, int B, int S, int pool_index, int32_t* cu, int32_t* row_map,
+                            int32_t* inv_map, int64_t* pmask, int32_t* pool_rows, int32_t* n_rows, mh_stream_t stream) {
+    if (!mask || !cu || !row_map || !inv_map || !pmask || !pool_rows || !n_rows) return MH_EINVAL;
+    if (B < 1 || B > 1024 || S < 1 || pool_index < 0 || pool_index >= S) return MH_ESHAPE;
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, S, pool_index, cu, row_map,
+                       inv_map, pmask, pool_rows, n_rows);
+    return mh_launch_status();
+}
+
+extern "C" int mh_pack_rows(const void* src, const int32_t* row_map, const int32_t* n_rows, void* dst, int max_rows,
+                            int D, mh_stream_t stream) {
+    if (!src || !row_map || !n_rows || !dst) return MH_EINVAL;
+    if (max_rows < 1 || D < 8 || (D % 8)) return MH_ESHAPE;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((max_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const h16*)src,
+                       row_map, n_rows, (h16*)dst, max_rows, D);
+    return mh_launch_status();
+}
+
+extern "C" int mh_unpack_rows(const void* src, const int32_t* inv_map, void* dst, int max_rows, int D,
+                              mh_stream_t stream) {
+    if (!src || !inv_map || !dst) return MH_EINVAL;
+    if (max_rows < 1 || D < 8 || (D % 8)) return MH_ESHAPE;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((max_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const h16*)src,
+                       inv_map, (h16*)dst, max_rows, D);
+    return mh_launch_status();
+}

@@ -126,8 +126,7 @@ MH_DEV h16x8 read_frag(const char* lds, int rb, int kk, int lane) {
 
 // ---- epilogue: f32 tile in LDS -> bias / GELU / gelu' / residual -> 16-B coalesced stores ----------
 template <int TM, int NTHR = TM * 2, bool DROP = true>
-MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n0, int tid) {
-    const int M = P.M;
+MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n0, int tid, int M) {
     const int flags = P.flags;
     const int ldc = P.ldc;
     const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
@@ -155,8 +154,9 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
         }
         const size_t o = (size_t)gm * ldc + gn;
         if (DROP && drop.on) {     // nn.Dropout on the Linear output (BertSelfOutput / BertOutput), before the residual add
+            const uint64_t dr = P.drop_rows ? (uint64_t)P.drop_rows[gm] : (uint64_t)gm;   // row in the unpacked tensor
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= mh_drop_mul(drop, (uint64_t)gm * (uint64_t)P.N + (uint64_t)(gn + e));
+            for (int e = 0; e < 8; ++e) v[e] *= mh_drop_mul(drop, dr * (uint64_t)P.N + (uint64_t)(gn + e));
         }
         if (P.aux) {
             Pack8 u;
@@ -227,7 +227,17 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int M = P.M, N = P.N, K = P.K;
+    int M = P.M, K = P.K;
+    const int N = P.N;
+    if (P.rows_dev) {   // packed (padding-free) token rows: the live row count is only known on the device
+        const int live = *P.rows_dev;
+        if (LA == 0) {
+            M = min(M, live);
+            if (m0 >= M) return;     // whole tile past the live rows (uniform per workgroup)
+        } else {
+            K = min(K, live);
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / NWN) * (NI * 16), wn0 = (wave % NWN) * (NJ * 16);
 
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
             }
     __syncthreads();
 
-    epilogue_rows<BM, NW * 64, DROP>(P, cs, m0, n0, tid);
+    epilogue_rows<BM, NW * 64, DROP>(P, cs, m0, n0, tid, M);
 }
 
 // one 1-KiB LDS-DMA piece of a 16-KiB panel ([128 rows][64 k] or [64 k][128 rows]), swizzle on the source
@@ -384,7 +394,17 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
     const int lt = t - g.d[pi].tile_start;
     const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
     const int m0 = tm * R_BM, n0 = tn * BN;
-    const int M = P.M, N = P.N, K = P.K;
+    int M = P.M, K = P.K;
+    const int N = P.N;
+    if (P.rows_dev) {
+        const int live = *P.rows_dev;
+        if (LA == 0) {
+            M = min(M, live);
+            if (m0 >= M) return;
+        } else {
+            K = min(K, live);
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -474,7 +494,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
                 cs[row * BN + col] = acc[i][j][r];
             }
     __syncthreads();
-    epilogue_rows<R_BM>(P, cs, m0, n0, tid);
+    epilogue_rows<R_BM>(P, cs, m0, n0, tid, M);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -517,7 +537,17 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
     const int lt = t - g.d[pi].tile_start;
     const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
     const int m0 = tm * R_BM, n0 = tn * BN;
-    const int M = P.M, N = P.N, K = P.K;
+    int M = P.M, K = P.K;
+    const int N = P.N;
+    if (P.rows_dev) {
+        const int live = *P.rows_dev;
+        if (LA == 0) {
+            M = min(M, live);
+            if (m0 >= M) return;
+        } else {
+            K = min(K, live);
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
@@ -641,7 +671,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
                 cs[row * BN + col] = acc[i][j][r];
             }
     __syncthreads();
-    epilogue_rows<R_BM>(P, cs, m0, n0, tid);
+    epilogue_rows<R_BM>(P, cs, m0, n0, tid, M);
 }
 
 int g_variant = -1;  // -1: read MEMEHIP_GEMM_VARIANT once; 0 = register staging, 1 = LDS-DMA 4 waves, 2 = 256x128 ring,

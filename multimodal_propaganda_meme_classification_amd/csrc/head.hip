@@ -11,13 +11,14 @@ constexpr int RB = 32;  // batch rows held in registers per pass
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ th, const float* __restrict__ ih,
                                                    float* __restrict__ pooled, int B, int S, int Nt, int Dt, int Di,
                                                    int pool, const uint32_t* __restrict__ rng, float drop_p,
-                                                   uint32_t drop_stream) {
+                                                   uint32_t drop_stream, const int32_t* __restrict__ text_rows) {
     const DropCtx drop = mh_drop_ctx(rng, drop_p, drop_stream);
     const int Dp = Dt + Di;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * Dp) return;
     const int b = idx / Dp, d = idx % Dp;
-    pooled[idx] = d < Dt ? th[((size_t)b * S + pool) * Dt + d] * mh_drop_mul(drop, (uint64_t)b * Dt + d)
+    const size_t trow = text_rows ? (size_t)text_rows[b] : (size_t)b * S + pool;
+    pooled[idx] = d < Dt ? th[trow * Dt + d] * mh_drop_mul(drop, (uint64_t)b * Dt + d)
                          : ih[(size_t)b * Nt * Di + (d - Dt)];
 }
 
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ W, void* __restrict__ dx,
                                                         size_t ldx, int M, int N, int K, float scale,
                                                         const uint32_t* __restrict__ rng, float drop_p,
-                                                        uint32_t drop_stream) {
+                                                        uint32_t drop_stream,
+                                                        const int32_t* __restrict__ out_rows = nullptr) {
     const DropCtx drop = mh_drop_ctx(rng, drop_p, drop_stream);
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int m = blockIdx.y;
@@ -66,8 +68,9 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
     float acc = 0.f;
 #pragma unroll 8
     for (int n = 0; n < N; ++n) acc += d[n] * W[(size_t)n * K + k];
-    if (OUT_BF16) ((h16*)dx)[(size_t)m * ldx + k] = mh_f2bf(acc * scale * mh_drop_mul(drop, (uint64_t)m * K + k));
-    else ((float*)dx)[(size_t)m * ldx + k] = acc;
+    const size_t orow = out_rows ? (size_t)out_rows[m] * K : (size_t)m * ldx;   // packed text tower: row per sample
+    if (OUT_BF16) ((h16*)dx)[orow + k] = mh_f2bf(acc * scale * mh_drop_mul(drop, (uint64_t)m * K + k));
+    else ((float*)dx)[orow + k] = acc;
 }
 
 // dW[n][k] = sum_m dy[m][n] x[m][k] ; db[n] = sum_m dy[m][n]
@@ -182,14 +185,14 @@ int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y
 extern "C" int mh_head_fwd(const MhHeadParams* p, const float* text_hidden, const float* image_hidden,
                            int text_pool_index, float* pooled, float* feat, float* fused, float* logits, int B,
                            int S, int Nt, int Dt, int Di, int P, int C, const uint32_t* rng, float drop_p,
-                           uint32_t drop_stream, mh_stream_t stream) {
+                           uint32_t drop_stream, const int32_t* text_rows, mh_stream_t stream) {
     if (!p || !text_hidden || !image_hidden || !pooled || !feat || !fused || !logits) return MH_EINVAL;
     if (!p->Wt || !p->bt || !p->Wi || !p->bi || !p->Wf || !p->bf_ || !p->Wo || !p->bo) return MH_EINVAL;
     if (B < 1 || text_pool_index < 0 || text_pool_index >= S || Nt < 1 || P < 1 || C < 1) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Dp = Dt + Di;
     hipLaunchKernelGGL(pool_kernel, dim3((B * Dp + 255) / 256), dim3(256), 0, s, text_hidden,
-                       image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index, rng, drop_p, drop_stream);
+                       image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index, rng, drop_p, drop_stream, text_rows);
     linear_fwd(pooled, Dp, p->Wt, p->bt, feat, 2 * P, B, P, Dt, s);
     linear_fwd(pooled + Dt, Dp, p->Wi, p->bi, feat + P, 2 * P, B, P, Di, s);
     linear_fwd(feat, 2 * P, p->Wf, p->bf_, fused, P, B, P, 2 * P, s);
@@ -201,7 +204,7 @@ extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const fl
                            const float* feat, const float* fused, float* dfeat, float* dfused, void* d_text_hidden,
                            void* d_image_hidden, int text_pool_index, int B, int S, int Nt, int Dt, int Di, int P,
                            int C, float out_scale, const uint32_t* rng, float drop_p, uint32_t drop_stream,
-                           mh_stream_t stream) {
+                           const int32_t* text_rows, mh_stream_t stream) {
     if (!p || !g || !dlogits || !pooled || !feat || !fused || !dfeat || !dfused || !d_text_hidden ||
         !d_image_hidden)
         return MH_EINVAL;
@@ -227,7 +230,8 @@ extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const fl
                        g->Wi, g->bi, B, P, Di);
     // gradients of the pooled rows go straight into the [B][S][D] hidden-state gradient buffers
     hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Dt), B), dim3(256), 0, s, dfeat, 2 * P, p->Wt,
-                       (void*)((h16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt, B, P, Dt, out_scale, rng, drop_p, drop_stream);
+                       text_rows ? d_text_hidden : (void*)((h16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt,
+                       B, P, Dt, out_scale, rng, drop_p, drop_stream, text_rows);
     hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Di), B), dim3(256), 0, s, dfeat + P, 2 * P, p->Wi,
                        d_image_hidden, (size_t)Nt * Di, B, P, Di, out_scale, nullptr, 0.f, 0u);
     return mh_launch_status();

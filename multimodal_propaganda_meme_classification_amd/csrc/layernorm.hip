@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp, int D
     float* __restrict__ y32 = jb.y_f32;
     float* __restrict__ mean = jb.mean;
     float* __restrict__ rstd = jb.rstd;
-    const int rows = jb.rows;
+    const int rows = jb.rows_dev ? min(jb.rows, *jb.rows_dev) : jb.rows;
     const float eps = jb.eps;
     const int lane = threadIdx.x & 63;
     const int row = ((int)blockIdx.x - grp.start[j]) * 4 + (threadIdx.x >> 6);
@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp, int D
     h16* __restrict__ dx = (h16*)jb.dx;
     float* __restrict__ part = jb.part;
     h16* __restrict__ dx_drop = (h16*)jb.dx_drop;
-    const int n_part = jb.n_part, rows = jb.rows;
+    const int n_part = jb.n_part;
+    const int rows = jb.rows_dev ? min(jb.rows, *jb.rows_dev) : jb.rows;
+    const int32_t* __restrict__ drop_rows = jb.drop_rows;
     const int blk = (int)blockIdx.x - grp.start[j];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float g[NCH][8], dg[NCH][8], db[NCH][8];
@@ -185,12 +187,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp, int D
                 for (int e = 0; e < 8; ++e) dv[i][e] = rs * (dv[i][e] * g[i][e] - c1 - xv[i][e] * c2);
         }
         store_row<NCH>(dx + (size_t)row * D, D, lane, dv);
+        const uint64_t drow = (DROP && drop_rows) ? (uint64_t)drop_rows[row] : (uint64_t)row;
         if (DROP && dropj) {    // gradient w.r.t. the dropped Linear output that fed this LayerNorm: dx * mask / (1 - p)
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c = (lane + 64 * i) * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dv[i][e] *= mh_drop_mul(drop, (uint64_t)row * D + c + e);
+                for (int e = 0; e < 8; ++e) dv[i][e] *= mh_drop_mul(drop, drow * D + c + e);
             }
             store_row<NCH>(dx_drop + (size_t)row * D, D, lane, dv);
         }
@@ -277,7 +280,7 @@ extern "C" int mh_layernorm_fwd_grouped(const MhLnFwdJob* jobs, int n_jobs, int 
 
 extern "C" int mh_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* y_f32,
                                 float* mean, float* rstd, int rows, int D, float eps, mh_stream_t stream) {
-    MhLnFwdJob jb = {x, gamma, beta, y, y_f32, mean, rstd, rows, eps};
+    MhLnFwdJob jb = {x, gamma, beta, y, y_f32, mean, rstd, rows, eps, nullptr};
     return mh_layernorm_fwd_grouped(&jb, 1, D, stream);
 }
 
@@ -313,7 +316,8 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
                                 const float* rstd, const void* dx_add, void* dx, float* part, int n_part, int rows,
                                 int D, void* dx_drop, const uint32_t* rng, float drop_p, uint32_t drop_stream,
                                 mh_stream_t stream) {
-    MhLnBwdJob jb = {dy, x, gamma, mean, rstd, dx_add, dx, part, dx_drop, rng, n_part, rows, drop_p, drop_stream};
+    MhLnBwdJob jb = {dy, x, gamma, mean, rstd, dx_add, dx, part, dx_drop, rng, n_part, rows, drop_p, drop_stream,
+                     nullptr, nullptr};
     return mh_layernorm_bwd_grouped(&jb, 1, D, stream);
 }
 

@@ -118,10 +118,13 @@ class Segment:
             d.record(side)
             events[self.name] = d
 
-    def run_timed(self, stream: int, tag: str, out: list):
+    def run_timed(self, stream: int, tag: str, out: list, dyn_scale: float = 1.0):
         """Eager replay that brackets every launch tagged `tag` with events on the launch stream;
-        appends (start_event, end_event, work) to `out`."""
+        appends (start_event, end_event, work) to `out`.  `work` of a launch is (fixed, per-live-row part at the
+        maximum row count): dyn_scale = live rows / maximum rows of the packed text tower."""
         for fn, args, name, t, work, _ in self.calls:
+            if isinstance(work, tuple):
+                work = work[0] + work[1] * dyn_scale
             if fn is None:
                 if name == "py":
                     args()
@@ -156,7 +159,9 @@ class Plan:
         self.bwd: List[Segment] = []          # backward segments in execution order
         self.bucket_after: Dict[str, Tuple[int, int]] = {}   # segment name -> flat grad range complete after it
         self.n_launches = 0
-        self.gemm_flops = 0.0                 # algorithmic GEMM FLOPs of one step (fwd + dgrad + wgrad)
+        self.gemm_flops = 0.0                 # algorithmic GEMM FLOPs of one step (fwd + dgrad + wgrad), no row packed away
+        self.gemm_flops_dyn = 0.0             # the part of it that scales with the live rows of the packed text tower
+        self.packed = False
 
 
 class Engine:
@@ -170,6 +175,9 @@ class Engine:
         assert SH.dtype == self.T16
         self.lib = _lib.load(self.kind)
         self.gscale = cfg.stream_scale          # scale carried by the 16-bit gradient streams
+        # padding-free text tower (rows with attention_mask == 0 are never computed); MEMEHIP_PACK_TEXT=0 for A/B runs
+        import os
+        self.pack_text = bool(getattr(cfg, "pack_text", True)) and os.environ.get("MEMEHIP_PACK_TEXT", "1") != "0"
         self.plans: Dict[Tuple[int, int], Plan] = {}
 
     # ---- parameter / gradient views -----------------------------------------------------------------
@@ -217,10 +225,16 @@ class Engine:
             e.alpha = float(d.get("alpha", 1.0))
             if d.get("drop") is not None:
                 e.drop_rng, e.drop_p, e.drop_stream = d["drop"]
+                e.drop_rows = _ptr(d.get("drop_rows"))
+            e.rows_dev = _ptr(d.get("rows_dev"))
         plan.keep.append(arr)
-        flops = float(sum(2.0 * d["M"] * d["N"] * d["K"] for d in probs))
-        plan.gemm_flops += flops
-        seg.c("mh_gemm_bf16_grouped", arr, n, int(a_k), int(b_k), tag=f"gemm<{int(a_k)},{int(b_k)}>", work=flops, lane=lane)
+        fl = [2.0 * d["M"] * d["N"] * d["K"] for d in probs]
+        dyn = float(sum(x for x, d in zip(fl, probs) if d.get("rows_dev") is not None))    # scales with the live rows
+        fixed = float(sum(fl)) - dyn
+        plan.gemm_flops += fixed + dyn
+        plan.gemm_flops_dyn += dyn
+        seg.c("mh_gemm_bf16_grouped", arr, n, int(a_k), int(b_k), tag=f"gemm<{int(a_k)},{int(b_k)}>", work=(fixed, dyn),
+              lane=lane)
 
     @staticmethod
     def _fwd_prob(x, w, out, T, N, K, **kw):
@@ -231,10 +245,10 @@ class Engine:
         # out[T, K_in] = dy[T, N_out] @ w[N_out, K_in]
         return dict(A=dy, B=w, C=out, M=T, N=K_in, K=N_out, lda=N_out, ldb=K_in, ldc=K_in, **kw)
 
-    def _wgrad_prob(self, dy, x, dw, db, T, N_out, K_in):
+    def _wgrad_prob(self, dy, x, dw, db, T, N_out, K_in, **kw):
         # dw[N_out, K_in] = dy[T, N_out]^T @ x[T, K_in]   (dy carries the gradient-stream scale: alpha removes it)
         return dict(A=dy, B=x, C=dw, M=N_out, N=K_in, K=T, lda=N_out, ldb=K_in, ldc=K_in, rowsum=db,
-                    alpha=1.0 / self.gscale)
+                    alpha=1.0 / self.gscale, **kw)
 
     @staticmethod
     def _ln_groups(by_d):
@@ -243,9 +257,9 @@ class Engine:
             return [(D, [j]) for D, js in by_d.items() for j in js]
         return list(by_d.items())
 
-    def _ln_fwd_job(self, x, gname, bname, y, mean, rstd, rows, D, eps, y32=None):
+    def _ln_fwd_job(self, x, gname, bname, y, mean, rstd, rows, D, eps, y32=None, rows_dev=None):
         return dict(x=x, gamma=self.p(gname), beta=self.p(bname), y=y, y32=y32, mean=mean, rstd=rstd, rows=rows, D=D,
-                    eps=float(eps))
+                    eps=float(eps), rows_dev=rows_dev)
 
     def _ln_fwd(self, plan: Plan, seg: Segment, jobs: List[Optional[dict]]):
         """LayerNorms that sit at the same point of the lockstep schedule go out as ONE grouped launch per width."""
@@ -260,16 +274,19 @@ class Engine:
                 assert j["x"].numel() >= j["rows"] * D and j["y"].numel() >= j["rows"] * D
                 e.x, e.gamma, e.beta, e.y, e.y_f32 = _ptr(j["x"]), _ptr(j["gamma"]), _ptr(j["beta"]), _ptr(j["y"]), _ptr(j["y32"])
                 e.mean, e.rstd, e.rows, e.eps = _ptr(j["mean"]), _ptr(j["rstd"]), j["rows"], j["eps"]
+                e.rows_dev = _ptr(j["rows_dev"])
             plan.keep.append(arr)
             seg.c("mh_layernorm_fwd_grouped", arr, len(js), D)
 
-    def _ln_bwd_job(self, plan, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None, dx_drop=None, drop=None):
+    def _ln_bwd_job(self, plan, dy, x, gname, bname, mean, rstd, dx, rows, D, dx_add=None, dx_drop=None, drop=None,
+                    rows_dev=None, drop_rows=None):
         part = torch.empty((2, LN_PARTS, D), dtype=F32, device=self.dev)
         plan.buf[f"lnpart.{gname}"] = part
         plan._ln_jobs.setdefault(D, []).append((part, self.g(gname), self.g(bname)))
         rng, p_, sid = drop if (drop is not None and dx_drop is not None) else (None, 0.0, 0)
         return dict(dy=dy, x=x, gamma=self.p(gname), mean=mean, rstd=rstd, dx_add=dx_add, dx=dx, part=part,
-                    dx_drop=dx_drop if rng is not None else None, rng=rng, p=float(p_), sid=int(sid), rows=rows, D=D)
+                    dx_drop=dx_drop if rng is not None else None, rng=rng, p=float(p_), sid=int(sid), rows=rows, D=D,
+                    rows_dev=rows_dev, drop_rows=drop_rows if rng is not None else None)
 
     def _ln_bwd(self, plan: Plan, seg: Segment, jobs: List[Optional[dict]]):
         by_d: Dict[int, List[dict]] = {}
@@ -286,6 +303,7 @@ class Engine:
                 e.dy, e.x, e.gamma, e.mean, e.rstd = _ptr(j["dy"]), _ptr(j["x"]), _ptr(j["gamma"]), _ptr(j["mean"]), _ptr(j["rstd"])
                 e.dx_add, e.dx, e.part, e.dx_drop, e.rng = _ptr(j["dx_add"]), _ptr(j["dx"]), _ptr(j["part"]), _ptr(j["dx_drop"]), j["rng"]
                 e.n_part, e.rows, e.drop_p, e.drop_stream = LN_PARTS, j["rows"], j["p"], j["sid"]
+                e.rows_dev, e.drop_rows = _ptr(j["rows_dev"]), _ptr(j["drop_rows"])
             plan.keep.append(arr)
             seg.c("mh_layernorm_bwd_grouped", arr, len(js), D)
 
@@ -312,12 +330,12 @@ class Engine:
         and embedding-gradient rows of all W ranks (6 MB per rank) instead of all-reducing the dense 196-MB table."""
         cfg = self.cfg
         has_drop = (cfg.text.hidden_dropout > 0 or cfg.text.attention_dropout > 0 or cfg.head_dropout > 0)
-        key = (B, S, bool(training and has_drop), int(gather_world))
+        key = (B, S, bool(training and has_drop), int(gather_world), self.pack_text)
         if key not in self.plans:
-            self.plans[key] = self._build(B, S, key[2], key[3])
+            self.plans[key] = self._build(B, S, key[2], key[3], key[4])
         return self.plans[key]
 
-    def _build(self, B: int, S: int, dropout_on: bool = False, gather_world: int = 0) -> Plan:
+    def _build(self, B: int, S: int, dropout_on: bool = False, gather_world: int = 0, pack: bool = False) -> Plan:
         cfg, t, v = self.cfg, self.cfg.text, self.cfg.image
         if S > t.max_position:
             raise ValueError(f"sequence length {S} > max_position {t.max_position}")
@@ -362,15 +380,43 @@ class Engine:
         # ------------------------------------------------------------------ forward ------------------
         f = pl.fwd
         TXT, IMG = "bert.", "image_model."
-        # text embeddings
+        # text embeddings (dense [B*S] rows: the tables are indexed by position)
+        pool_index = 0 if cfg.pool == "cls" else S - 1
         pre0 = alloc("t.pre0", (Tt, Dt))
-        xt = [alloc("t.x0", (Tt, Dt))]
+        x0d = alloc("t.x0", (Tt, Dt))
         m0, r0 = alloc("t.m0", (Tt,), F32), alloc("t.r0", (Tt,), F32)
         type0 = self.p(TXT + "embeddings.token_type_embeddings.weight")[:Dt] if t.type_vocab > 0 else None
         f.c("mh_bert_embed_fwd", _ptr(ids), _ptr(self.p(TXT + "embeddings.word_embeddings.weight")),
             _ptr(self.p(TXT + "embeddings.position_embeddings.weight")), _ptr(type0),
             _ptr(self.p(TXT + "embeddings.LayerNorm.weight")), _ptr(self.p(TXT + "embeddings.LayerNorm.bias")),
-            _ptr(pre0), _ptr(xt[0]), _ptr(m0), _ptr(r0), B, S, Dt, t.vocab_size, float(t.ln_eps), *site_args(p_h, 1))
+            _ptr(pre0), _ptr(x0d), _ptr(m0), _ptr(r0), B, S, Dt, t.vocab_size, float(t.ln_eps), *site_args(p_h, 1))
+        # padding-free text tower: the encoder layers see only the rows that matter (attention_mask != 0, plus the
+        # pooled position), packed back to back.  The row count lives on the device (n_rows): every text launch below
+        # is sized for B*S rows and clamps itself at run time, so one plan / one hipGraph serves every batch.
+        pl.packed = pack
+        if pack:
+            I32 = torch.int32
+            cu, row_map = alloc("pk.cu", (B + 1,), I32, zero=True), alloc("pk.row_map", (Tt,), I32, zero=True)
+            inv_map, pmask = alloc("pk.inv_map", (Tt,), I32, zero=True), alloc("pk.pmask", (Tt,), I64, zero=True)
+            pool_rows, n_rows = alloc("pk.pool_rows", (B,), I32, zero=True), alloc("pk.n_rows", (1,), I32, zero=True)
+            f.c("mh_pack_plan", _ptr(mask), B, S, pool_index, _ptr(cu), _ptr(row_map), _ptr(inv_map), _ptr(pmask),
+                _ptr(pool_rows), _ptr(n_rows))
+            xt = [alloc("t.x0p", (Tt, Dt))]
+            f.c("mh_pack_rows", _ptr(x0d), _ptr(row_map), _ptr(n_rows), _ptr(xt[0]), Tt, Dt)
+            tp = dict(rows_dev=n_rows)                  # every text GEMM problem / LayerNorm job
+            tpd = dict(rows_dev=n_rows, drop_rows=row_map)
+        else:
+            cu = row_map = inv_map = pmask = pool_rows = n_rows = None
+            xt = [x0d]
+            tp, tpd = {}, {}
+
+        def text_attn_fwd(seg_, a_, sid):
+            if pack:
+                seg_.c("mh_attn_fwd_packed", _ptr(a_["qkv"]), _ptr(pmask), _ptr(a_["ctx"]), _ptr(a_["lse"]), _ptr(cu),
+                       _ptr(row_map), B, S, Ht, *site_args(p_a, sid))
+            else:
+                seg_.c("mh_attn_fwd", _ptr(a_["qkv"]), _ptr(mask), _ptr(a_["ctx"]), _ptr(a_["lse"]), B, S, Ht,
+                       *site_args(p_a, sid))
         # image embeddings
         patches = alloc("i.patches", (B * Np, Kp))
         proj = alloc("i.proj", (B * Np, Di))
@@ -425,7 +471,7 @@ class Engine:
             pr = []
             if has_t:
                 pr.append(self._fwd_prob(xt[l], self.w(LT + "attention.self.query.weight", 3), a["qkv"], Tt, 3 * Dt, Dt,
-                                         bias=self.p(LT + "attention.self.query.bias", 3)))
+                                         bias=self.p(LT + "attention.self.query.bias", 3), **tp))
             if has_i:
                 pr.append(self._fwd_prob(b_["u"], self.w(LI + "attention.attention.query.weight", 3), b_["qkv"], Ti,
                                          3 * Di, Di, bias=self.p(LI + "attention.attention.query.bias", 3)))
@@ -434,29 +480,28 @@ class Engine:
             if has_i:
                 f.c("mh_attn_fwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(b_["lse"]), B, Nt, Hi, None, 0.0, 0, lane=2)
             if has_t:
-                f.c("mh_attn_fwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(a["lse"]), B, S, Ht,
-                    *site_args(p_a, 16 * (l + 1) + 1))
+                text_attn_fwd(f, a, 16 * (l + 1) + 1)
             f.join()
             # attention output projection + residual
             pr = []
             if has_t:
                 pr.append(self._fwd_prob(a["ctx"], self.w(LT + "attention.output.dense.weight"), a["a"], Tt, Dt, Dt,
                                          bias=self.p(LT + "attention.output.dense.bias"), residual=xt[l],
-                                         drop=site(p_h, 16 * (l + 1) + 2)))
+                                         drop=site(p_h, 16 * (l + 1) + 2), **tpd))
             if has_i:
                 pr.append(self._fwd_prob(b_["ctx"], self.w(LI + "attention.output.dense.weight"), b_["xp"], Ti, Di, Di,
                                          bias=self.p(LI + "attention.output.dense.bias"), residual=xi[l]))
             self._gemm(pl, f, pr, False, False)
             self._ln_fwd(pl, f, [
                 self._ln_fwd_job(a["a"], LT + "attention.output.LayerNorm.weight", LT + "attention.output.LayerNorm.bias",
-                                 a["y"], a["m1"], a["r1"], Tt, Dt, t.ln_eps) if has_t else None,
+                                 a["y"], a["m1"], a["r1"], Tt, Dt, t.ln_eps, **tp) if has_t else None,
                 self._ln_fwd_job(b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["w"], b_["m2"],
                                  b_["r2"], Ti, Di, v.ln_eps) if has_i else None])
             # FFN up + GELU (pre-activation kept for the backward)
             pr = []
             if has_t:
                 pr.append(self._fwd_prob(a["y"], self.w(LT + "intermediate.dense.weight"), a["g"], Tt, It, Dt,
-                                         bias=self.p(LT + "intermediate.dense.bias"), aux=a["h"], gelu=True))
+                                         bias=self.p(LT + "intermediate.dense.bias"), aux=a["h"], gelu=True, **tp))
             if has_i:
                 pr.append(self._fwd_prob(b_["w"], self.w(LI + "intermediate.dense.weight"), b_["g"], Ti, Ii, Di,
                                          bias=self.p(LI + "intermediate.dense.bias"), aux=b_["h"], gelu=True))
@@ -466,7 +511,7 @@ class Engine:
             if has_t:
                 pr.append(self._fwd_prob(a["g"], self.w(LT + "output.dense.weight"), a["f"], Tt, Dt, It,
                                          bias=self.p(LT + "output.dense.bias"), residual=a["y"],
-                                         drop=site(p_h, 16 * (l + 1) + 3)))
+                                         drop=site(p_h, 16 * (l + 1) + 3), **tpd))
             if has_i:
                 pr.append(self._fwd_prob(b_["g"], self.w(LI + "output.dense.weight"), xi[l + 1], Ti, Di, Ii,
                                          bias=self.p(LI + "output.dense.bias"), residual=b_["xp"]))
@@ -474,11 +519,10 @@ class Engine:
             # the text LayerNorm closing this layer + the image LayerNorm opening the next (or the final ViT one)
             self._ln_fwd(pl, f, [
                 self._ln_fwd_job(a["f"], LT + "output.LayerNorm.weight", LT + "output.LayerNorm.bias", xt[l + 1], a["m2"],
-                                 a["r2"], Tt, Dt, t.ln_eps, y32=xt_last32 if l == Lt - 1 else None) if has_t else None,
+                                 a["r2"], Tt, Dt, t.ln_eps, y32=xt_last32 if l == Lt - 1 else None, **tp) if has_t else None,
                 img_ln1(l + 1) if has_i else None])
 
         # head
-        pool_index = 0 if cfg.pool == "cls" else S - 1
         hp, hg = MhHeadParams(), MhHeadGrads()
         for fld, nm in (("Wt", "bert_fc.weight"), ("bt", "bert_fc.bias"), ("Wi", "image_fc.weight"),
                         ("bi", "image_fc.bias"), ("Wf", "fusion_fc.weight"), ("bf_", "fusion_fc.bias"),
@@ -490,7 +534,7 @@ class Engine:
         feat, fused = alloc("h.feat", (B, 2 * P_), F32), alloc("h.fused", (B, P_), F32)
         logits = alloc("logits", (B, Cn), F32)
         f.c("mh_head_fwd", C.byref(hp), _ptr(xt_last32), _ptr(xf32), pool_index, _ptr(pooled), _ptr(feat), _ptr(fused),
-            _ptr(logits), B, S, Nt, Dt, Di, P_, Cn, *site_args(p_head, 7))
+            _ptr(logits), B, S, Nt, Dt, Di, P_, Cn, *site_args(p_head, 7), _ptr(pool_rows))
 
         # loss
         loss = alloc("loss", (1,), F32, zero=True)
@@ -518,7 +562,7 @@ class Engine:
         s.py(dXf.zero_)
         s.c("mh_head_bwd", C.byref(hp), C.byref(hg), _ptr(dlogits), _ptr(pooled), _ptr(feat), _ptr(fused), _ptr(dfeat),
             _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale),
-            *site_args(p_head, 7))
+            *site_args(p_head, 7), _ptr(pool_rows))
         # backward temporaries, one set per layer parity
         T_ = [dict(dh=alloc(f"t.dh{i}", (Tt, It)), da=alloc(f"t.da{i}", (Tt, Dt)),
                    dqkv=alloc(f"t.dqkv{i}", (Tt, 3 * Dt)),
@@ -543,7 +587,7 @@ class Engine:
             LT_ = f"{TXT}encoder.layer.{l}."
             return self._ln_bwd_job(pl, dXt[ct_], tl[l]["f"], LT_ + "output.LayerNorm.weight", LT_ + "output.LayerNorm.bias",
                                     tl[l]["m2"], tl[l]["r2"], DF_[l % 3]["df"], Tt, Dt,
-                                    dx_drop=DF_[l % 3]["dfm"] if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 3))
+                                    dx_drop=DF_[l % 3]["dfm"] if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 3), **tpd)
 
         nl = max(Lt, Li)
         self._ln_bwd(pl, s, [
@@ -567,27 +611,27 @@ class Engine:
             # d gelu_in = (d_out @ W2) * gelu'(h)
             pr = []
             if has_t:
-                pr.append(self._dgrad_prob(t_dfm, self.w(LT + "output.dense.weight"), t_dh, Tt, Dt, It, mul=a["h"]))
+                pr.append(self._dgrad_prob(t_dfm, self.w(LT + "output.dense.weight"), t_dh, Tt, Dt, It, mul=a["h"], **tp))
             if has_i:
                 pr.append(self._dgrad_prob(dXi[ci], self.w(LI + "output.dense.weight"), i_dh, Ti, Di, Ii, mul=b_["h"]))
             self._gemm(pl, s, pr, False, True)
             # through W1 (text adds the residual branch df)
             pr = []
             if has_t:
-                pr.append(self._dgrad_prob(t_dh, self.w(LT + "intermediate.dense.weight"), t_dy, Tt, It, Dt, residual=t_df))
+                pr.append(self._dgrad_prob(t_dh, self.w(LT + "intermediate.dense.weight"), t_dy, Tt, It, Dt, residual=t_df, **tp))
             if has_i:
                 pr.append(self._dgrad_prob(i_dh, self.w(LI + "intermediate.dense.weight"), i_dw, Ti, Ii, Di))
             self._gemm(pl, s, pr, False, True)
             self._ln_bwd(pl, s, [
                 self._ln_bwd_job(pl, t_dy, a["a"], LT + "attention.output.LayerNorm.weight",
                                  LT + "attention.output.LayerNorm.bias", a["m1"], a["r1"], t_da, Tt, Dt,
-                                 dx_drop=t_dam if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 2)) if has_t else None,
+                                 dx_drop=t_dam if p_h > 0 else None, drop=site(p_h, 16 * (l + 1) + 2), **tpd) if has_t else None,
                 self._ln_bwd_job(pl, i_dw, b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["m2"],
                                  b_["r2"], i_dxp, Ti, Di, dx_add=dXi[ci]) if has_i else None])
             # through the attention output projection
             pr = []
             if has_t:
-                pr.append(self._dgrad_prob(t_dam, self.w(LT + "attention.output.dense.weight"), t_dctx, Tt, Dt, Dt))
+                pr.append(self._dgrad_prob(t_dam, self.w(LT + "attention.output.dense.weight"), t_dctx, Tt, Dt, Dt, **tp))
             if has_i:
                 pr.append(self._dgrad_prob(i_dxp, self.w(LI + "attention.output.dense.weight"), i_dctx, Ti, Di, Di))
             self._gemm(pl, s, pr, False, True)
@@ -595,7 +639,10 @@ class Engine:
             if has_i:
                 s.c("mh_attn_bwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(i_dctx), _ptr(b_["lse"]), _ptr(i_delta),
                     _ptr(i_dqkv), B, Nt, Hi, None, 0.0, 0, lane=2)
-            if has_t:
+            if has_t and pack:
+                s.c("mh_attn_bwd_packed", _ptr(a["qkv"]), _ptr(pmask), _ptr(a["ctx"]), _ptr(t_dctx), _ptr(a["lse"]),
+                    _ptr(t_delta), _ptr(t_dqkv), _ptr(cu), _ptr(row_map), B, S, Ht, *site_args(p_a, 16 * (l + 1) + 1))
+            elif has_t:
                 s.c("mh_attn_bwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(t_dctx), _ptr(a["lse"]), _ptr(t_delta),
                     _ptr(t_dqkv), B, S, Ht, *site_args(p_a, 16 * (l + 1) + 1))
             s.join()
@@ -603,7 +650,7 @@ class Engine:
             pr = []
             if has_t:
                 pr.append(self._dgrad_prob(t_dqkv, self.w(LT + "attention.self.query.weight", 3), dXt[(ct + 1) % 3], Tt, 3 * Dt, Dt,
-                                           residual=t_da))
+                                           residual=t_da, **tp))
             if has_i:
                 pr.append(self._dgrad_prob(i_dqkv, self.w(LI + "attention.attention.query.weight", 3), i_du, Ti, 3 * Di, Di))
             self._gemm(pl, s, pr, False, True)
@@ -613,9 +660,13 @@ class Engine:
             if l >= 1:
                 t_job = text_ln2_bwd(l - 1, ct_next)
             else:
+                d_emb = dXt[ct_next]
+                if pack:        # back to dense [B*S] rows (zeros at the dropped positions) for the embedding tables
+                    d_emb = alloc("t.dX_dense", (Tt, Dt))
+                    s.c("mh_unpack_rows", _ptr(dXt[ct_next]), _ptr(inv_map), _ptr(d_emb), Tt, Dt)
                 if p_h > 0:     # gradient w.r.t. the dropped embedding output -> w.r.t. the LayerNorm output
-                    s.c("mh_dropout_apply", _ptr(dXt[ct_next]), Tt * Dt, rng_t.data_ptr(), float(p_h), 1)
-                t_job = self._ln_bwd_job(pl, dXt[ct_next], pre0, TXT + "embeddings.LayerNorm.weight",
+                    s.c("mh_dropout_apply", _ptr(d_emb), Tt * Dt, rng_t.data_ptr(), float(p_h), 1)
+                t_job = self._ln_bwd_job(pl, d_emb, pre0, TXT + "embeddings.LayerNorm.weight",
                                          TXT + "embeddings.LayerNorm.bias", m0, r0, t_dpre, Tt, Dt)
             self._ln_bwd(pl, s, [
                 t_job,
@@ -626,10 +677,10 @@ class Engine:
             # take 254 us, the two 432-tile launches back to back 215 us.
             if has_t:
                 self._gemm(pl, s, [
-                    self._wgrad_prob(t_dfm, a["g"], self.g(LT + "output.dense.weight"), self.g(LT + "output.dense.bias"), Tt, Dt, It),
-                    self._wgrad_prob(t_dh, a["y"], self.g(LT + "intermediate.dense.weight"), self.g(LT + "intermediate.dense.bias"), Tt, It, Dt),
-                    self._wgrad_prob(t_dam, a["ctx"], self.g(LT + "attention.output.dense.weight"), self.g(LT + "attention.output.dense.bias"), Tt, Dt, Dt),
-                    self._wgrad_prob(t_dqkv, xt[l], self.g(LT + "attention.self.query.weight", 3), self.g(LT + "attention.self.query.bias", 3), Tt, 3 * Dt, Dt)],
+                    self._wgrad_prob(t_dfm, a["g"], self.g(LT + "output.dense.weight"), self.g(LT + "output.dense.bias"), Tt, Dt, It, **tp),
+                    self._wgrad_prob(t_dh, a["y"], self.g(LT + "intermediate.dense.weight"), self.g(LT + "intermediate.dense.bias"), Tt, It, Dt, **tp),
+                    self._wgrad_prob(t_dam, a["ctx"], self.g(LT + "attention.output.dense.weight"), self.g(LT + "attention.output.dense.bias"), Tt, Dt, Dt, **tp),
+                    self._wgrad_prob(t_dqkv, xt[l], self.g(LT + "attention.self.query.weight", 3), self.g(LT + "attention.self.query.bias", 3), Tt, 3 * Dt, Dt, **tp)],
                     True, True, lane=1)
             if has_i:
                 self._gemm(pl, s, [

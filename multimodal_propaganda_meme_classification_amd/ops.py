@@ -58,11 +58,12 @@ class Gemm:
     """One problem of a grouped launch (see MhGemmProblem in include/memehip.h)."""
 
     __slots__ = ("A", "B", "C", "bias", "residual", "aux", "mul", "rowsum", "M", "N", "K", "lda", "ldb", "ldc",
-                 "flags", "alpha", "drop")
+                 "flags", "alpha", "drop", "rows_dev", "drop_rows")
 
     def __init__(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, residual=None, aux=None, mul=None,
-                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None):
+                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None, rows_dev=None, drop_rows=None):
         self.alpha = alpha
+        self.rows_dev, self.drop_rows = rows_dev, drop_rows     # packed token rows: device int32 [1] / int32 [M]
         self.drop = drop            # (rng u32[4] device tensor, p, site id) or None
         self.A, self.B, self.C = A, B, C
         self.bias, self.residual, self.aux, self.mul, self.rowsum = bias, residual, aux, mul, rowsum
@@ -131,6 +132,11 @@ def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
         a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.flags, a.alpha = g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.flags, g.alpha
         if g.drop is not None:
             a.drop_rng, a.drop_p, a.drop_stream = _rng(g.drop[0]), float(g.drop[1]), int(g.drop[2])
+            a.drop_rows = _p(g.drop_rows)
+        if g.rows_dev is not None:
+            if not (g.rows_dev.is_cuda and g.rows_dev.dtype == torch.int32):
+                raise TypeError("rows_dev must be a device int32 tensor")
+            a.rows_dev = _p(g.rows_dev)
     check(_L(problems[0].A).mh_gemm_bf16_grouped(arr, n, int(a_kmajor), int(b_kmajor), _stream()), "mh_gemm_bf16_grouped")
 
 
@@ -229,6 +235,63 @@ def attn_fwd(qkv, key_mask, B, S, H, out=None, lse=None, drop=None):
     return out, lse
 
 
+def pack_plan(mask, pool_index: int):
+    """Row bookkeeping of the padding-free text tower (mh_pack_plan). Returns a dict of device tensors."""
+    _chk(mask, I64, "mask")
+    B, S = mask.shape
+    dev = mask.device
+    I32 = torch.int32
+    out = dict(cu=torch.empty(B + 1, dtype=I32, device=dev), row_map=torch.empty(B * S, dtype=I32, device=dev),
+               inv_map=torch.empty(B * S, dtype=I32, device=dev), pmask=torch.empty(B * S, dtype=I64, device=dev),
+               pool_rows=torch.empty(B, dtype=I32, device=dev), n_rows=torch.empty(1, dtype=I32, device=dev))
+    check(_lib.load().mh_pack_plan(_p(mask), B, S, int(pool_index), _p(out["cu"]), _p(out["row_map"]), _p(out["inv_map"]),
+                                   _p(out["pmask"]), _p(out["pool_rows"]), _p(out["n_rows"]), _stream()), "mh_pack_plan")
+    return out
+
+
+def pack_rows(src, plan, D):
+    _chk(src, BF16, "src")
+    max_rows = plan["row_map"].numel()
+    assert src.numel() == max_rows * D
+    dst = torch.zeros_like(src)
+    check(_L(src).mh_pack_rows(_p(src), _p(plan["row_map"]), _p(plan["n_rows"]), _p(dst), max_rows, D, _stream()),
+          "mh_pack_rows")
+    return dst
+
+
+def unpack_rows(src, plan, D):
+    _chk(src, BF16, "src")
+    max_rows = plan["inv_map"].numel()
+    assert src.numel() == max_rows * D
+    dst = torch.empty_like(src)
+    check(_L(src).mh_unpack_rows(_p(src), _p(plan["inv_map"]), _p(dst), max_rows, D, _stream()), "mh_unpack_rows")
+    return dst
+
+
+def attn_fwd_packed(qkv, plan, B, S, H, drop=None):
+    """qkv: packed rows [B*S (max), 3*H*64]; sequences delimited by plan['cu']."""
+    _chk(qkv, BF16, "qkv")
+    assert qkv.numel() == B * S * 3 * H * 64
+    out = torch.zeros((B * S, H * 64), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.zeros((B, H, S), dtype=F32, device=qkv.device)
+    r, p, sid = _drop(drop)
+    check(_L(qkv).mh_attn_fwd_packed(_p(qkv), _p(plan["pmask"]), _p(out), _p(lse), _p(plan["cu"]), _p(plan["row_map"]),
+                                     B, S, H, r, p, sid, _stream()), "mh_attn_fwd_packed")
+    return out, lse
+
+
+def attn_bwd_packed(qkv, plan, out, dout, lse, B, S, H, drop=None):
+    _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse")
+    assert qkv.numel() == B * S * 3 * H * 64 and out.numel() == B * S * H * 64 == dout.numel()
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty((B, H, S), dtype=F32, device=qkv.device)
+    r, p, sid = _drop(drop)
+    check(_L(qkv).mh_attn_bwd_packed(_p(qkv), _p(plan["pmask"]), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv),
+                                     _p(plan["cu"]), _p(plan["row_map"]), B, S, H, r, p, sid, _stream()),
+          "mh_attn_bwd_packed")
+    return dqkv
+
+
 def attn_bwd(qkv, key_mask, out, dout, lse, B, S, H, dqkv=None, delta=None, drop=None):
     _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse")
     assert qkv.numel() == B * S * 3 * H * 64 and out.numel() == B * S * H * 64 == dout.numel()
@@ -307,18 +370,19 @@ def _head_struct(cls, tensors):
 
 
 def head_fwd(params, text_hidden, image_hidden, pool_index, pooled, feat, fused, logits, B, S, Nt, Dt, Di, P, Cn,
-             drop=None):
+             drop=None, text_rows=None):
     hp = _head_struct(MhHeadParams, params)
     _chk(text_hidden, F32, "text_hidden"), _chk(image_hidden, F32, "image_hidden")
     assert text_hidden.numel() >= B * S * Dt and image_hidden.numel() >= B * Nt * Di
     assert pooled.numel() >= B * (Dt + Di) and feat.numel() >= B * 2 * P and fused.numel() >= B * P and logits.numel() >= B * Cn
     assert params[0].numel() == P * Dt and params[2].numel() == P * Di and params[4].numel() == P * 2 * P and params[6].numel() == Cn * P
     check(_lib.load().mh_head_fwd(C.byref(hp), _p(text_hidden), _p(image_hidden), pool_index, _p(pooled), _p(feat),
-                                  _p(fused), _p(logits), B, S, Nt, Dt, Di, P, Cn, *_drop(drop), _stream()), "mh_head_fwd")
+                                  _p(fused), _p(logits), B, S, Nt, Dt, Di, P, Cn, *_drop(drop), _p(text_rows), _stream()),
+          "mh_head_fwd")
 
 
 def head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, d_text_hidden, d_image_hidden, pool_index,
-             B, S, Nt, Dt, Di, P, Cn, out_scale: float = 1.0, drop=None):
+             B, S, Nt, Dt, Di, P, Cn, out_scale: float = 1.0, drop=None, text_rows=None):
     hp = _head_struct(MhHeadParams, params)
     hg = _head_struct(MhHeadGrads, grads)
     for a, b in zip(params, grads):
@@ -328,7 +392,7 @@ def head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, d_text_
     assert dfeat.numel() >= B * 2 * P and dfused.numel() >= B * P and dlogits.numel() >= B * Cn
     check(_L(d_text_hidden).mh_head_bwd(C.byref(hp), C.byref(hg), _p(dlogits), _p(pooled), _p(feat), _p(fused), _p(dfeat),
                                         _p(dfused), _p(d_text_hidden), _p(d_image_hidden), pool_index, B, S, Nt, Dt, Di, P,
-                                        Cn, float(out_scale), *_drop(drop), _stream()), "mh_head_bwd")
+                                        Cn, float(out_scale), *_drop(drop), _p(text_rows), _stream()), "mh_head_bwd")
 
 
 def ce_fwd_bwd(logits, labels, loss, dlogits, n_correct=None, grad_scale: float = 1.0):

@@ -43,10 +43,10 @@ def test_binding_covers_header(lib):
 
 
 def test_struct_layout_matches_header(lib):
-    # 8 pointers + 7 int32 + float + pointer + float + uint32 = 112 bytes; a drift here would corrupt every grouped launch
-    assert ctypes.sizeof(lib.MhGemmProblem) == 112
+    # 8 pointers + 7 int32 + float + pointer + float + uint32 + 2 pointers = 128 bytes; a drift here would corrupt every grouped launch
+    assert ctypes.sizeof(lib.MhGemmProblem) == 128
     assert ctypes.sizeof(lib.MhColsumJob) == 24
-    assert ctypes.sizeof(lib.MhLnFwdJob) == 64 and ctypes.sizeof(lib.MhLnBwdJob) == 96
+    assert ctypes.sizeof(lib.MhLnFwdJob) == 72 and ctypes.sizeof(lib.MhLnBwdJob) == 112
     assert ctypes.sizeof(lib.MhHeadParams) == 64 == ctypes.sizeof(lib.MhHeadGrads)
 
 

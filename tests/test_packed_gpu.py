@@ -1,0 +1,217 @@
+"""Padding-free text tower (mh_pack_plan / packed attention / device-side live row counts).
+
+BertModel computes every padded position and then ignores it; the HIP path never computes rows with
+attention_mask == 0 (reference call: self.bert(text, attention_mask=mask), Multimodal_example_task2C.txt:175).
+Checked here:
+  * the row bookkeeping is bit-exact against a numpy restatement (prefix masks, masks with holes, all ones,
+    one-token sequences, both pooling positions);
+  * pack -> unpack round trips;
+  * packed attention == dense masked attention on the kept rows;
+  * a GEMM launch clamped by the device-side row count touches exactly the live rows (fwd) / contracts over them (wgrad);
+  * the whole step, packed vs dense plan of the same model: bit-identical logits, matching gradients, with and
+    without dropout, for masks with holes and for the organizers' last-position pooling;
+  * packed step vs the CPU oracle on a mask with holes (the oracle applies the additive mask the way the
+    reference's BertModel does).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import multimodal_propaganda_meme_classification_amd as m
+    return m
+
+
+def _oracle():
+    from oracle import meme_oracle as O
+    return O
+
+
+def _masks(B, S, kind, seed):
+    g = np.random.default_rng(seed)
+    if kind == "prefix":
+        lens = g.integers(1, S + 1, size=B)
+        m = (np.arange(S)[None] < lens[:, None])
+    elif kind == "holes":
+        m = g.random((B, S)) < 0.6
+        m[:, 0] = True
+    elif kind == "ones":
+        m = np.ones((B, S), bool)
+    elif kind == "single":
+        m = np.zeros((B, S), bool)
+        m[:, 0] = True
+    else:
+        raise ValueError(kind)
+    return m.astype(np.int64)
+
+
+def _plan_numpy(mask, pool):
+    B, S = mask.shape
+    keep = (mask != 0) | (np.arange(S)[None] == pool)
+    cu = np.zeros(B + 1, np.int32)
+    cu[1:] = np.cumsum(keep.sum(1))
+    n = int(cu[-1])
+    row_map = np.full(B * S, -1, np.int32)
+    inv_map = np.full(B * S, -1, np.int32)
+    pmask = np.zeros(B * S, np.int64)
+    dense = np.flatnonzero(keep.reshape(-1))
+    row_map[:n] = dense
+    inv_map[dense] = np.arange(n, dtype=np.int32)
+    pmask[:n] = (mask.reshape(-1)[dense] != 0)
+    pool_rows = inv_map[np.arange(B) * S + pool]
+    return dict(cu=cu, row_map=row_map, inv_map=inv_map, pmask=pmask, pool_rows=pool_rows, n_rows=np.array([n], np.int32))
+
+
+@pytest.mark.parametrize("kind", ["prefix", "holes", "ones", "single"])
+@pytest.mark.parametrize("B,S", [(1, 8), (5, 16), (32, 128), (70, 200), (1024, 64)])
+def test_pack_plan_bit_exact(pkg, kind, B, S):
+    from multimodal_propaganda_meme_classification_amd import ops
+    for pool in (0, S - 1):
+        mask = _masks(B, S, kind, seed=B * 1000 + S + pool)
+        got = ops.pack_plan(torch.from_numpy(mask).cuda(), pool)
+        want = _plan_numpy(mask, pool)
+        for k, v in want.items():
+            assert np.array_equal(got[k].cpu().numpy(), v), (kind, B, S, pool, k)
+
+
+def test_pack_unpack_round_trip(pkg):
+    from multimodal_propaganda_meme_classification_amd import ops
+    B, S, D = 7, 40, 256
+    mask = _masks(B, S, "holes", 3)
+    plan = ops.pack_plan(torch.from_numpy(mask).cuda(), 0)
+    x = torch.randn((B * S, D), device="cuda").to(torch.bfloat16)
+    packed = ops.pack_rows(x, plan, D)
+    n = int(plan["n_rows"])
+    rm = plan["row_map"][:n].long()
+    assert torch.equal(packed[:n], x[rm])
+    back = ops.unpack_rows(packed, plan, D)
+    keep = torch.from_numpy(mask.reshape(-1) != 0).cuda()
+    assert torch.equal(back[keep], x[keep])
+    assert float(back[~keep].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind,B,S,H", [("prefix", 6, 128, 4), ("holes", 4, 64, 2), ("prefix", 3, 200, 2), ("prefix", 2, 300, 2)])
+def test_packed_attention_equals_dense_on_kept_rows(pkg, dtype, kind, B, S, H):
+    from multimodal_propaganda_meme_classification_amd import ops
+    mask_np = _masks(B, S, kind, 11 + S)
+    mask = torch.from_numpy(mask_np).cuda()
+    plan = ops.pack_plan(mask, 0)
+    n = int(plan["n_rows"])
+    rm = plan["row_map"][:n].long()
+    qkv = (torch.randn((B * S, 3 * H * 64), device="cuda") * 0.7).to(dtype)
+    dout = (torch.randn((B * S, H * 64), device="cuda") * 0.1).to(dtype)
+    keep = (mask.reshape(-1) != 0)
+    dout = dout * keep[:, None].to(dtype)          # nothing downstream reads the padded rows: their gradient is zero
+    out_d, lse_d = ops.attn_fwd(qkv, mask, B, S, H)
+    dqkv_d = ops.attn_bwd(qkv, mask, out_d, dout, lse_d, B, S, H)
+    qkv_p, dout_p = ops.pack_rows(qkv, plan, 3 * H * 64), ops.pack_rows(dout, plan, H * 64)
+    out_p, lse_p = ops.attn_fwd_packed(qkv_p, plan, B, S, H)
+    dqkv_p = ops.attn_bwd_packed(qkv_p, plan, out_p, dout_p, lse_p, B, S, H)
+    torch.cuda.synchronize()
+    if kind == "prefix":      # same keys in the same 32-key sub-tiles: the same arithmetic
+        assert torch.equal(out_p[:n], out_d[rm])
+    else:                     # holes: the kept keys are compacted, the online softmax visits them in other sub-tiles
+        assert float((out_p[:n].float() - out_d[rm].float()).abs().max()) <= 8e-3 * float(out_d.float().abs().max())
+    got, want = dqkv_p[:n].float(), dqkv_d[rm].float()
+    # dQ rows are computed identically; dK / dV sum the same non-zero terms (padded queries contribute exact zeros)
+    rel = 2e-3 if kind == "prefix" else 1e-2      # holes: other sub-tile order, a 16-bit ulp of the stored gradient
+    assert float((got - want).abs().max()) <= rel * float(want.abs().max()) + 1e-6
+
+
+def test_gemm_clamps_to_live_rows(pkg):
+    from multimodal_propaganda_meme_classification_amd import ops
+    T, K, N, live = 512, 256, 384, 137
+    n_dev = torch.tensor([live], dtype=torch.int32, device="cuda")
+    x = torch.randn((T, K), device="cuda").to(torch.bfloat16)
+    w = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
+    y = torch.full((T, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_grouped([ops.Gemm(x, w, y, T, N, K, K, K, N, rows_dev=n_dev)], False, False)
+    ref = (x.float() @ w.float().t())
+    assert float((y[:live].float() - ref[:live]).abs().max()) < 0.05
+    assert float((y[live:].float() - 7.0).abs().max()) == 0.0            # rows past the live count are never written
+    # wgrad: the contraction stops at the live rows
+    dy = (torch.randn((T, N), device="cuda") * 0.1).to(torch.bfloat16)
+    dw = torch.zeros((N, K), device="cuda", dtype=torch.float32)
+    db = torch.zeros((N,), device="cuda", dtype=torch.float32)
+    ops.gemm_grouped([ops.Gemm(dy, x, dw, N, K, T, N, K, K, rowsum=db, rows_dev=n_dev)], True, True)
+    ref_dw = dy[:live].float().t() @ x[:live].float()
+    assert float((dw - ref_dw).abs().max()) <= 2e-2 * float(ref_dw.abs().max())
+    assert float((db - dy[:live].float().sum(0)).abs().max()) <= 2e-2 * float(db.abs().max())
+
+
+def _tiny(pkg, O, pool, seed=21, dropout=False):
+    cfg = O.tiny_config(pool)
+    params = O.init_params(cfg, seed)
+    mc = pkg.ModelConfig.from_dict(cfg.to_dict())
+    if dropout:
+        mc.with_reference_dropout()
+    model = pkg.MultimodalClassifier.from_config(mc, init=False)
+    model.load_state_dict(params)
+    model.to("cuda")
+    return model, params, cfg
+
+
+@pytest.mark.parametrize("pool", ["cls", "last"])
+@pytest.mark.parametrize("kind", ["prefix", "holes"])
+@pytest.mark.parametrize("dropout", [False, True])
+def test_packed_step_equals_dense_step(pkg, pool, kind, dropout):
+    O = _oracle()
+    B, S = 6, 32
+    text, image, _, labels = O.synthetic_batch(O.tiny_config(pool), B, S, seed=77)
+    mask = torch.from_numpy(_masks(B, S, kind, 5))
+    if pool == "cls":
+        mask[:, 0] = 1
+    text = text * mask
+    dev = [t.cuda() for t in (text, image, mask, labels)]
+    outs = []
+    for pack in (True, False):
+        model, _, _ = _tiny(pkg, O, pool, dropout=dropout)
+        model.manual_seed(1234)
+        eng = model._get_engine()
+        eng.pack_text = pack
+        model.train()
+        loss, _, logits = model.forward_backward(*dev)
+        torch.cuda.synchronize()
+        assert model._get_engine().plan(B, S, True).packed == pack
+        outs.append((float(loss), logits.detach().float().cpu().clone(), model.flat_grads.detach().float().cpu().clone()))
+    (l1, z1, g1), (l2, z2, g2) = outs
+    if kind == "prefix":
+        assert torch.equal(z1, z2), (z1, z2)      # every kept row goes through the same arithmetic
+        assert l1 == l2
+    else:                                         # compacted keys: another online-softmax order (a few 16-bit ulps)
+        assert float((z1 - z2).abs().max()) <= 2e-3, (z1, z2)
+        assert abs(l1 - l2) <= 2e-3
+    # weight gradients sum the same non-zero terms in a different K-tile partition
+    rel = 2e-3 if kind == "prefix" else 2e-2
+    assert float((g1 - g2).norm()) <= rel * float(g2.norm())
+    assert float((g1 - g2).abs().max()) <= 2.5 * rel * float(g2.abs().max())
+
+
+def test_packed_step_with_mask_holes_matches_oracle(pkg):
+    O = _oracle()
+    B, S = 5, 24
+    cfg = O.tiny_config("cls")
+    text, image, _, labels = O.synthetic_batch(cfg, B, S, seed=31)
+    mask = torch.from_numpy(_masks(B, S, "holes", 9))
+    text = text * mask
+    model, params, _ = _tiny(pkg, O, "cls", seed=13)
+    assert model._get_engine().pack_text
+    model.train()
+    loss, _, logits = model.forward_backward(text.cuda(), image.cuda(), mask.cuda(), labels.cuda())
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(params, text, image, mask, labels, cfg)
+    tol = 3e-3
+    assert float((logits.detach().float().cpu() - ref_logits).abs().max()) <= tol
+    assert abs(float(loss) - float(ref_loss)) <= tol
+    for name, p in model.named_parameters():
+        ref = ref_grads[name]
+        got = p.grad.detach().float().cpu()
+        if ".key.bias" in name:
+            continue
+        assert float((got - ref).norm()) <= 3e-2 * float(ref.norm()) + 2e-6, name
