@@ -205,7 +205,9 @@ int mh_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, c
                       mh_stream_t stream);
 int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre /*bf16 [T][D]*/, float* dword /*[V][D]*/,
                       float* dpos /*[P][D]*/, float* dtype0 /*[D] or NULL*/, int B, int S, int D,
-                      int vocab, int64_t pad_id, float scale, mh_stream_t stream);
+                      int vocab, int64_t pad_id, float scale,
+                      uint8_t* row_live /*[V] or NULL: set to 1 for every table row that receives a gradient*/,
+                      mh_stream_t stream);
 /* Dropout helpers.  mh_dropout_apply: x[i] *= mask(i)/(1-p) in place (16-bit), e.g. the gradient arriving at a
  * dropped activation.  mh_dropout_mask_u8: the 0/1 mask a site would use for element indices 0..n-1 (tests). */
 int mh_dropout_apply(void* x, int64_t n, const uint32_t* rng, float p, uint32_t stream_id, mh_stream_t stream);
@@ -283,6 +285,10 @@ int mh_focal_fwd_bwd(const float* logits, int ld, const float* targets /*f32 [B]
  *     m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
  *     (L2 wd folds into g', decoupled wd scales p first); also refreshes the bf16 shadow copy
  *     p_bf16[i] for i < n_shadow (the GEMM operands).  n, n_shadow multiples of 4.
+ *   mh_adam_step_rows: the same update over a [rows][D] table, skipping rows whose row_live byte is 0.  A row of
+ *     the word-embedding table that has never received a gradient has g = m = v = 0, for which the dense update is
+ *     the identity (with weight_decay == 0): skipping it is bit-identical to torch.optim.Adam and saves 28 B/element
+ *     of HBM traffic on the 49 M-element table (a batch touches at most B*S of its 64 000 rows).
  *   mh_cast_f32_bf16: shadow refresh on its own (after load_state_dict).
  * ------------------------------------------------------------------------------------------ */
 int mh_sumsq_f32(const float* g, int64_t n, float* workspace /*>=1024 f32*/, float* out,
@@ -290,6 +296,11 @@ int mh_sumsq_f32(const float* g, int64_t n, float* workspace /*>=1024 f32*/, flo
 int mh_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t n,
                  int64_t n_shadow, const float* hyper /*device f32[8]*/, int decoupled,
                  const float* gnorm_sq /*device or NULL*/, float max_norm, mh_stream_t stream);
+int mh_adam_step_rows(float* p, float* m, float* v, const float* g,
+                      uint8_t* row_live /*[rows] optimizer state: 1 = this row's m / v may be non-zero*/,
+                      const uint8_t* row_touched /*[rows] or NULL: rows that have received a gradient (mh_bert_embed_bwd);
+                      OR-ed into row_live*/, int rows, int D, const float* hyper /*device f32[8]*/, int decoupled,
+                      const float* gnorm_sq, float max_norm, mh_stream_t stream);
 int mh_cast_f32_bf16(const float* src, void* dst, int64_t n, mh_stream_t stream);
 int mh_cast_bf16_f32(const void* src, float* dst, int64_t n, mh_stream_t stream);
 

@@ -80,7 +80,8 @@ template <int NCH>
 __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const int64_t* __restrict__ ids,
                                                                   const h16* __restrict__ d_pre,
                                                                   float* __restrict__ dword, int T, int D,
-                                                                  int vocab, int64_t pad_id, float scale) {
+                                                                  int vocab, int64_t pad_id, float scale,
+                                                                  uint8_t* __restrict__ row_live) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const int64_t*
         }
     }
     float* out = dword + (size_t)id * D;
+    if (row_live && lane == 0) row_live[id] = 1;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
@@ -288,13 +290,14 @@ extern "C" int mh_bert_embed_fwd(const int64_t* ids, const float* word, const fl
 }
 
 extern "C" int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre, float* dword, float* dpos, float* dtype0,
-                                 int B, int S, int D, int vocab, int64_t pad_id, float scale, mh_stream_t stream) {
+                                 int B, int S, int D, int vocab, int64_t pad_id, float scale, uint8_t* row_live,
+                                 mh_stream_t stream) {
     if (!ids || !d_pre || !dword || !dpos) return MH_EINVAL;
     if (B < 1 || S < 1 || D < 8 || (D % 8) || D > 4096 || vocab < 1) return MH_ESHAPE;
     const int T = B * S;
     hipStream_t s = (hipStream_t)stream;
     NCH_DISPATCH(bert_embed_bwd_word_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, (const h16*)d_pre, dword, T,
-                 D, vocab, pad_id, scale);
+                 D, vocab, pad_id, scale, row_live);
     NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const h16*)d_pre, dpos, B, S, D, scale);
     if (dtype0)
         hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dpos, dtype0, S, D);

@@ -79,6 +79,53 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// the same update over a [rows][D] table, one wave per row, rows without a gradient history skipped
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                        float* __restrict__ v, const float* __restrict__ g,
+                                                        uint8_t* __restrict__ row_live,
+                                                        const uint8_t* __restrict__ row_touched, int rows, int D,
+                                                        const float* __restrict__ hyper, int decoupled,
+                                                        const float* __restrict__ gnorm_sq, float max_norm) {
+    const int lane = threadIdx.x & 63;
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+    const float inv_bc1 = hyper[5], inv_sqrt_bc2 = hyper[6];
+    float gs = hyper[7];
+    if (gnorm_sq) {
+        const float nrm = sqrtf(gnorm_sq[0]) * fabsf(gs);
+        gs *= fminf(1.0f, max_norm / (nrm + 1e-6f));
+    }
+    const float step = lr * inv_bc1;
+    const float decay = decoupled ? 1.0f - lr * wd : 1.0f;
+    const float l2 = decoupled ? 0.f : wd;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        bool live = row_live[row] != 0;
+        if (!live && row_touched && row_touched[row]) {
+            live = true;
+            if (lane == 0) row_live[row] = 1;
+        }
+        if (!live) continue;
+        const size_t base = (size_t)row * D;
+        for (int c = lane * 4; c < D; c += 256) {
+            f32x4 pv = *(const f32x4*)(p + base + c);
+            f32x4 mv = *(const f32x4*)(m + base + c);
+            f32x4 vv = *(const f32x4*)(v + base + c);
+            const f32x4 gv = *(const f32x4*)(g + base + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float w = pv[e] * decay;
+                const float gg = gv[e] * gs + l2 * w;
+                const float mm = mv[e] * b1 + (1.0f - b1) * gg;
+                const float v2 = vv[e] * b2 + (1.0f - b2) * gg * gg;
+                w -= step * (mm / (sqrtf(v2) * inv_sqrt_bc2 + eps));
+                pv[e] = w; mv[e] = mm; vv[e] = v2;
+            }
+            *(f32x4*)(p + base + c) = pv;
+            *(f32x4*)(m + base + c) = mv;
+            *(f32x4*)(v + base + c) = vv;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, h16* __restrict__ dst,
                                                             int64_t n) {
     const int64_t n8 = n >> 3;
@@ -129,6 +176,18 @@ extern "C" int mh_adam_step(float* p, float* m, float* v, const float* g, void* 
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
                        (h16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm);
+    return mh_launch_status();
+}
+
+extern "C" int mh_adam_step_rows(float* p, float* m, float* v, const float* g, uint8_t* row_live,
+                                 const uint8_t* row_touched, int rows, int D, const float* hyper, int decoupled,
+                                 const float* gnorm_sq, float max_norm, mh_stream_t stream) {
+    if (!p || !m || !v || !g || !row_live || !hyper) return MH_EINVAL;
+    if (rows < 1 || D < 4 || (D & 3)) return MH_ESHAPE;
+    if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
+    const int blocks = (rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096;
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, row_live, row_touched,
+                       rows, D, hyper, decoupled, gnorm_sq, max_norm);
     return mh_launch_status();
 }
 

@@ -373,7 +373,7 @@ class Adam(torch.optim.Optimizer):
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, decoupled_weight_decay: bool = False, max_grad_norm: Optional[float] = None,
-                 model: Optional[MultimodalClassifier] = None):
+                 model: Optional[MultimodalClassifier] = None, skip_untouched_embedding_rows: bool = True):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.decoupled = decoupled_weight_decay
@@ -382,6 +382,9 @@ class Adam(torch.optim.Optimizer):
         self._flat = None
         self._step = 0
         self.grad_scale = 1.0          # DDP sets 1/world_size (all-reduce sums)
+        # word-embedding rows that never received a gradient have g = m = v = 0: the dense Adam update is the identity
+        # on them (weight_decay == 0), so they are skipped -- same numbers as torch.optim.Adam, ~1.4 GB less HBM traffic
+        self.skip_untouched_rows = bool(skip_untouched_embedding_rows)
 
     def _bind(self):
         if self._flat is not None:
@@ -473,6 +476,21 @@ class Adam(torch.optim.Optimizer):
                             nxt.append((sb, y))
                 pieces = nxt
             runs += [(gi, x, y) for x, y in pieces if y > x]
+        table = self._word_table()
+        if table is not None:       # carve the word-embedding table out of its run: it goes through the row-skipping kernel
+            ta, tb, V, D, touched = table
+            nxt = []
+            for gi, a, b in runs:
+                if a <= ta and tb <= b and float(self.param_groups[gi]["weight_decay"]) == 0.0:
+                    if a < ta:
+                        nxt.append((gi, a, ta))
+                    ops.adam_step_rows(f["P"][ta:tb], f["M"][ta:tb], f["V"][ta:tb], f["G"][ta:tb], f["row_live"], touched, V, D,
+                                       f["hyper"][gi], self.decoupled, nrm, float(self.max_grad_norm or 0.0))
+                    if tb < b:
+                        nxt.append((gi, tb, b))
+                else:
+                    nxt.append((gi, a, b))
+            runs = nxt
         for gi, a, b in runs:
             sh_n = max(0, min(b, n_shadow) - a)            # part of this run that has a 16-bit shadow
             shadow = model.flat_shadow[a:a + sh_n] if (model is not None and sh_n > 0) else None
@@ -480,6 +498,24 @@ class Adam(torch.optim.Optimizer):
                           nrm, float(self.max_grad_norm or 0.0))
         if model is not None:
             model._shadow_stale = False
+
+    def _word_table(self):
+        """(start, end, rows, D, touched-row bytes) of the word-embedding table in the flat buffer, or None."""
+        model = self._model
+        if not self.skip_untouched_rows or model is None:
+            return None
+        f = self._flat
+        if "row_live" not in f:
+            sp = model.layout.spec["bert.embeddings.word_embeddings.weight"]
+            V, D = sp.shape
+            if sp.offset + V * D > model.layout.n_shadow and sp.numel == V * D:
+                f["table"] = (sp.offset, sp.offset + V * D, V, D)
+                f["row_live"] = torch.zeros(V, dtype=torch.uint8, device=f["P"].device)
+            else:
+                f["table"], f["row_live"] = None, None
+        if f["table"] is None:
+            return None
+        return f["table"] + (model._get_engine().word_row_live,)
 
     def state_dict(self):
         self._bind()

@@ -320,13 +320,13 @@ def bert_embed_fwd(ids, word, pos, type0, gamma, beta, eps, pre, y, mean, rstd, 
                                         D, V, float(eps), *_drop(drop), _stream()), "mh_bert_embed_fwd")
 
 
-def bert_embed_bwd(ids, d_pre, dword, dpos, dtype0, pad_id: int, scale: float = 1.0):
+def bert_embed_bwd(ids, d_pre, dword, dpos, dtype0, pad_id: int, scale: float = 1.0, row_live=None):
     _chk(ids, I64, "ids"), _chk(d_pre, BF16, "d_pre"), _chk(dword, F32, "dword"), _chk(dpos, F32, "dpos")
     B, S = ids.shape
     V, D = dword.shape
     assert d_pre.numel() >= B * S * D and dpos.shape[0] >= S
     check(_L(d_pre).mh_bert_embed_bwd(_p(ids), _p(d_pre), _p(dword), _p(dpos), _p(dtype0), B, S, D, V, int(pad_id),
-                                      float(scale), _stream()), "mh_bert_embed_bwd")
+                                      float(scale), _p(row_live), _stream()), "mh_bert_embed_bwd")
 
 
 def zero_rows(ids, table):
@@ -430,6 +430,18 @@ def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=Non
         assert shadow.numel() >= n_shadow
     check(_L(shadow if shadow is not None else p).mh_adam_step(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, n_shadow if shadow is not None else 0,
                                    _p(hyper), int(decoupled), _p(gnorm_sq), float(max_norm), _stream()), "mh_adam_step")
+
+
+def adam_step_rows(p, m, v, g, row_live, row_touched, rows, D, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0):
+    """mh_adam_step_rows: Adam over a [rows][D] table, rows with no gradient history skipped (row_live |= row_touched)."""
+    for nm, t in (("p", p), ("m", m), ("v", v), ("g", g), ("hyper", hyper)):
+        _chk(t, F32, nm)
+    n = rows * D
+    assert p.numel() == n and m.numel() == n and v.numel() == n and g.numel() == n and hyper.numel() >= 8
+    if not (row_live.is_cuda and row_live.dtype == torch.uint8 and row_live.numel() >= rows):
+        raise TypeError("row_live must be a device uint8 tensor with one byte per row")
+    check(_lib.load().mh_adam_step_rows(_p(p), _p(m), _p(v), _p(g), _p(row_live), _p(row_touched), rows, D, _p(hyper), int(decoupled),
+                                        _p(gnorm_sq), float(max_norm), _stream()), "mh_adam_step_rows")
 
 
 def cast_f32_bf16(src, dst):

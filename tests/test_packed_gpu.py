@@ -215,3 +215,29 @@ def test_packed_step_with_mask_holes_matches_oracle(pkg):
         if ".key.bias" in name:
             continue
         assert float((got - ref).norm()) <= 3e-2 * float(ref.norm()) + 2e-6, name
+
+
+def test_adam_skipping_untouched_embedding_rows_is_bit_identical(pkg):
+    """torch.optim.Adam (dense, Multimodal_example_task2C.txt:249) leaves a parameter with g = m = v = 0 unchanged;
+    the fused Adam skips word-embedding rows that never received a gradient.  Same numbers, bit for bit, over steps
+    whose batches touch different rows (rows touched once keep being updated while their moments decay)."""
+    O = _oracle()
+    cfg = O.tiny_config("cls")
+    models, opts = [], []
+    for skip in (True, False):
+        model, _, _ = _tiny(pkg, O, "cls", seed=3)
+        models.append(model)
+        opts.append(pkg.Adam(model.parameters(), lr=1e-3, model=model, skip_untouched_embedding_rows=skip))
+    for step in range(4):
+        text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=100 + step)
+        dev = [t.cuda() for t in (text, image, mask, labels)]
+        for model, opt in zip(models, opts):
+            model.train()
+            model.forward_backward(*dev)
+            opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(models[0].flat_params, models[1].flat_params), step
+        assert torch.equal(opts[0]._flat["M"], opts[1]._flat["M"]) and torch.equal(opts[0]._flat["V"], opts[1]._flat["V"])
+    live = opts[0]._flat["row_live"]
+    assert 0 < int(live.sum()) < live.numel()          # some rows updated, most of the table skipped
+    assert opts[1]._flat.get("row_live") is None or int(opts[1]._flat["row_live"].sum()) == 0
