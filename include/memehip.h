@@ -166,6 +166,21 @@ int mh_attn_bwd_packed(const void* qkv, const int64_t* key_mask, const void* out
                        const float* lse, float* delta, void* dqkv, const int32_t* cu, const int32_t* row_map, int B,
                        int S, int H, const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream);
 
+/* Grouped form: up to MH_ATTN_MAX_GROUP problems per call.  The two towers' attention of a layer pair
+ * (ViT: 129..224 tokens, no dropout; text: <= 128 tokens) goes out as ONE launch per kernel: the short text heads
+ * fill the occupancy holes of the ViT launch.  Other combinations run back to back.  The backward fields are
+ * ignored by mh_attn_fwd_grouped; cu / row_map select the packed form per problem. */
+#define MH_ATTN_MAX_GROUP 2
+typedef struct MhAttnProblem {
+    const void* qkv; const int64_t* key_mask; void* out; float* lse;
+    const void* dout; float* delta; void* dqkv;
+    const int32_t* cu; const int32_t* row_map;
+    const uint32_t* rng; float drop_p; uint32_t drop_stream;
+    int32_t B, S, H; int32_t reserved;
+} MhAttnProblem;
+int mh_attn_fwd_grouped(const MhAttnProblem* problems /*host*/, int n, mh_stream_t stream);
+int mh_attn_bwd_grouped(const MhAttnProblem* problems /*host*/, int n, mh_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Padding-free text tower.  BertModel computes every padded position and then ignores it (the keys are masked,
  * the pooling reads one row): rows with attention_mask == 0 influence neither the logits nor any gradient.

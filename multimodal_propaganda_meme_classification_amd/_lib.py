@@ -20,6 +20,7 @@ MH_GEMM_OUT_F32 = 2
 MH_GEMM_ACCUM = 4
 MH_COLSUM_MAX_JOBS = 64
 MH_LN_MAX_JOBS = 4
+MH_ATTN_MAX_GROUP = 2
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -49,6 +50,12 @@ class MhLnBwdJob(C.Structure):
                 ("rows_dev", c_void_p), ("drop_rows", c_void_p)]
 
 
+class MhAttnProblem(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("qkv", "key_mask", "out", "lse", "dout", "delta", "dqkv", "cu", "row_map", "rng")] + \
+               [("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class MhHeadParams(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("Wt", "bt", "Wi", "bi", "Wf", "bf_", "Wo", "bo")]
 
@@ -68,6 +75,8 @@ _PROTOS = {
     "mh_colsum_partials_f32": [C.POINTER(MhColsumJob), c_int, c_int, c_int, c_float, c_void_p],
     "mh_attn_fwd": [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_attn_bwd": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
+    "mh_attn_fwd_grouped": [C.POINTER(MhAttnProblem), c_int, c_void_p],
+    "mh_attn_bwd_grouped": [C.POINTER(MhAttnProblem), c_int, c_void_p],
     "mh_attn_fwd_packed": [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_attn_bwd_packed": [c_void_p] * 9 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_pack_plan": [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p],

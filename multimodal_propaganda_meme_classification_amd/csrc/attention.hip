@@ -107,29 +107,50 @@ MH_DEV void store_rows_from_T(h16* __restrict__ base, size_t pitch, int row0, in
         }
 }
 
+// one attention problem (a tower's heads); the backward fields are unused by the forward
+struct AttnArgs {
+    const h16* qkv;
+    const int64_t* key_mask;
+    h16* out;            // forward output / backward input
+    float* lse;
+    const h16* dout;
+    float* delta;
+    h16* dqkv;
+    int B, S, H;
+    const uint32_t* rng;
+    float drop_p;
+    uint32_t drop_stream;
+    const int32_t* cu;
+    const int32_t* row_map;
+};
+
 // ----------------------------------------------------------------------------------------------
 // forward.  NT_RES > 0: the head's whole K and V (NT_RES tiles of 64 keys) are staged into LDS once,
 // then every wave sweeps its 32-query tiles with no further barrier or global K/V load (S <= 64*NT_RES).
 // NT_RES == 0: streaming fallback for long sequences (one K/V tile resident at a time).
 // ----------------------------------------------------------------------------------------------
+// bx / gx / bh: this workgroup's index and count along the query split, and its (batch, head) index
 template <int NW, int NT_RES, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict__ qkv,
-                                                           const int64_t* __restrict__ key_mask,
-                                                           h16* __restrict__ out, float* __restrict__ lse,
-                                                           int B, int S, int H, const uint32_t* __restrict__ rng,
-                                                           float drop_p, uint32_t drop_stream,
-                                                           const int32_t* __restrict__ cu,
-                                                           const int32_t* __restrict__ row_map) {
+MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const int bh, char* smem) {
+    const h16* __restrict__ qkv = A.qkv;
+    const int64_t* __restrict__ key_mask = A.key_mask;
+    h16* __restrict__ out = A.out;
+    float* __restrict__ lse = A.lse;
+    const int S = A.S, H = A.H;
+    const uint32_t* __restrict__ rng = A.rng;
+    const float drop_p = A.drop_p;
+    const uint32_t drop_stream = A.drop_stream;
+    const int32_t* __restrict__ cu = A.cu;
+    const int32_t* __restrict__ row_map = A.row_map;
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const DropCtx drop = mh_drop_ctx(DROP ? rng : nullptr, drop_p, drop_stream);   // dropout on the probabilities
     char* k_img = smem;
     char* v_img = smem + NTL * IMG;
     float* kbias = (float*)(smem + 2 * NTL * IMG);
     int* kany = (int*)(kbias + NTL * TILE);   // per 32-key sub-tile: any key to attend to?
 
-    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+    const int b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
     // packed token stream: this sequence's rows are cu[b] .. cu[b+1]-1 (Sb of them); dense: b*S .. b*S+S-1
@@ -163,8 +184,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
         __syncthreads();
     }
 
-    for (int qt = blockIdx.x * NW + wave; (NT_RES > 0) ? (qt * 32 < Sb) : (qt == (int)blockIdx.x * NW + wave);
-         qt += NW * gridDim.x) {
+    for (int qt = bx * NW + wave; (NT_RES > 0) ? (qt * 32 < Sb) : (qt == bx * NW + wave); qt += NW * gx) {
         const int wq0 = qt * 32;
         const bool active = wq0 < Sb;
         h16x8 qf[4];
@@ -252,19 +272,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const h16* __restrict
 // backward, dQ:  one wave = 32 queries at a time, sweep key tiles (resident K/V when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
 template <int NW, int NT_RES, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restrict__ qkv,
-                                                              const int64_t* __restrict__ key_mask,
-                                                              const h16* __restrict__ out,
-                                                              const h16* __restrict__ dout,
-                                                              const float* __restrict__ lse,
-                                                              float* __restrict__ delta,
-                                                              h16* __restrict__ dqkv, int B, int S, int H,
-                                                              const uint32_t* __restrict__ rng, float drop_p,
-                                                              uint32_t drop_stream, const int32_t* __restrict__ cu,
-                                                              const int32_t* __restrict__ row_map) {
+MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, const int bh, char* smem) {
+    const h16* __restrict__ qkv = A.qkv;
+    const int64_t* __restrict__ key_mask = A.key_mask;
+    const h16* __restrict__ out = A.out;
+    const h16* __restrict__ dout = A.dout;
+    const float* __restrict__ lse = A.lse;
+    float* __restrict__ delta = A.delta;
+    h16* __restrict__ dqkv = A.dqkv;
+    const int S = A.S, H = A.H;
+    const uint32_t* __restrict__ rng = A.rng;
+    const float drop_p = A.drop_p;
+    const uint32_t drop_stream = A.drop_stream;
+    const int32_t* __restrict__ cu = A.cu;
+    const int32_t* __restrict__ row_map = A.row_map;
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const DropCtx drop = mh_drop_ctx(DROP ? rng : nullptr, drop_p, drop_stream);
     char* k_img = smem;
     char* kt_img = smem + NTL * IMG;
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
     float* kbias = (float*)(smem + 3 * NTL * IMG);
     int* kany = (int*)(kbias + NTL * TILE);
 
-    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+    const int b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
     // packed token stream: this sequence's rows are cu[b] .. cu[b+1]-1 (Sb of them); dense: b*S .. b*S+S-1
@@ -307,8 +330,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
         __syncthreads();
     }
 
-    for (int qt = blockIdx.x * NW + wave; (NT_RES > 0) ? (qt * 32 < Sb) : (qt == (int)blockIdx.x * NW + wave);
-         qt += NW * gridDim.x) {
+    for (int qt = bx * NW + wave; (NT_RES > 0) ? (qt * 32 < Sb) : (qt == bx * NW + wave); qt += NW * gx) {
         const int wq0 = qt * 32;
         const bool active = wq0 < Sb;
         const int q = wq0 + (lane & 31);
@@ -393,18 +415,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const h16* __restr
 // backward, dK / dV:  one wave = 32 keys at a time, sweep query tiles (resident Q/dO when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
 template <int NW, int NT_RES, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __restrict__ qkv,
-                                                               const int64_t* __restrict__ key_mask,
-                                                               const h16* __restrict__ dout,
-                                                               const float* __restrict__ lse,
-                                                               const float* __restrict__ delta,
-                                                               h16* __restrict__ dqkv, int B, int S, int H,
-                                                               const uint32_t* __restrict__ rng, float drop_p,
-                                                               uint32_t drop_stream, const int32_t* __restrict__ cu,
-                                                               const int32_t* __restrict__ row_map) {
+MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, const int bh, char* smem) {
+    const h16* __restrict__ qkv = A.qkv;
+    const int64_t* __restrict__ key_mask = A.key_mask;
+    const h16* __restrict__ dout = A.dout;
+    const float* __restrict__ lse = A.lse;
+    const float* __restrict__ delta = A.delta;
+    h16* __restrict__ dqkv = A.dqkv;
+    const int S = A.S, H = A.H;
+    const uint32_t* __restrict__ rng = A.rng;
+    const float drop_p = A.drop_p;
+    const uint32_t drop_stream = A.drop_stream;
+    const int32_t* __restrict__ cu = A.cu;
+    const int32_t* __restrict__ row_map = A.row_map;
     constexpr int NT = NW * 64;
     constexpr int NTL = NT_RES > 0 ? NT_RES : 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const DropCtx drop = mh_drop_ctx(DROP ? rng : nullptr, drop_p, drop_stream);
     char* q_img = smem;
     char* qt_img = smem + NTL * IMG;
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
     float* lse_t = (float*)(smem + 4 * NTL * IMG);
     float* dl_t = lse_t + NTL * TILE;
 
-    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+    const int b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const size_t pitch = (size_t)3 * H * HD;
     // packed token stream: this sequence's rows are cu[b] .. cu[b+1]-1 (Sb of them); dense: b*S .. b*S+S-1
@@ -443,8 +468,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
         __syncthreads();
     }
 
-    for (int kt = blockIdx.x * NW + wave; (NT_RES > 0) ? (kt * 32 < Sb) : (kt == (int)blockIdx.x * NW + wave);
-         kt += NW * gridDim.x) {
+    for (int kt = bx * NW + wave; (NT_RES > 0) ? (kt * 32 < Sb) : (kt == bx * NW + wave); kt += NW * gx) {
         const int wk0 = kt * 32;
         const bool active = wk0 < Sb;
         const int key = wk0 + (lane & 31);
@@ -525,6 +549,58 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const h16* __rest
     }
 }
 
+
+// ---- kernels: one problem per launch, or two problems (the two towers) in one launch ---------------------
+template <int NW, int NT_RES, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_fwd_body<NW, NT_RES, DROP>(A, blockIdx.x, gridDim.x, blockIdx.y, smem);
+}
+template <int NW, int NT_RES, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_bwd_dq_body<NW, NT_RES, DROP>(A, blockIdx.x, gridDim.x, blockIdx.y, smem);
+}
+template <int NW, int NT_RES, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_bwd_dkv_body<NW, NT_RES, DROP>(A, blockIdx.x, gridDim.x, blockIdx.y, smem);
+}
+// Dual launch for the lockstep towers: workgroups [0, nA) run problem A (ViT, 129..224 tokens: one 7-wave workgroup
+// per head), workgroups [nA, ..) run problem B (text, <= 128 tokens, 4 waves: waves 4-6 of the 448-thread workgroup
+// retire at once, the hardware barrier only counts live waves).  The text heads are short latency chains that fit in
+// the occupancy holes of the ViT launch instead of paying their own launch + drain.
+template <int RES_A, bool DROP_B>
+__global__ __launch_bounds__(448) void attn_fwd_dual_kernel(const AttnArgs A, const AttnArgs Bp, const int nA) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.y < nA) {
+        attn_fwd_body<7, RES_A, false>(A, 0, 1, blockIdx.y, smem);
+    } else {
+        if (threadIdx.x >= 256) return;
+        attn_fwd_body<4, 2, DROP_B>(Bp, 0, 1, blockIdx.y - nA, smem);
+    }
+}
+template <bool DROP_B>
+__global__ __launch_bounds__(448) void attn_bwd_dq_dual_kernel(const AttnArgs A, const AttnArgs Bp, const int nA) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.y < nA) {
+        attn_bwd_dq_body<7, 0, false>(A, 0, 1, blockIdx.y, smem);
+    } else {
+        if (threadIdx.x >= 256) return;
+        attn_bwd_dq_body<4, 2, DROP_B>(Bp, 0, 1, blockIdx.y - nA, smem);
+    }
+}
+template <bool DROP_B>
+__global__ __launch_bounds__(448) void attn_bwd_dkv_dual_kernel(const AttnArgs A, const AttnArgs Bp, const int nA) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.y < nA) {
+        attn_bwd_dkv_body<7, 0, false>(A, 0, 1, blockIdx.y, smem);
+    } else {
+        if (threadIdx.x >= 256) return;
+        attn_bwd_dkv_body<4, 2, DROP_B>(Bp, 0, 1, blockIdx.y - nA, smem);
+    }
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------
 // resident when S <= 256 (NT_RES = 2 for S <= 128, else 4); the 32-row tiles of a head are dealt to
 // `split` workgroups of 4 waves (split chosen so that every wave has work and the grid fills 256 CUs)
@@ -565,102 +641,204 @@ int split_for(int S) {
 
 }  // namespace
 
-#define ATTN_LAUNCH(KERN, NW_, NT_, GRID, LDS, ...)                                                         \
+#define ATTN_LAUNCH(KERN, NW_, NT_, GRID, LDS, ARGS)                                                      \
     do {                                                                                                 \
         if (dr) {                                                                                        \
             static bool once_t = (set_lds(KERN<NW_, NT_, true>, LDS), true);                             \
             (void)once_t;                                                                                \
-            hipLaunchKernelGGL((KERN<NW_, NT_, true>), GRID, dim3(NW_ * 64), LDS, s, __VA_ARGS__);       \
+            hipLaunchKernelGGL((KERN<NW_, NT_, true>), GRID, dim3(NW_ * 64), LDS, s, ARGS);              \
         } else {                                                                                         \
             static bool once_f = (set_lds(KERN<NW_, NT_, false>, LDS), true);                            \
             (void)once_f;                                                                                \
-            hipLaunchKernelGGL((KERN<NW_, NT_, false>), GRID, dim3(NW_ * 64), LDS, s, __VA_ARGS__);      \
+            hipLaunchKernelGGL((KERN<NW_, NT_, false>), GRID, dim3(NW_ * 64), LDS, s, ARGS);             \
+        }                                                                                                \
+    } while (0)
+#define ATTN_LAUNCH_DUAL(KERN, LDS, GRID, A_, B_, NA_)                                                   \
+    do {                                                                                                 \
+        if (dr) {                                                                                        \
+            static bool once_t = (set_lds(KERN<true>, LDS), true);                                       \
+            (void)once_t;                                                                                \
+            hipLaunchKernelGGL((KERN<true>), GRID, dim3(448), LDS, s, A_, B_, NA_);                      \
+        } else {                                                                                         \
+            static bool once_f = (set_lds(KERN<false>, LDS), true);                                      \
+            (void)once_f;                                                                                \
+            hipLaunchKernelGGL((KERN<false>), GRID, dim3(448), LDS, s, A_, B_, NA_);                     \
         }                                                                                                \
     } while (0)
 
-static int attn_fwd_impl(const void* qkv, const int64_t* key_mask, void* out, float* lse, const int32_t* cu,
-                         const int32_t* row_map, int B, int S, int H, const uint32_t* rng, float drop_p,
-                         uint32_t drop_stream, mh_stream_t stream) {
-    if (!qkv || !out || !lse) return MH_EINVAL;
-    if (B < 1 || S < 1 || H < 1 || drop_p < 0.f || drop_p >= 1.f) return MH_ESHAPE;
-    hipStream_t s = (hipStream_t)stream;
-    const h16* q = (const h16*)qkv;
-    const bool dr = rng && drop_p > 0.f;
-    if (S <= 128) {
-        constexpr int L = 2 * 2 * IMG + 2 * TILE * 4 + 64;
-        ATTN_LAUNCH(attn_fwd_kernel, 4, 2, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-    } else if (S <= 224 && fwd_seven_waves()) {
-        constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
-        ATTN_LAUNCH(attn_fwd_kernel, 7, 4, dim3(1, B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-    } else if (S <= 256) {
-        constexpr int L = 2 * 4 * IMG + 4 * TILE * 4 + 64;
-        ATTN_LAUNCH(attn_fwd_kernel, 4, 4, dim3(split_for(S), B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream, cu, row_map);
+namespace {
+
+int check_problem(const MhAttnProblem& p, bool bwd) {
+    if (!p.qkv || !p.out || !p.lse) return MH_EINVAL;
+    if (bwd && (!p.dout || !p.delta || !p.dqkv)) return MH_EINVAL;
+    if (p.B < 1 || p.S < 1 || p.H < 1 || p.drop_p < 0.f || p.drop_p >= 1.f) return MH_ESHAPE;
+    return MH_OK;
+}
+AttnArgs to_args(const MhAttnProblem& p) {
+    AttnArgs a;
+    a.qkv = (const h16*)p.qkv;
+    a.key_mask = p.key_mask;
+    a.out = (h16*)p.out;
+    a.lse = p.lse;
+    a.dout = (const h16*)p.dout;
+    a.delta = p.delta;
+    a.dqkv = (h16*)p.dqkv;
+    a.B = p.B; a.S = p.S; a.H = p.H;
+    a.rng = p.rng; a.drop_p = p.drop_p; a.drop_stream = p.drop_stream;
+    a.cu = p.cu; a.row_map = p.row_map;
+    return a;
+}
+bool has_drop(const MhAttnProblem& p) { return p.rng && p.drop_p > 0.f; }
+
+// LDS bytes: forward <NW, NT_RES>, backward dQ (L1) / dK,dV (L2)
+constexpr int lds_fwd(int nt) { return 2 * (nt > 0 ? nt : 1) * IMG + (nt > 0 ? nt : 1) * TILE * 4 + 64; }
+constexpr int lds_dq(int nt) { return 3 * (nt > 0 ? nt : 1) * IMG + (nt > 0 ? nt : 1) * TILE * 4 + 64; }
+constexpr int lds_dkv(int nt) { return 4 * (nt > 0 ? nt : 1) * IMG + 2 * (nt > 0 ? nt : 1) * TILE * 4; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+void launch_fwd(const MhAttnProblem& p, hipStream_t s) {
+    const AttnArgs a = to_args(p);
+    const bool dr = has_drop(p);
+    const int S = p.S, BH = p.B * p.H;
+    if (S <= 128) ATTN_LAUNCH(attn_fwd_kernel, 4, 2, dim3(split_for(S), BH), lds_fwd(2), a);
+    else if (S <= 224 && fwd_seven_waves()) ATTN_LAUNCH(attn_fwd_kernel, 7, 4, dim3(1, BH), lds_fwd(4), a);
+    else if (S <= 256) ATTN_LAUNCH(attn_fwd_kernel, 4, 4, dim3(split_for(S), BH), lds_fwd(4), a);
+    else ATTN_LAUNCH(attn_fwd_kernel, 4, 0, dim3((S + 127) / 128, BH), lds_fwd(0), a);
+}
+
+void launch_bwd(const MhAttnProblem& p, hipStream_t s) {
+    const AttnArgs a = to_args(p);
+    const bool dr = has_drop(p);
+    const int S = p.S, BH = p.B * p.H;
+    const int rmax = bwd_resident_max();
+    if (S <= 128 && S <= rmax) {
+        const dim3 grid(split_for(S), BH);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, lds_dq(2), a);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 2, grid, lds_dkv(2), a);
+    } else if (S <= 256 && S <= rmax) {
+        const dim3 grid(split_for(S), BH);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, lds_dq(4), a);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 4, grid, lds_dkv(4), a);
+    } else if (S > 128 && S <= 224 && seven_waves()) {
+        // ViT-B/16 (197 tokens = 7 tiles of 32): one 7-wave workgroup per head, every wave busy, K/V (Q/dO) streamed once
+        const dim3 grid(1, BH);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 7, 0, grid, lds_dq(0), a);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 7, 0, grid, lds_dkv(0), a);
     } else {
-        constexpr int L = 2 * IMG + TILE * 4 + 64;
-        ATTN_LAUNCH(attn_fwd_kernel, 4, 0, dim3((S + 127) / 128, B * H), L, q, key_mask, (h16*)out, lse, B, S, H, rng, drop_p, drop_stream, cu, row_map);
+        const dim3 grid((S + 127) / 128, BH);
+        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 0, grid, lds_dq(0), a);
+        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 0, grid, lds_dkv(0), a);
+    }
+}
+
+bool dual_off() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MEMEHIP_ATTN_DUAL");
+        v = (e && atoi(e) == 0) ? 1 : 0;
+    }
+    return v != 0;
+}
+// two problems that fit the dual kernels: A = 129..224 tokens without dropout (ViT), B = <= 128 tokens (text)
+bool dual_pair(const MhAttnProblem* p, int n, int& ia, int& ib) {
+    if (n != 2 || dual_off() || !seven_waves() || !fwd_seven_waves() || bwd_resident_max() < 128) return false;
+    for (int k = 0; k < 2; ++k) {
+        const MhAttnProblem &a = p[k], &b = p[1 - k];
+        if (a.S > 128 && a.S <= 224 && !has_drop(a) && b.S <= 128) {
+            ia = k;
+            ib = 1 - k;
+            return true;
+        }
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" int mh_attn_fwd_grouped(const MhAttnProblem* p, int n, mh_stream_t stream) {
+    if (!p || n < 1 || n > MH_ATTN_MAX_GROUP) return MH_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (int st = check_problem(p[i], false)) return st;
+    hipStream_t s = (hipStream_t)stream;
+    int ia, ib;
+    if (dual_pair(p, n, ia, ib)) {
+        const AttnArgs A = to_args(p[ia]), Bp = to_args(p[ib]);
+        const int nA = p[ia].B * p[ia].H, nB = p[ib].B * p[ib].H;
+        const bool dr = has_drop(p[ib]);
+        constexpr int L = cmax(lds_fwd(4), lds_fwd(2));
+        if (dr) {
+            static bool once_t = (set_lds(attn_fwd_dual_kernel<4, true>, L), true);
+            (void)once_t;
+            hipLaunchKernelGGL((attn_fwd_dual_kernel<4, true>), dim3(1, nA + nB), dim3(448), L, s, A, Bp, nA);
+        } else {
+            static bool once_f = (set_lds(attn_fwd_dual_kernel<4, false>, L), true);
+            (void)once_f;
+            hipLaunchKernelGGL((attn_fwd_dual_kernel<4, false>), dim3(1, nA + nB), dim3(448), L, s, A, Bp, nA);
+        }
+    } else {
+        for (int i = 0; i < n; ++i) launch_fwd(p[i], s);
     }
     return mh_launch_status();
 }
 
+extern "C" int mh_attn_bwd_grouped(const MhAttnProblem* p, int n, mh_stream_t stream) {
+    if (!p || n < 1 || n > MH_ATTN_MAX_GROUP) return MH_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (int st = check_problem(p[i], true)) return st;
+    hipStream_t s = (hipStream_t)stream;
+    int ia, ib;
+    if (dual_pair(p, n, ia, ib)) {
+        const AttnArgs A = to_args(p[ia]), Bp = to_args(p[ib]);
+        const int nA = p[ia].B * p[ia].H, nB = p[ib].B * p[ib].H;
+        const bool dr = has_drop(p[ib]);
+        const dim3 grid(1, nA + nB);
+        ATTN_LAUNCH_DUAL(attn_bwd_dq_dual_kernel, cmax(lds_dq(0), lds_dq(2)), grid, A, Bp, nA);
+        ATTN_LAUNCH_DUAL(attn_bwd_dkv_dual_kernel, cmax(lds_dkv(0), lds_dkv(2)), grid, A, Bp, nA);
+    } else {
+        for (int i = 0; i < n; ++i) launch_bwd(p[i], s);
+    }
+    return mh_launch_status();
+}
+
+static MhAttnProblem one_problem(const void* qkv, const int64_t* key_mask, const void* out, float* lse, const void* dout,
+                                 float* delta, void* dqkv, const int32_t* cu, const int32_t* row_map, int B, int S, int H,
+                                 const uint32_t* rng, float drop_p, uint32_t drop_stream) {
+    MhAttnProblem p;
+    p.qkv = qkv; p.key_mask = key_mask; p.out = (void*)out; p.lse = lse;
+    p.dout = dout; p.delta = delta; p.dqkv = dqkv;
+    p.cu = cu; p.row_map = row_map;
+    p.rng = rng; p.drop_p = drop_p; p.drop_stream = drop_stream;
+    p.B = B; p.S = S; p.H = H; p.reserved = 0;
+    return p;
+}
+
 extern "C" int mh_attn_fwd(const void* qkv, const int64_t* key_mask, void* out, float* lse, int B, int S,
                            int H, const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream) {
-    return attn_fwd_impl(qkv, key_mask, out, lse, nullptr, nullptr, B, S, H, rng, drop_p, drop_stream, stream);
+    const MhAttnProblem p = one_problem(qkv, key_mask, out, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, S, H, rng,
+                                        drop_p, drop_stream);
+    return mh_attn_fwd_grouped(&p, 1, stream);
 }
 extern "C" int mh_attn_fwd_packed(const void* qkv, const int64_t* key_mask, void* out, float* lse, const int32_t* cu,
                                   const int32_t* row_map, int B, int S, int H, const uint32_t* rng, float drop_p,
                                   uint32_t drop_stream, mh_stream_t stream) {
     if (!cu) return MH_EINVAL;
-    return attn_fwd_impl(qkv, key_mask, out, lse, cu, row_map, B, S, H, rng, drop_p, drop_stream, stream);
+    const MhAttnProblem p = one_problem(qkv, key_mask, out, lse, nullptr, nullptr, nullptr, cu, row_map, B, S, H, rng,
+                                        drop_p, drop_stream);
+    return mh_attn_fwd_grouped(&p, 1, stream);
 }
-
-static int attn_bwd_impl(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
-                         const float* lse, float* delta, void* dqkv, const int32_t* cu, const int32_t* row_map, int B,
-                         int S, int H, const uint32_t* rng, float drop_p, uint32_t drop_stream, mh_stream_t stream) {
-    if (!qkv || !out || !dout || !lse || !delta || !dqkv) return MH_EINVAL;
-    if (B < 1 || S < 1 || H < 1 || drop_p < 0.f || drop_p >= 1.f) return MH_ESHAPE;
-    hipStream_t s = (hipStream_t)stream;
-    const h16* q = (const h16*)qkv;
-    const h16* O = (const h16*)out;
-    const h16* dO = (const h16*)dout;
-    h16* dq = (h16*)dqkv;
-    const bool dr = rng && drop_p > 0.f;
-    const int rmax = bwd_resident_max();
-    if (S <= 128 && S <= rmax) {
-        constexpr int L1 = 3 * 2 * IMG + 2 * TILE * 4 + 64, L2 = 4 * 2 * IMG + 2 * 2 * TILE * 4;
-        const dim3 grid(split_for(S), B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 2, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-    } else if (S <= 256 && S <= rmax) {
-        constexpr int L1 = 3 * 4 * IMG + 4 * TILE * 4 + 64, L2 = 4 * 4 * IMG + 2 * 4 * TILE * 4;
-        const dim3 grid(split_for(S), B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 4, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 4, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-    } else if (S > 128 && S <= 224 && seven_waves()) {
-        // ViT-B/16 (197 tokens = 7 tiles of 32): one 7-wave workgroup per head, every wave busy, K/V (Q/dO) streamed once
-        constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
-        const dim3 grid(1, B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 7, 0, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-        ATTN_LAUNCH(attn_bwd_dkv_kernel, 7, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-    } else {
-        constexpr int L1 = 3 * IMG + TILE * 4 + 64, L2 = 4 * IMG + 2 * TILE * 4;
-        const dim3 grid((S + 127) / 128, B * H);
-        ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 0, grid, L1, q, key_mask, O, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-        ATTN_LAUNCH(attn_bwd_dkv_kernel, 4, 0, grid, L2, q, key_mask, dO, lse, delta, dq, B, S, H, rng, drop_p, drop_stream, cu, row_map);
-    }
-    return mh_launch_status();
-}
-
 extern "C" int mh_attn_bwd(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
                            const float* lse, float* delta, void* dqkv, int B, int S, int H, const uint32_t* rng,
                            float drop_p, uint32_t drop_stream, mh_stream_t stream) {
-    return attn_bwd_impl(qkv, key_mask, out, dout, lse, delta, dqkv, nullptr, nullptr, B, S, H, rng, drop_p, drop_stream,
-                         stream);
+    const MhAttnProblem p = one_problem(qkv, key_mask, out, (float*)lse, dout, delta, dqkv, nullptr, nullptr, B, S, H, rng,
+                                        drop_p, drop_stream);
+    return mh_attn_bwd_grouped(&p, 1, stream);
 }
 extern "C" int mh_attn_bwd_packed(const void* qkv, const int64_t* key_mask, const void* out, const void* dout,
                                   const float* lse, float* delta, void* dqkv, const int32_t* cu, const int32_t* row_map,
                                   int B, int S, int H, const uint32_t* rng, float drop_p, uint32_t drop_stream,
                                   mh_stream_t stream) {
     if (!cu) return MH_EINVAL;
-    return attn_bwd_impl(qkv, key_mask, out, dout, lse, delta, dqkv, cu, row_map, B, S, H, rng, drop_p, drop_stream,
-                         stream);
+    const MhAttnProblem p = one_problem(qkv, key_mask, out, (float*)lse, dout, delta, dqkv, cu, row_map, B, S, H, rng,
+                                        drop_p, drop_stream);
+    return mh_attn_bwd_grouped(&p, 1, stream);
 }

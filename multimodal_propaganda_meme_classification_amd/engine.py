@@ -22,8 +22,8 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhColsumJob, MhGemmProblem, MhHeadGrads, MhHeadParams,
-                   MhLnBwdJob, MhLnFwdJob)
+from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhAttnProblem, MhColsumJob, MhGemmProblem, MhHeadGrads,
+                   MhHeadParams, MhLnBwdJob, MhLnFwdJob)
 from .config import Layout, ModelConfig
 
 BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
@@ -310,6 +310,26 @@ class Engine:
             plan.keep.append(arr)
             seg.c("mh_layernorm_bwd_grouped", arr, len(js), D)
 
+    def _attn(self, plan: Plan, seg: Segment, probs: List[Optional[dict]], backward: bool):
+        """Both towers' attention of a layer pair as one grouped call (one launch per kernel when the pair fits the
+        dual kernels, see include/memehip.h: mh_attn_fwd_grouped)."""
+        probs = [d for d in probs if d is not None]
+        if not probs:
+            return
+        arr = (MhAttnProblem * len(probs))()
+        for e, d in zip(arr, probs):
+            for k in ("qkv", "key_mask", "out", "lse", "dout", "delta", "dqkv", "cu", "row_map"):
+                setattr(e, k, _ptr(d.get(k)))
+            rng, p_, sid = d.get("drop") or (None, 0.0, 0)
+            e.rng, e.drop_p, e.drop_stream = rng, float(p_), int(sid)
+            e.B, e.S, e.H = d["B"], d["S"], d["H"]
+            n = d["B"] * d["S"] * d["H"] * 64
+            assert d["qkv"].numel() >= 3 * n and d["out"].numel() >= n and d["lse"].numel() >= d["B"] * d["H"] * d["S"]
+            if backward:
+                assert d["dout"].numel() >= n and d["dqkv"].numel() >= 3 * n and d["delta"].numel() >= d["B"] * d["H"] * d["S"]
+        plan.keep.append(arr)
+        seg.c("mh_attn_bwd_grouped" if backward else "mh_attn_fwd_grouped", arr, len(probs))
+
     def before_backward(self, plan: Plan):
         """Each plan re-zeroes the word-embedding gradient rows IT touched last time (the table gradient is dense,
         only touched rows are ever non-zero).  When the previous backward ran under a different plan (another
@@ -413,13 +433,12 @@ class Engine:
             xt = [x0d]
             tp, tpd = {}, {}
 
-        def text_attn_fwd(seg_, a_, sid):
+        def text_attn(a_, sid, **bw):
+            base = dict(qkv=a_["qkv"], out=a_["ctx"], lse=a_["lse"], B=B, S=S, H=Ht, drop=site(p_a, sid), **bw)
             if pack:
-                seg_.c("mh_attn_fwd_packed", _ptr(a_["qkv"]), _ptr(pmask), _ptr(a_["ctx"]), _ptr(a_["lse"]), _ptr(cu),
-                       _ptr(row_map), B, S, Ht, *site_args(p_a, sid))
-            else:
-                seg_.c("mh_attn_fwd", _ptr(a_["qkv"]), _ptr(mask), _ptr(a_["ctx"]), _ptr(a_["lse"]), B, S, Ht,
-                       *site_args(p_a, sid))
+                return dict(base, key_mask=pmask, cu=cu, row_map=row_map)
+            return dict(base, key_mask=mask)
+
         # image embeddings
         patches = alloc("i.patches", (B * Np, Kp))
         proj = alloc("i.proj", (B * Np, Di))
@@ -479,12 +498,9 @@ class Engine:
                 pr.append(self._fwd_prob(b_["u"], self.w(LI + "attention.attention.query.weight", 3), b_["qkv"], Ti,
                                          3 * Di, Di, bias=self.p(LI + "attention.attention.query.bias", 3)))
             self._gemm(pl, f, pr, False, False)
-            f.fork()
-            if has_i:
-                f.c("mh_attn_fwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(b_["lse"]), B, Nt, Hi, None, 0.0, 0, lane=2)
-            if has_t:
-                text_attn_fwd(f, a, 16 * (l + 1) + 1)
-            f.join()
+            self._attn(pl, f, [
+                dict(qkv=b_["qkv"], out=b_["ctx"], lse=b_["lse"], B=B, S=Nt, H=Hi) if has_i else None,
+                text_attn(a, 16 * (l + 1) + 1) if has_t else None], backward=False)
             # attention output projection + residual
             pr = []
             if has_t:
@@ -638,17 +654,10 @@ class Engine:
             if has_i:
                 pr.append(self._dgrad_prob(i_dxp, self.w(LI + "attention.output.dense.weight"), i_dctx, Ti, Di, Di))
             self._gemm(pl, s, pr, False, True)
-            s.fork()
-            if has_i:
-                s.c("mh_attn_bwd", _ptr(b_["qkv"]), None, _ptr(b_["ctx"]), _ptr(i_dctx), _ptr(b_["lse"]), _ptr(i_delta),
-                    _ptr(i_dqkv), B, Nt, Hi, None, 0.0, 0, lane=2)
-            if has_t and pack:
-                s.c("mh_attn_bwd_packed", _ptr(a["qkv"]), _ptr(pmask), _ptr(a["ctx"]), _ptr(t_dctx), _ptr(a["lse"]),
-                    _ptr(t_delta), _ptr(t_dqkv), _ptr(cu), _ptr(row_map), B, S, Ht, *site_args(p_a, 16 * (l + 1) + 1))
-            elif has_t:
-                s.c("mh_attn_bwd", _ptr(a["qkv"]), _ptr(mask), _ptr(a["ctx"]), _ptr(t_dctx), _ptr(a["lse"]), _ptr(t_delta),
-                    _ptr(t_dqkv), B, S, Ht, *site_args(p_a, 16 * (l + 1) + 1))
-            s.join()
+            self._attn(pl, s, [
+                dict(qkv=b_["qkv"], out=b_["ctx"], lse=b_["lse"], dout=i_dctx, delta=i_delta, dqkv=i_dqkv, B=B, S=Nt,
+                     H=Hi) if has_i else None,
+                text_attn(a, 16 * (l + 1) + 1, dout=t_dctx, delta=t_delta, dqkv=t_dqkv) if has_t else None], backward=True)
             # through the QKV projection
             pr = []
             if has_t:

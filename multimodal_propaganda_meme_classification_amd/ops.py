@@ -292,6 +292,27 @@ def attn_bwd_packed(qkv, plan, out, dout, lse, B, S, H, drop=None):
     return dqkv
 
 
+def attn_grouped(problems, backward: bool = False):
+    """mh_attn_fwd_grouped / mh_attn_bwd_grouped.  problems: dicts with tensors qkv, out, lse (+ dout, delta, dqkv for the
+    backward), optional key_mask, cu, row_map, drop=(rng, p, site) and ints B, S, H.  Outputs are written in place."""
+    from ._lib import MhAttnProblem
+    arr = (MhAttnProblem * len(problems))()
+    for e, d in zip(arr, problems):
+        _chk(d["qkv"], BF16, "qkv"), _chk(d["out"], BF16, "out"), _chk(d["lse"], F32, "lse")
+        n = d["B"] * d["S"] * d["H"] * 64
+        assert d["qkv"].numel() >= 3 * n and d["out"].numel() >= n and d["lse"].numel() >= d["B"] * d["H"] * d["S"]
+        if backward:
+            _chk(d["dout"], BF16, "dout"), _chk(d["dqkv"], BF16, "dqkv"), _chk(d["delta"], F32, "delta")
+            assert d["dout"].numel() >= n and d["dqkv"].numel() >= 3 * n and d["delta"].numel() >= d["B"] * d["H"] * d["S"]
+        for k in ("qkv", "key_mask", "out", "lse", "dout", "delta", "dqkv", "cu", "row_map"):
+            setattr(e, k, _p(d.get(k)))
+        e.rng, e.drop_p, e.drop_stream = _drop(d.get("drop"))
+        e.B, e.S, e.H = d["B"], d["S"], d["H"]
+    lib = _L(problems[0]["qkv"])
+    fn = lib.mh_attn_bwd_grouped if backward else lib.mh_attn_fwd_grouped
+    check(fn(arr, len(problems), _stream()), "mh_attn_bwd_grouped" if backward else "mh_attn_fwd_grouped")
+
+
 def attn_bwd(qkv, key_mask, out, dout, lse, B, S, H, dqkv=None, delta=None, drop=None):
     _chk(qkv, BF16, "qkv"), _chk(out, BF16, "out"), _chk(dout, BF16, "dout"), _chk(lse, F32, "lse")
     assert qkv.numel() == B * S * 3 * H * 64 and out.numel() == B * S * H * 64 == dout.numel()

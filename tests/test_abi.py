@@ -46,6 +46,7 @@ def test_struct_layout_matches_header(lib):
     # 8 pointers + 7 int32 + float + pointer + float + uint32 + 2 pointers = 128 bytes; a drift here would corrupt every grouped launch
     assert ctypes.sizeof(lib.MhGemmProblem) == 128
     assert ctypes.sizeof(lib.MhColsumJob) == 24
+    assert ctypes.sizeof(lib.MhAttnProblem) == 104
     assert ctypes.sizeof(lib.MhLnFwdJob) == 72 and ctypes.sizeof(lib.MhLnBwdJob) == 112
     assert ctypes.sizeof(lib.MhHeadParams) == 64 == ctypes.sizeof(lib.MhHeadGrads)
 

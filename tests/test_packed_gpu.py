@@ -241,3 +241,43 @@ def test_adam_skipping_untouched_embedding_rows_is_bit_identical(pkg):
     live = opts[0]._flat["row_live"]
     assert 0 < int(live.sum()) < live.numel()          # some rows updated, most of the table skipped
     assert opts[1]._flat.get("row_live") is None or int(opts[1]._flat["row_live"].sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("packed", [True, False])
+def test_grouped_attention_equals_separate_launches(pkg, dtype, packed):
+    """The dual launch (ViT heads + text heads in one grid) runs the same per-head code as the two separate launches."""
+    from multimodal_propaganda_meme_classification_amd import ops
+    B, Hn, Si, St = 5, 3, 197, 128
+    mask = torch.from_numpy(_masks(B, St, "prefix", 41)).cuda()
+    plan = ops.pack_plan(mask, 0)
+    qi = (torch.randn((B * Si, 3 * Hn * 64), device="cuda") * 0.7).to(dtype)
+    qt = (torch.randn((B * St, 3 * Hn * 64), device="cuda") * 0.7).to(dtype)
+    doi = (torch.randn((B * Si, Hn * 64), device="cuda") * 0.1).to(dtype)
+    dot = (torch.randn((B * St, Hn * 64), device="cuda") * 0.1).to(dtype)
+    rng = torch.tensor([123, 0, 7, 0], dtype=torch.int32, device="cuda")
+    for drop in (None, (rng, 0.1, 17)):
+        # separate launches
+        oi, li = ops.attn_fwd(qi, None, B, Si, Hn)
+        di = ops.attn_bwd(qi, None, oi, doi, li, B, Si, Hn)
+        if packed:
+            ot, lt = ops.attn_fwd_packed(qt, plan, B, St, Hn, drop=drop)
+            dt = ops.attn_bwd_packed(qt, plan, ot, dot, lt, B, St, Hn, drop=drop)
+            extra = dict(key_mask=plan["pmask"], cu=plan["cu"], row_map=plan["row_map"])
+        else:
+            ot, lt = ops.attn_fwd(qt, mask, B, St, Hn, drop=drop)
+            dt = ops.attn_bwd(qt, mask, ot, dot, lt, B, St, Hn, drop=drop)
+            extra = dict(key_mask=mask)
+        # grouped
+        z = lambda t: torch.zeros_like(t)
+        pi = dict(qkv=qi, out=z(oi), lse=z(li), dout=doi, delta=z(li), dqkv=z(di), B=B, S=Si, H=Hn)
+        pt = dict(qkv=qt, out=z(ot), lse=z(lt), dout=dot, delta=z(lt), dqkv=z(dt), B=B, S=St, H=Hn, drop=drop, **extra)
+        for order in ([pi, pt], [pt, pi]):
+            for d in order:
+                d["out"].zero_(), d["dqkv"].zero_()
+            ops.attn_grouped(order, backward=False)
+            ops.attn_grouped(order, backward=True)
+            torch.cuda.synchronize()
+            n = int(plan["n_rows"]) if packed else B * St
+            assert torch.equal(pi["out"], oi) and torch.equal(pi["dqkv"], di)
+            assert torch.equal(pt["out"][:n], ot[:n]) and torch.equal(pt["dqkv"][:n], dt[:n])
