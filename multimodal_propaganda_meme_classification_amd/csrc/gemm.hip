@@ -125,8 +125,32 @@ MH_DEV h16x8 read_frag(const char* lds, int rb, int kk, int lane) {
 }
 
 // ---- epilogue: f32 tile in LDS -> bias / GELU / gelu' / residual -> 16-B coalesced stores ----------
-template <int TM, int NTHR = TM * 2, bool DROP = true>
-MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n0, int tid, int M) {
+// The 16-bit epilogue operands (residual, gelu' pre-activation) are fetched BEFORE the accumulators go through
+// LDS (epilogue_prefetch), so their HBM latency hides behind the LDS transpose + barrier instead of stalling
+// every store iteration.
+template <int TM, int NTHR>
+struct EpiPrefetch {
+    static constexpr int iters = TM * 16 / NTHR;
+    i32x4 res[iters], mul[iters];
+};
+template <int TM, int NTHR>
+MH_DEV void epilogue_prefetch(const MhGemmProblem& P, int m0, int n0, int tid, int M, EpiPrefetch<TM, NTHR>& pf) {
+#pragma unroll
+    for (int it = 0; it < EpiPrefetch<TM, NTHR>::iters; ++it) {
+        const int q = it * NTHR + tid;
+        const int row = q >> 4, cc = q & 15;
+        const int gm = min(m0 + row, M - 1), gn = n0 + cc * 8;       // clamped: rows past M are never stored
+        const size_t o = (size_t)gm * P.ldc + gn;
+        pf.res[it] = i32x4{0, 0, 0, 0};
+        pf.mul[it] = i32x4{0, 0, 0, 0};
+        if (P.residual) pf.res[it] = *(const i32x4*)((const h16*)P.residual + o);
+        if (P.mul) pf.mul[it] = *(const i32x4*)((const h16*)P.mul + o);
+    }
+}
+
+template <int TM, int NTHR = TM * 2, bool DROP = true, bool PREF = false>
+MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n0, int tid, int M,
+                          const EpiPrefetch<TM, NTHR>* pf = nullptr) {
     const int flags = P.flags;
     const int ldc = P.ldc;
     const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
@@ -170,13 +194,15 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
         }
         if (P.mul) {
             Pack8 u;
-            u.v = *(const i32x4*)((const h16*)P.mul + o);
+            if (PREF) u.v = pf->mul[it];
+            else u.v = *(const i32x4*)((const h16*)P.mul + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(mh_bf2f(u.e[e]));
         }
         if (P.residual) {
             Pack8 u;
-            u.v = *(const i32x4*)((const h16*)P.residual + o);
+            if (PREF) u.v = pf->res[it];
+            else u.v = *(const i32x4*)((const h16*)P.residual + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += mh_bf2f(u.e[e]);
         }
@@ -201,7 +227,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
 // NW = 4: four waves, 64x64 each (2 workgroups/CU = 2 waves/SIMD).  NW = 8 / 16 (LDS-DMA staging only): eight
 // waves of 64x32 / sixteen of 32x32 on the same tile and LDS (4 / 8 waves per SIMD): more waves to cover barrier
 // and LDS latency, at 1.5x / 2x the fragment reads per MFMA.
-template <int LA, int LB, int DMA, int NW = 4, bool DROP = true>
+template <int LA, int LB, int DMA, int NW = 4, bool DROP = true, bool PREF = true>
 __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g) {
     static_assert(NW == 4 || DMA == 1, "register staging is written for 256 threads");
     constexpr int NWM = NW == 16 ? 4 : 2;      // waves along M
@@ -332,6 +358,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
                 if (row < M) P.rowsum[row] = accb[i][r] * (P.alpha == 0.f ? 1.0f : P.alpha);
             }
     }
+    // (issuing these under the last K tile's MFMAs instead was measured 20 % slower: the extra live registers
+    //  across the main loop cost more than the remaining exposed latency)
+    EpiPrefetch<BM, NW * 64> pf;
+    if (PREF) epilogue_prefetch<BM, NW * 64>(P, m0, n0, tid, M, pf);
     float* cs = (float*)smem;  // [128][128] f32
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -345,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
             }
     __syncthreads();
 
-    epilogue_rows<BM, NW * 64, DROP>(P, cs, m0, n0, tid, M);
+    epilogue_rows<BM, NW * 64, DROP, PREF>(P, cs, m0, n0, tid, M, &pf);
 }
 
 // one 1-KiB LDS-DMA piece of a 16-KiB panel ([128 rows][64 k] or [64 k][128 rows]), swizzle on the source
@@ -688,16 +718,26 @@ int launch1(const GemmGroup& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<LA, LB, DMA>), dim3(g.total_tiles), dim3(NTHREADS), LDS_BYTES, s, g);
     return mh_launch_status();
 }
-template <int LA, int LB, int NW, bool DROP>
-int launch_nw2(const GemmGroup& g, hipStream_t s) {
+template <int LA, int LB, int NW, bool DROP, bool PREF>
+int launch_nw3(const GemmGroup& g, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB, 1, NW, DROP>,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB, 1, NW, DROP, PREF>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<LA, LB, 1, NW, DROP>), dim3(g.total_tiles), dim3(NW * 64), LDS_BYTES, s, g);
+    hipLaunchKernelGGL((gemm_kernel<LA, LB, 1, NW, DROP, PREF>), dim3(g.total_tiles), dim3(NW * 64), LDS_BYTES, s, g);
     return mh_launch_status();
+}
+template <int LA, int LB, int NW, bool DROP>
+int launch_nw2(const GemmGroup& g, hipStream_t s) {
+    static int pref = -1;     // A/B switch: MEMEHIP_GEMM_EPI_PREFETCH=0 loads the epilogue operands inside the store loop
+    if (pref < 0) {
+        const char* e = getenv("MEMEHIP_GEMM_EPI_PREFETCH");
+        pref = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (NW == 8 && pref == 0) return launch_nw3<LA, LB, NW, DROP, false>(g, s);
+    return launch_nw3<LA, LB, NW, DROP, true>(g, s);
 }
 template <int LA, int LB, int NW>
 int launch_nw(const GemmGroup& g, hipStream_t s) {
