@@ -73,6 +73,7 @@ def cpu_baseline(batch, seq, tiny):
     """Oracle fine-tune step (fp32, eager PyTorch CPU, dropout 0) on a bounded sample."""
     from oracle import meme_oracle as O
     cfg = O.tiny_config("cls") if tiny else O.config3("cls")
+    torch.set_num_threads(min(16, torch.get_num_threads()))      # the GPU box's CPU share for one GPU
     threads = torch.get_num_threads()
     params = O.init_params(cfg, seed=0)
     text, image, mask, labels = O.synthetic_batch(cfg, batch, seq, seed=1234)
