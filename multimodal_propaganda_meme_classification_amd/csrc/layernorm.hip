@@ -1,6 +1,7 @@
 // LayerNorm forward / backward, one 64-lane wavefront per row, 16-B h16 loads (HBM-bound).
 // See include/memehip.h.  Rows of D <= 4096 live in registers (NCH chunks of 8 per lane).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -121,9 +122,11 @@ struct LnBwdGroup {
     MhLnBwdJob job[MH_LN_MAX_JOBS];
 };
 
-template <int NCH, bool DROP>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp, int D) {
-    __shared__ float red[4][64 * 8];
+// NWV waves per workgroup (4 or 8): one workgroup = one set of column partials, so 8 waves double the rows in
+// flight (the kernel is a chain of load -> reduce -> store per row, i.e. latency-bound) without more partials
+template <int NCH, bool DROP, int NWV>
+__global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LnBwdGroup grp, int D) {
+    __shared__ float red[NWV][64 * 8];
     int j = 0;
     while (j + 1 < grp.n && (int)blockIdx.x >= grp.start[j + 1]) ++j;
     const MhLnBwdJob& jb = grp.job[j];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp, int D
     const float invD = 1.0f / (float)D;
     const bool dropj = DROP && dx_drop != nullptr;      // per job: only some jobs of a group carry a dropout site
     const DropCtx drop = mh_drop_ctx(dropj ? jb.rng : nullptr, jb.drop_p, jb.drop_stream);
-    for (int row = blk * 4 + wave; row < rows; row += n_part * 4) {
+    for (int row = blk * NWV + wave; row < rows; row += n_part * NWV) {
         float xv[NCH][8], dv[NCH][8];
         load_row<NCH>(x + (size_t)row * D, D, lane, xv);
         load_row<NCH>(dy + (size_t)row * D, D, lane, dv);
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp, int D
             store_row<NCH>(dx_drop + (size_t)row * D, D, lane, dv);
         }
     }
-    // cross-wave reduce of the column partials, one chunk slot at a time (8 KB of LDS: a workgroup must fit
+    // cross-wave reduce of the column partials, one chunk slot at a time (8-16 KB of LDS: a workgroup must fit
     // beside two 64-KB GEMM workgroups when the weight-gradient GEMMs run on the side stream)
     float* pg = part + (size_t)blk * D;
     float* pb = part + (size_t)n_part * D + (size_t)blk * D;
@@ -211,11 +214,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdGroup grp, int D
             for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = pass == 0 ? dg[i][e] : db[i][e];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int cidx = threadIdx.x + 256 * k;  // = l*8+e
+            for (int k = 0; k < 8 / NWV; ++k) {
+                const int cidx = threadIdx.x + NWV * 64 * k;  // = l*8+e
                 const int col = (cidx >> 3) * 8 + 64 * 8 * i + (cidx & 7);
                 if (col < D) {
-                    const float s = red[0][cidx] + red[1][cidx] + red[2][cidx] + red[3][cidx];
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWV; ++w) s += red[w][cidx];
                     (pass == 0 ? pg : pb)[col] = s;
                 }
             }
@@ -304,10 +309,26 @@ extern "C" int mh_layernorm_bwd_grouped(const MhLnBwdJob* jobs, int n_jobs, int 
     for (int i = n_jobs; i <= MH_LN_MAX_JOBS; ++i) g.start[i] = blocks;
     hipStream_t s = (hipStream_t)stream;
     const int nch = (D / 8 + 63) / 64;
-#define LN_BWD_ARGS dim3(blocks), dim3(256), 0, s, g, D
-    if (nch <= 1) { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<1, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), LN_BWD_ARGS); }
-    else if (nch <= 2) { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<2, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<2, false>), LN_BWD_ARGS); }
-    else { if (dr) hipLaunchKernelGGL((ln_bwd_kernel<4, true>), LN_BWD_ARGS); else hipLaunchKernelGGL((ln_bwd_kernel<4, false>), LN_BWD_ARGS); }
+    static int nwv = -1;      // MEMEHIP_LN_BWD_WAVES=8 for A/B runs (measured: 0.66 vs 0.54 ms per step, 4 stays)
+    if (nwv < 0) {
+        const char* e = getenv("MEMEHIP_LN_BWD_WAVES");
+        nwv = (e && atoi(e) == 8) ? 8 : 4;
+    }
+#define LN_BWD_ARGS dim3(blocks), dim3(nwv * 64), 0, s, g, D
+#define LN_BWD_GO(NCH_)                                                                                          \
+    do {                                                                                                         \
+        if (nwv == 8) {                                                                                          \
+            if (dr) hipLaunchKernelGGL((ln_bwd_kernel<NCH_, true, 8>), LN_BWD_ARGS);                             \
+            else hipLaunchKernelGGL((ln_bwd_kernel<NCH_, false, 8>), LN_BWD_ARGS);                               \
+        } else {                                                                                                 \
+            if (dr) hipLaunchKernelGGL((ln_bwd_kernel<NCH_, true, 4>), LN_BWD_ARGS);                             \
+            else hipLaunchKernelGGL((ln_bwd_kernel<NCH_, false, 4>), LN_BWD_ARGS);                               \
+        }                                                                                                        \
+    } while (0)
+    if (nch <= 1) LN_BWD_GO(1);
+    else if (nch <= 2) LN_BWD_GO(2);
+    else LN_BWD_GO(4);
+#undef LN_BWD_GO
 #undef LN_BWD_ARGS
     return mh_launch_status();
 }

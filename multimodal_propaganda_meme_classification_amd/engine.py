@@ -27,7 +27,8 @@ from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhAttnProblem, 
 from .config import Layout, ModelConfig
 
 BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
-LN_PARTS = 512
+import os as _os
+LN_PARTS = int(_os.environ.get("MEMEHIP_LN_PARTS", "512"))     # workgroups (= sets of dgamma/dbeta partials) per LayerNorm backward
 
 
 class Segment:
