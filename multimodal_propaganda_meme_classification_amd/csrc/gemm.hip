@@ -26,12 +26,34 @@ struct DevProblem {
     MhGemmProblem p;
     int tiles_n;
     int tile_start;
+    int tiles_m;
+    int pad_;
 };
 struct GemmGroup {
     int n;
     int total_tiles;
+    int group_m;      // L2 blocking of the tile order: GROUP_M row panels are swept column by column (0/1: n-fastest)
+    int pad_;
     DevProblem d[MH_GEMM_MAX_GROUP];
 };
+
+// local tile index -> (row tile, column tile).  n-fastest order makes the ~64 tiles an XCD runs at once span
+// 3-4 row panels x ALL column tiles: every K step touches the whole of B (3.5-4.7 MB at N = 2304 / 3072, K = 768),
+// which together with the A panels overflows the XCD's 4-MB L2.  Blocked order: GROUP_M row panels x 8 column
+// tiles at once = 8 + 8 operand panels, each re-used 8 times while it is hot.
+MH_DEV void tile_coords(const DevProblem& d, int group_m, int lt, int& tm, int& tn) {
+    if (group_m <= 1) {
+        tm = lt / d.tiles_n;
+        tn = lt % d.tiles_n;
+        return;
+    }
+    const int per_group = group_m * d.tiles_n;
+    const int g = lt / per_group;
+    const int r = lt - g * per_group;
+    const int rows = min(group_m, d.tiles_m - g * group_m);
+    tn = r / rows;
+    tm = g * group_m + (r - tn * rows);
+}
 
 MH_DEV int swz_kstrided(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
@@ -250,7 +272,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
         if (i < g.n && t >= g.d[i].tile_start) pi = i;
     const MhGemmProblem& P = g.d[pi].p;
     const int lt = t - g.d[pi].tile_start;
-    const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
+    int tm, tn;
+    tile_coords(g.d[pi], g.group_m, lt, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     int M = P.M, K = P.K;
@@ -422,7 +445,8 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
         if (i < g.n && t >= g.d[i].tile_start) pi = i;
     const MhGemmProblem& P = g.d[pi].p;
     const int lt = t - g.d[pi].tile_start;
-    const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
+    int tm, tn;
+    tile_coords(g.d[pi], g.group_m, lt, tm, tn);
     const int m0 = tm * R_BM, n0 = tn * BN;
     int M = P.M, K = P.K;
     const int N = P.N;
@@ -565,7 +589,8 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
         if (i < g.n && t >= g.d[i].tile_start) pi = i;
     const MhGemmProblem& P = g.d[pi].p;
     const int lt = t - g.d[pi].tile_start;
-    const int tm = lt / g.d[pi].tiles_n, tn = lt % g.d[pi].tiles_n;
+    int tm, tn;
+    tile_coords(g.d[pi], g.group_m, lt, tm, tn);
     const int m0 = tm * R_BM, n0 = tn * BN;
     int M = P.M, K = P.K;
     const int N = P.N;
@@ -806,9 +831,17 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         g.d[i].p = p;
         g.d[i].tiles_n = p.N / BN;
         g.d[i].tile_start = total;
-        total += ((p.M + tile_m - 1) / tile_m) * (p.N / BN);
+        g.d[i].tiles_m = (p.M + tile_m - 1) / tile_m;
+        total += g.d[i].tiles_m * (p.N / BN);
     }
     g.total_tiles = total;
+    static int group_m = -1;
+    if (group_m < 0) {
+        const char* e = getenv("MEMEHIP_GEMM_GROUP_M");
+        group_m = e ? atoi(e) : 8;
+        if (group_m < 0 || group_m > 64) group_m = 8;
+    }
+    g.group_m = group_m;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor) return launch<0, 0>(g, s);
     if (!a_kmajor && b_kmajor) return launch<0, 1>(g, s);
