@@ -92,7 +92,8 @@ int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems,
  * 0 = 4 waves, tiles staged global->VGPR->LDS; 1 = 4 waves, LDS-DMA (buffer_load ... lds);
  * 2 = 256x128 tile, 8 waves, 3-stage LDS-DMA ring with counted vmcnt; 3 = that ring with the two wave
  * groups in ping-pong read/MFMA slots; 4 = LDS-DMA, 8 waves of 64x32 (default: 4 waves/SIMD hide the
- * barrier + LDS latency best on this path's shapes); 5 = LDS-DMA, 16 waves of 32x32.
+ * barrier + LDS latency best on this path's shapes); 5 = LDS-DMA, 16 waves of 32x32; 6 = variant 4's tile with a
+ * four-slot ring of 32-deep K steps and counted vmcnt (slower: a barrier per 8 MFMAs).
  * Default 4 (or env MEMEHIP_GEMM_VARIANT at first launch). */
 int mh_gemm_set_variant(int variant);
 

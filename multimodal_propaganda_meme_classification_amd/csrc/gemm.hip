@@ -249,6 +249,11 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
 // NW = 4: four waves, 64x64 each (2 workgroups/CU = 2 waves/SIMD).  NW = 8 / 16 (LDS-DMA staging only): eight
 // waves of 64x32 / sixteen of 32x32 on the same tile and LDS (4 / 8 waves per SIMD): more waves to cover barrier
 // and LDS latency, at 1.5x / 2x the fragment reads per MFMA.
+// Measured with two throw-away variants of this loop (wrong results, timing only) on the path's grouped shapes:
+// without any operand traffic in the K loop (MFMA + LDS reads + barriers + epilogue) it runs at 1030-1370 TF/s;
+// with the LDS-DMA issued but never waited for it runs exactly as fast as the real kernel (730-950 TF/s).  So the
+// loop is not waiting for data: the LDS itself (fragment reads + DMA writes, ~640 LDS cycles per 512 MFMA cycles
+// per K step) is the limiter, and a deeper ring (variant 6) cannot help.
 template <int LA, int LB, int DMA, int NW = 4, bool DROP = true, bool PREF = true>
 __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g) {
     static_assert(NW == 4 || DMA == 1, "register staging is written for 256 threads");
@@ -729,6 +734,163 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
     epilogue_rows<R_BM>(P, cs, m0, n0, tid, M);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Variant 6: the same 128x128 tile and 8 waves (64x32 each, two workgroups per CU), but the K loop runs in
+// steps of 32 through a FOUR-slot LDS ring of 16-KiB half-stages (same 64 KiB): the tile of step t+3 is issued
+// right after the barrier of step t and waited for with a counted vmcnt three steps later, so every LDS-DMA has
+// 1.5 of the old K steps to land instead of 1, and 48 KiB instead of 32 KiB per workgroup are in flight
+// (the hypothesis: the L2 -> LDS stream is latency-bound).  MEASURED: 490-650 TF/s against variant 4's 600-950 on
+// every shape -- a barrier per 8 MFMAs costs far more than the extra run-ahead returns, and the loop was not
+// waiting for data in the first place (see gemm_kernel).  Kept for A/B.
+//   step t:  vmcnt(<= 2 tiles pending) -> s_barrier -> issue tile t+3 into slot (t+3)%4 -> 8 MFMAs on slot t%4
+// RAW: a wave's own counted wait + the barrier every wave reaches after its wait.  WAR: slot (t+3)%4 == (t-1)%4
+// was last read in step t-1, which every wave has left before this step's barrier.
+// Half-stage images:  K-contiguous operand [128 rows][32 k]: 16-row blocks of 1 KiB, inside a block the 16-B
+// chunk c of row r sits at slot 16 c + r -- a fragment read is then simply lane*16 inside the block, and each
+// of ds_read_b128's four lane groups touches 16 distinct slots (conflict-free).  K-strided operand
+// [32 k][128 rows]: the first 32 k-rows of the 64-deep layout above.
+// ---------------------------------------------------------------------------------------------------
+constexpr int S4_BK = 32, S4_HALF = 8192, S4_STAGE = 2 * S4_HALF, S4_SLOTS = 4;
+
+template <int KMAJOR>
+MH_DEV void dma_half(__amdgpu_buffer_rsrc_t r, int ld, int r0, int k0, int piece, int lane, char* img) {
+    uint32_t off;
+    if (KMAJOR == 0) {
+        const int row = piece * 16 + (lane & 15);
+        off = (uint32_t)((r0 + row) * ld + k0 + (lane >> 4) * 8) * 2u;
+    } else {
+        const int kr = piece * 4 + (lane >> 4);
+        const int pos = lane & 15;
+        const int c = (((pos >> 1) ^ swz_kstrided(kr)) << 1) | (pos & 1);
+        off = (uint32_t)((k0 + kr) * ld + r0 + c * 8) * 2u;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(void, img + piece * 1024), 16, off, 0, 0, 0);
+}
+template <int KMAJOR>
+MH_DEV h16x8 read_frag_half(const char* img, int rb, int lane) {
+    if (KMAJOR == 0) {
+        Pack8 u;
+        u.v = *(const i32x4*)(img + (rb >> 4) * 1024 + lane * 16);
+        return u.h;
+    } else {
+        return read_frag<1>(img, rb, 0, lane);
+    }
+}
+
+template <int LA, int LB, bool DROP>
+__global__ __launch_bounds__(512, 4) void gemm_s4_kernel(const GemmGroup g) {
+    constexpr int NW = 8, NWN = 4, NI = 4, NJ = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.total_tiles;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
+        if (i < g.n && t >= g.d[i].tile_start) pi = i;
+    const MhGemmProblem& P = g.d[pi].p;
+    const int lt = t - g.d[pi].tile_start;
+    int tm, tn;
+    tile_coords(g.d[pi], g.group_m, lt, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    int M = P.M, K = P.K;
+    const int N = P.N;
+    if (P.rows_dev) {
+        const int live = *P.rows_dev;
+        if (LA == 0) {
+            M = min(M, live);
+            if (m0 >= M) return;
+        } else {
+            K = min(K, live);
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / NWN) * (NI * 16), wn0 = (wave % NWN) * (NJ * 16);
+
+    const uint32_t a_bytes = (LA == 0) ? (uint32_t)((M - 1) * P.lda + K) * 2u : (uint32_t)((K - 1) * P.lda + M) * 2u;
+    const uint32_t b_bytes = (LB == 0) ? (uint32_t)((N - 1) * P.ldb + K) * 2u : (uint32_t)((K - 1) * P.ldb + N) * 2u;
+    const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, b_bytes);
+
+    f32x4 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave % NWN) == 0);
+    h16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (h16)1.0f;
+
+    const int nk = (K + S4_BK - 1) / S4_BK;
+    // wave w moves piece w of the A half-stage and piece w of the B half-stage (two LDS-DMA instructions per step)
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & (S4_SLOTS - 1)) * S4_STAGE;
+        dma_half<LA>(ra, P.lda, m0, kt * S4_BK, wave, lane, st);
+        dma_half<LB>(rb, P.ldb, n0, kt * S4_BK, wave, lane, st + S4_HALF);
+    };
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int pending = min(2, nk - 1 - kt);     // tiles issued after tile kt that may still be in flight
+        if (pending == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (pending == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) issue(kt + 3);
+        const char* la = smem + (kt & (S4_SLOTS - 1)) * S4_STAGE;
+        const char* lb = la + S4_HALF;
+        h16x8 fa[NI], fb[NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fa[i] = read_frag_half<LA>(la, wm0 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = read_frag_half<LB>(lb, wn0 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = MH_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (do_rowsum) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) accb[i] = MH_MFMA_16x16x32(fa[i], ones, accb[i], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // every wave is done reading the ring before it becomes the f32 output tile
+
+    if (do_rowsum && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm0 + i * 16 + (lane >> 4) * 4 + r;
+                if (row < M) P.rowsum[row] = accb[i][r] * (P.alpha == 0.f ? 1.0f : P.alpha);
+            }
+    }
+    EpiPrefetch<BM, NW * 64> pf;
+    epilogue_prefetch<BM, NW * 64>(P, m0, n0, tid, M, pf);
+    float* cs = (float*)smem;  // [128][128] f32
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
+                const int col = wn0 + j * 16 + (lane & 15);
+                cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    epilogue_rows<BM, NW * 64, DROP, true>(P, cs, m0, n0, tid, M, &pf);
+}
+
 int g_variant = -1;  // -1: read MEMEHIP_GEMM_VARIANT once; 0 = register staging, 1 = LDS-DMA 4 waves, 2 = 256x128 ring,
                      // 3 = ping-pong ring, 4 = LDS-DMA 8 waves (default), 5 = LDS-DMA 16 waves
 
@@ -793,8 +955,27 @@ int launch_pp(const GemmGroup& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm_pp_kernel<LA, LB>), dim3(g.total_tiles), dim3(R_THREADS), R_LDS, s, g);
     return mh_launch_status();
 }
+template <int LA, int LB, bool DROP>
+int launch_s4b(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_s4_kernel<LA, LB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_s4_kernel<LA, LB, DROP>), dim3(g.total_tiles), dim3(512), LDS_BYTES, s, g);
+    return mh_launch_status();
+}
+template <int LA, int LB>
+int launch_s4(const GemmGroup& g, hipStream_t s) {
+    bool any_drop = false;
+    for (int i = 0; i < g.n; ++i) any_drop |= (g.d[i].p.drop_rng != nullptr && g.d[i].p.drop_p > 0.f);
+    if (LA == 0 && LB == 0 && any_drop) return launch_s4b<LA, LB, true>(g, s);
+    return launch_s4b<LA, LB, false>(g, s);
+}
 template <int LA, int LB>
 int launch(const GemmGroup& g, hipStream_t s) {
+    if (g_variant == 6) return launch_s4<LA, LB>(g, s);
     if (g_variant == 0) return launch1<LA, LB, 0>(g, s);
     if (g_variant == 1) return launch1<LA, LB, 1>(g, s);
     if (g_variant == 2) return launch_ring<LA, LB>(g, s);
@@ -811,7 +992,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     if (g_variant < 0) {
         const char* e = getenv("MEMEHIP_GEMM_VARIANT");
         g_variant = e ? atoi(e) : 4;
-        if (g_variant < 0 || g_variant > 5) g_variant = 4;
+        if (g_variant < 0 || g_variant > 6) g_variant = 4;
     }
     const int tile_m = (g_variant == 2 || g_variant == 3) ? R_BM : BM;
     GemmGroup g;
@@ -823,7 +1004,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         if (p.M < 1 || p.N < 1 || p.K < 1) return MH_ESHAPE;
         if (p.N % BN) return MH_ESHAPE;
         if (a_kmajor && (p.M % BM)) return MH_ESHAPE;
-        if (!(a_kmajor && b_kmajor) && (p.K % BK)) return MH_ESHAPE;
+        if (!(a_kmajor && b_kmajor) && (p.K % BK)) return MH_ESHAPE;     // (also a multiple of variant 6's 32)
         if ((p.lda % 8) || (p.ldb % 8) || (p.ldc % 8)) return MH_ESHAPE;
         if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return MH_EINVAL;
         if (p.rowsum && !a_kmajor) return MH_EINVAL;
@@ -851,7 +1032,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
 
 // experiment knob (A/B in one process): 0 = register-staged tiles, 1 = LDS-DMA staged tiles
 extern "C" int mh_gemm_set_variant(int v) {
-    if (v < 0 || v > 5) return MH_EINVAL;
+    if (v < 0 || v > 6) return MH_EINVAL;
     g_variant = v;
     return MH_OK;
 }
