@@ -130,50 +130,86 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const int64_t*
     }
 }
 
-// dpos[s] = sum_b d[b][s]  (rows: tokens per sample = S, B samples); one wave per s
+// dpos[s] = sum_b d[b][s]  (rows: tokens per sample = S, B samples).  One workgroup per position s: the four waves
+// take the samples b = w, w+4, ... (independent 16-B loads, four in flight per wave) and are summed in wave order
+// through LDS -- a fixed order, so the result is bitwise reproducible.
 template <int NCH>
 __global__ __launch_bounds__(256) void sum_over_batch_kernel(const h16* __restrict__ d, float* __restrict__ out,
                                                              int B, int S, int D, float scale) {
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= S) return;
+    __shared__ float red[3][NCH * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x;
     float acc[NCH][8];
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const h16* row = d + ((size_t)b * S + s) * D;
+    for (int b0 = wave; b0 < B; b0 += 16) {
+        Pack8 u[4][NCH];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int b = b0 + 4 * k;
+            const h16* row = d + ((size_t)min(b, B - 1) * S + s) * D;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = (lane + 64 * i) * 8;
+                u[k][i].v = i32x4{0, 0, 0, 0};
+                if (c < D && b < B) u[k][i].v = *(const i32x4*)(row + c);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][e] += mh_bf2f(u[k][i].e[e]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wave - 1][(i * 64 + lane) * 8 + e] = acc[i][e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* o = out + (size_t)s * D;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = (lane + 64 * i) * 8;
             if (c < D) {
-                Pack8 u;
-                u.v = *(const i32x4*)(row + c);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[i][e] += mh_bf2f(u.e[e]);
+                for (int w = 0; w < 3; ++w)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][e] += red[w][(i * 64 + lane) * 8 + e];
+                *(f32x4*)(o + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]} * scale;
+                *(f32x4*)(o + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]} * scale;
             }
-        }
-    }
-    float* o = out + (size_t)s * D;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = (lane + 64 * i) * 8;
-        if (c < D) {
-            *(f32x4*)(o + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]} * scale;
-            *(f32x4*)(o + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]} * scale;
         }
     }
 }
 
-// out[d] = sum_{r<R} in[r][d]   (R small: <= 1024 rows), thread per column
+// out[d] = sum_{r<R} in[r][d]   (R small: <= 1024 rows).  Workgroup = 64 columns; the four waves take rows
+// r = w, w+4, ... (four loads in flight), summed in wave order through LDS (fixed order).
 __global__ __launch_bounds__(256) void colsum_rows_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               int R, int D) {
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= D) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += in[(size_t)r * D + d];
-    out[d] = s;
+    if (d < D) {
+        for (int r0 = wave; r0 < R; r0 += 16) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + 4 * k;
+                v[k] = r < R ? in[(size_t)r * D + d] : 0.f;
+            }
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && d < D) out[d] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 __global__ __launch_bounds__(256) void zero_rows_kernel(const int64_t* __restrict__ ids, float* __restrict__ table,
@@ -298,9 +334,9 @@ extern "C" int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre, float* d
     hipStream_t s = (hipStream_t)stream;
     NCH_DISPATCH(bert_embed_bwd_word_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, (const h16*)d_pre, dword, T,
                  D, vocab, pad_id, scale, row_live);
-    NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const h16*)d_pre, dpos, B, S, D, scale);
+    NCH_DISPATCH(sum_over_batch_kernel, dim3(S), dim3(256), 0, s, (const h16*)d_pre, dpos, B, S, D, scale);
     if (dtype0)
-        hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dpos, dtype0, S, D);
+        hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 63) / 64), dim3(256), 0, s, dpos, dtype0, S, D);
     return mh_launch_status();
 }
 
@@ -341,9 +377,9 @@ extern "C" int mh_vit_assemble_bwd(const void* dx, void* dproj, float* dcls, flo
     hipLaunchKernelGGL(vit_assemble_bwd_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        (const h16*)dx, (h16*)dproj, B, Np, D);
     const int S = Np + 1;
-    NCH_DISPATCH(sum_over_batch_kernel, dim3((S + 3) / 4), dim3(256), 0, s, (const h16*)dx, dpos, B, S, D, scale);
+    NCH_DISPATCH(sum_over_batch_kernel, dim3(S), dim3(256), 0, s, (const h16*)dx, dpos, B, S, D, scale);
     // d cls = sum_b dx[b][0] = dpos row 0
-    hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dpos, dcls, 1, D);
+    hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 63) / 64), dim3(256), 0, s, dpos, dcls, 1, D);
     return mh_launch_status();
 }
 

@@ -23,11 +23,11 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ th,
 }
 
 // y[m][n] = b[n] + sum_k x[m][k] W[n][k] ; one wave per output column n
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx,
-                                                         const float* __restrict__ W, const float* __restrict__ bias,
-                                                         float* __restrict__ y, int ldy, int M, int N, int K) {
+MH_DEV void linear_fwd_body(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                            const float* __restrict__ bias, float* __restrict__ y, int ldy, int M, int N, int K,
+                            int bx) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = bx * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const float* w = W + (size_t)n * K;
     for (int m0 = 0; m0 < M; m0 += RB) {
@@ -52,17 +52,25 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
+// several independent Linear layers of one head stage in ONE launch (blockIdx.y = which)
+struct LinFwdJobs {
+    int n;
+    struct J { const float* x; int ldx; const float* W; const float* bias; float* y; int ldy; int M, N, K; } j[2];
+};
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const LinFwdJobs jobs) {
+    const LinFwdJobs::J& j = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x * 4 >= j.N) return;
+    linear_fwd_body(j.x, j.ldx, j.W, j.bias, j.y, j.ldy, j.M, j.N, j.K, blockIdx.x);
+}
+
 // dx[m][k] = sum_n dy[m][n] W[n][k] ; thread per (m, k), wave rows share m
-template <bool OUT_BF16>
-__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, int ldy,
-                                                        const float* __restrict__ W, void* __restrict__ dx,
-                                                        size_t ldx, int M, int N, int K, float scale,
-                                                        const uint32_t* __restrict__ rng, float drop_p,
-                                                        uint32_t drop_stream,
-                                                        const int32_t* __restrict__ out_rows = nullptr) {
+MH_DEV void linear_dx_body(const bool OUT_BF16, const float* __restrict__ dy, int ldy, const float* __restrict__ W,
+                           void* __restrict__ dx, size_t ldx, int M, int N, int K, float scale,
+                           const uint32_t* __restrict__ rng, float drop_p, uint32_t drop_stream,
+                           const int32_t* __restrict__ out_rows, int bx, int by) {
     const DropCtx drop = mh_drop_ctx(rng, drop_p, drop_stream);
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int m = blockIdx.y;
+    const int k = bx * 256 + threadIdx.x;
+    const int m = by;
     if (k >= K) return;
     const float* d = dy + (size_t)m * ldy;
     float acc = 0.f;
@@ -74,12 +82,10 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
 }
 
 // dW[n][k] = sum_m dy[m][n] x[m][k] ; db[n] = sum_m dy[m][n]
-__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, int ldy,
-                                                        const float* __restrict__ x, int ldx,
-                                                        float* __restrict__ dW, float* __restrict__ db, int M, int N,
-                                                        int K) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int n = blockIdx.y;
+MH_DEV void linear_dw_body(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                           float* __restrict__ dW, float* __restrict__ db, int M, int N, int K, int bx, int by) {
+    const int k = bx * 256 + threadIdx.x;
+    const int n = by;
     if (k >= K) return;
     float acc = 0.f, accb = 0.f;
     for (int m = 0; m < M; ++m) {
@@ -89,6 +95,34 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     }
     dW[(size_t)n * K + k] = acc;
     if (k == 0) db[n] = accb;
+}
+
+// one stage of the head backward in ONE launch: the weight gradients and the input gradients that depend on
+// the same upstream gradient are independent of each other (blockIdx.z = which job)
+struct HeadBwdJobs {
+    int n;
+    struct J {
+        int type;             // 0: dW/db = dy^T x ; 1: dx = dy W
+        int out_bf16;
+        const float* dy; int ldy;
+        const float* b; int ldb;      // x (type 0) or W (type 1)
+        void* out; size_t ldo;        // dW (type 0) or dx (type 1)
+        float* db;
+        int M, N, K;
+        float scale;
+        const uint32_t* rng; float drop_p; uint32_t drop_stream;
+        const int32_t* out_rows;
+        int gx, gy;
+    } j[4];
+};
+__global__ __launch_bounds__(256) void head_bwd_stage_kernel(const HeadBwdJobs jobs) {
+    const HeadBwdJobs::J& j = jobs.j[blockIdx.z];
+    if ((int)blockIdx.x >= j.gx || (int)blockIdx.y >= j.gy) return;
+    if (j.type == 0)
+        linear_dw_body(j.dy, j.ldy, j.b, j.ldb, (float*)j.out, j.db, j.M, j.N, j.K, blockIdx.x, blockIdx.y);
+    else
+        linear_dx_body(j.out_bf16 != 0, j.dy, j.ldy, j.b, j.out, j.ldo, j.M, j.N, j.K, j.scale, j.rng, j.drop_p,
+                       j.drop_stream, j.out_rows, blockIdx.x, blockIdx.y);
 }
 
 // cross-entropy forward + dlogits, one block; B <= 1024
@@ -174,10 +208,37 @@ __global__ __launch_bounds__(1024) void focal_kernel(const float* __restrict__ l
     }
 }
 
-int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N, int K,
-               hipStream_t s) {
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, ldx, W, b, y, ldy, M, N, K);
-    return 0;
+void add_fwd(LinFwdJobs& L, const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N,
+             int K) {
+    LinFwdJobs::J& j = L.j[L.n++];
+    j.x = x; j.ldx = ldx; j.W = W; j.bias = b; j.y = y; j.ldy = ldy; j.M = M; j.N = N; j.K = K;
+}
+void run_fwd(const LinFwdJobs& L, hipStream_t s) {
+    int nmax = 0;
+    for (int i = 0; i < L.n; ++i) nmax = L.j[i].N > nmax ? L.j[i].N : nmax;
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((nmax + 3) / 4, L.n), dim3(256), 0, s, L);
+}
+int blocks256(int k) { return (k + 255) / 256; }
+void add_dw(HeadBwdJobs& H, const float* dy, int ldy, const float* x, int ldx, float* dW, float* db, int M, int N, int K) {
+    HeadBwdJobs::J& j = H.j[H.n++];
+    j.type = 0; j.out_bf16 = 0; j.dy = dy; j.ldy = ldy; j.b = x; j.ldb = ldx; j.out = dW; j.ldo = 0; j.db = db;
+    j.M = M; j.N = N; j.K = K; j.scale = 1.f; j.rng = nullptr; j.drop_p = 0.f; j.drop_stream = 0; j.out_rows = nullptr;
+    j.gx = blocks256(K); j.gy = N;
+}
+void add_dx(HeadBwdJobs& H, bool out_bf16, const float* dy, int ldy, const float* W, void* dx, size_t ldx, int M, int N,
+            int K, float scale, const uint32_t* rng, float drop_p, uint32_t drop_stream, const int32_t* out_rows) {
+    HeadBwdJobs::J& j = H.j[H.n++];
+    j.type = 1; j.out_bf16 = out_bf16 ? 1 : 0; j.dy = dy; j.ldy = ldy; j.b = W; j.ldb = 0; j.out = dx; j.ldo = ldx;
+    j.db = nullptr; j.M = M; j.N = N; j.K = K; j.scale = scale; j.rng = rng; j.drop_p = drop_p; j.drop_stream = drop_stream;
+    j.out_rows = out_rows; j.gx = blocks256(K); j.gy = M;
+}
+void run_bwd(const HeadBwdJobs& H, hipStream_t s) {
+    int gx = 1, gy = 1;
+    for (int i = 0; i < H.n; ++i) {
+        gx = H.j[i].gx > gx ? H.j[i].gx : gx;
+        gy = H.j[i].gy > gy ? H.j[i].gy : gy;
+    }
+    hipLaunchKernelGGL(head_bwd_stage_kernel, dim3(gx, gy, H.n), dim3(256), 0, s, H);
 }
 
 }  // namespace
@@ -193,10 +254,15 @@ extern "C" int mh_head_fwd(const MhHeadParams* p, const float* text_hidden, cons
     const int Dp = Dt + Di;
     hipLaunchKernelGGL(pool_kernel, dim3((B * Dp + 255) / 256), dim3(256), 0, s, text_hidden,
                        image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index, rng, drop_p, drop_stream, text_rows);
-    linear_fwd(pooled, Dp, p->Wt, p->bt, feat, 2 * P, B, P, Dt, s);
-    linear_fwd(pooled + Dt, Dp, p->Wi, p->bi, feat + P, 2 * P, B, P, Di, s);
-    linear_fwd(feat, 2 * P, p->Wf, p->bf_, fused, P, B, P, 2 * P, s);
-    linear_fwd(fused, P, p->Wo, p->bo, logits, C, B, C, P, s);
+    LinFwdJobs L1, L2, L3;
+    L1.n = L2.n = L3.n = 0;
+    add_fwd(L1, pooled, Dp, p->Wt, p->bt, feat, 2 * P, B, P, Dt);              // bert_fc and image_fc: one launch
+    add_fwd(L1, pooled + Dt, Dp, p->Wi, p->bi, feat + P, 2 * P, B, P, Di);
+    add_fwd(L2, feat, 2 * P, p->Wf, p->bf_, fused, P, B, P, 2 * P);
+    add_fwd(L3, fused, P, p->Wo, p->bo, logits, C, B, C, P);
+    run_fwd(L1, s);
+    run_fwd(L2, s);
+    run_fwd(L3, s);
     return mh_launch_status();
 }
 
@@ -212,28 +278,25 @@ extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const fl
     if (B < 1 || text_pool_index < 0 || text_pool_index >= S) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int Dp = Dt + Di;
-    auto blocks = [](int k) { return (k + 255) / 256; };
-    // output_fc
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(P), C), dim3(256), 0, s, dlogits, C, fused, P, g->Wo, g->bo, B,
-                       C, P);
-    hipLaunchKernelGGL((linear_dx_kernel<false>), dim3(blocks(P), B), dim3(256), 0, s, dlogits, C, p->Wo,
-                       (void*)dfused, (size_t)P, B, C, P, 1.0f, nullptr, 0.f, 0u);
-    // fusion_fc
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(2 * P), P), dim3(256), 0, s, dfused, P, feat, 2 * P, g->Wf,
-                       g->bf_, B, P, 2 * P);
-    hipLaunchKernelGGL((linear_dx_kernel<false>), dim3(blocks(2 * P), B), dim3(256), 0, s, dfused, P, p->Wf,
-                       (void*)dfeat, (size_t)(2 * P), B, P, 2 * P, 1.0f, nullptr, 0.f, 0u);
-    // bert_fc / image_fc
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(Dt), P), dim3(256), 0, s, dfeat, 2 * P, pooled, Dp, g->Wt,
-                       g->bt, B, P, Dt);
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(blocks(Di), P), dim3(256), 0, s, dfeat + P, 2 * P, pooled + Dt, Dp,
-                       g->Wi, g->bi, B, P, Di);
+    // three dependent stages (dlogits -> dfused -> dfeat -> hidden-state gradients); inside a stage the weight
+    // gradients and the input gradients are independent and share a launch
+    HeadBwdJobs H1, H2, H3;
+    H1.n = H2.n = H3.n = 0;
+    add_dw(H1, dlogits, C, fused, P, g->Wo, g->bo, B, C, P);                                      // output_fc
+    add_dx(H1, false, dlogits, C, p->Wo, (void*)dfused, (size_t)P, B, C, P, 1.0f, nullptr, 0.f, 0u, nullptr);
+    add_dw(H2, dfused, P, feat, 2 * P, g->Wf, g->bf_, B, P, 2 * P);                                // fusion_fc
+    add_dx(H2, false, dfused, P, p->Wf, (void*)dfeat, (size_t)(2 * P), B, P, 2 * P, 1.0f, nullptr, 0.f, 0u, nullptr);
+    add_dw(H3, dfeat, 2 * P, pooled, Dp, g->Wt, g->bt, B, P, Dt);                                  // bert_fc / image_fc
+    add_dw(H3, dfeat + P, 2 * P, pooled + Dt, Dp, g->Wi, g->bi, B, P, Di);
     // gradients of the pooled rows go straight into the [B][S][D] hidden-state gradient buffers
-    hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Dt), B), dim3(256), 0, s, dfeat, 2 * P, p->Wt,
-                       text_rows ? d_text_hidden : (void*)((h16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt,
-                       B, P, Dt, out_scale, rng, drop_p, drop_stream, text_rows);
-    hipLaunchKernelGGL((linear_dx_kernel<true>), dim3(blocks(Di), B), dim3(256), 0, s, dfeat + P, 2 * P, p->Wi,
-                       d_image_hidden, (size_t)Nt * Di, B, P, Di, out_scale, nullptr, 0.f, 0u);
+    add_dx(H3, true, dfeat, 2 * P, p->Wt,
+           text_rows ? d_text_hidden : (void*)((h16*)d_text_hidden + (size_t)text_pool_index * Dt), (size_t)S * Dt, B, P, Dt,
+           out_scale, rng, drop_p, drop_stream, text_rows);
+    add_dx(H3, true, dfeat + P, 2 * P, p->Wi, d_image_hidden, (size_t)Nt * Di, B, P, Di, out_scale, nullptr, 0.f, 0u,
+           nullptr);
+    run_bwd(H1, s);
+    run_bwd(H2, s);
+    run_bwd(H3, s);
     return mh_launch_status();
 }
 

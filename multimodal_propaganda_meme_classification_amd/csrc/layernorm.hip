@@ -235,21 +235,35 @@ struct ColsumJobs {
     float* out1[MH_COLSUM_MAX_JOBS];
 };
 
-// grid (ceil(D/64), 2, n_jobs), block 256: 4 waves split the partial rows, lane = column
+// grid (ceil(D/256), 2, n_jobs), block 256: the four waves split the partial rows (four 16-B loads in flight per
+// lane, 1-KiB row segments per wave), lane = 4 columns; summed in wave order through LDS (fixed order)
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs jobs, int n_part, int D, float scale) {
-    __shared__ float red[4][64];
+    __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
+    const int col = blockIdx.x * 256 + lane * 4;
     const int which = blockIdx.y, job = blockIdx.z;
     float* out = which == 0 ? jobs.out0[job] : jobs.out1[job];
     if (!out) return;
     const float* p = jobs.part[job] + (size_t)which * n_part * D;
-    float s = 0.f;
-    if (col < D)
-        for (int i = wave; i < n_part; i += 4) s += p[(size_t)i * D + col];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < D) {
+        for (int i0 = wave; i0 < n_part; i0 += 16) {
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + 4 * k;
+                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < n_part) v[k] = *(const f32x4*)(p + (size_t)i * D + col);
+            }
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && col < D) out[col] = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) * scale;
+    if (wave == 0 && col < D) {
+        const f32x4 t = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale;
+        *(f32x4*)(out + col) = t;
+    }
 }
 
 }  // namespace
@@ -345,7 +359,7 @@ extern "C" int mh_layernorm_bwd(const void* dy, const void* x, const float* gamm
 extern "C" int mh_colsum_partials_f32(const MhColsumJob* jobs, int n_jobs, int n_part, int D, float scale,
                                       mh_stream_t stream) {
     if (!jobs || n_jobs < 1 || n_jobs > MH_COLSUM_MAX_JOBS) return MH_EINVAL;
-    if (n_part < 1 || D < 1) return MH_ESHAPE;
+    if (n_part < 1 || D < 4 || (D % 4)) return MH_ESHAPE;
     ColsumJobs j;
     j.n = n_jobs;
     for (int i = 0; i < n_jobs; ++i) {
@@ -354,7 +368,7 @@ extern "C" int mh_colsum_partials_f32(const MhColsumJob* jobs, int n_jobs, int n
         j.out0[i] = jobs[i].out0;
         j.out1[i] = jobs[i].out1;
     }
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64, 2, n_jobs), dim3(256), 0, (hipStream_t)stream, j,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 255) / 256, 2, n_jobs), dim3(256), 0, (hipStream_t)stream, j,
                        n_part, D, scale);
     return mh_launch_status();
 }
