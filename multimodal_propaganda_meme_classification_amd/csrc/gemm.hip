@@ -891,6 +891,121 @@ __global__ __launch_bounds__(512, 4) void gemm_s4_kernel(const GemmGroup g) {
     epilogue_rows<BM, NW * 64, DROP, true>(P, cs, m0, n0, tid, M, &pf);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Variant 7 ("wide"): 128x256 tile, K steps of 32, 8 waves as 2(M) x 4(N) of 64x64 each, three-slot LDS-DMA ring
+// (3 x 24 KiB; two workgroups per CU), counted vmcnt, one barrier per step.  Per barrier a wave still issues 16
+// MFMAs (as variant 4 does per 64-deep step), but it reads 8 fragments instead of 12 (-33 % LDS reads) and the
+// workgroup moves 24 KiB instead of 32 KiB into LDS for the same 2.1 MFLOP (-25 %): variant 4's loop is bound by
+// exactly that LDS traffic.  The price is the tile count: half as many, twice as large, so it is only chosen for
+// launches whose rounds of 512 resident workgroups do not get longer, and only in the dgrad layout, where it
+// measured faster (N = 3072: FFN-down dgrad 805 vs 723 TF/s; the forward layout lost: FFN up 620 vs 756).
+//   step t:  vmcnt(tile t+1 may be pending) -> s_barrier -> issue tile t+2 into slot (t+2)%3 -> 16 MFMAs on slot t%3
+// A operand K-contiguous; B either layout.  Epilogue in two 128-column passes through the 64-KiB f32 staging area.
+// ---------------------------------------------------------------------------------------------------
+constexpr int W_BN = 256, W_SLOT = 8192 + 16384, W_SLOTS = 3, W_LDS = W_SLOTS * W_SLOT;   // 72 KiB >= the 64-KiB staging
+
+template <int LB, bool DROP>
+__global__ __launch_bounds__(512, 4) void gemm_wide_kernel(const GemmGroup g) {
+    constexpr int NW = 8, NWN = 4, NI = 4, NJ = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.total_tiles;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
+        if (i < g.n && t >= g.d[i].tile_start) pi = i;
+    const MhGemmProblem& P = g.d[pi].p;
+    const int lt = t - g.d[pi].tile_start;
+    int tm, tn;
+    tile_coords(g.d[pi], g.group_m, lt, tm, tn);
+    const int m0 = tm * BM, n0 = tn * W_BN;
+    int M = P.M;
+    const int N = P.N, K = P.K;
+    if (P.rows_dev) {
+        M = min(M, *P.rows_dev);
+        if (m0 >= M) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / NWN) * 64, wn0 = (wave % NWN) * 64;
+
+    const uint32_t a_bytes = (uint32_t)((M - 1) * P.lda + K) * 2u;
+    const uint32_t b_bytes = (LB == 0) ? (uint32_t)((N - 1) * P.ldb + K) * 2u : (uint32_t)((K - 1) * P.ldb + N) * 2u;
+    const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, b_bytes);
+
+    f32x4 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / S4_BK;
+    // per step a wave moves piece w of A and, of B, pieces w and w+8 (K-contiguous B: 16 blocks of 16 rows;
+    // K-strided B: two 128-column panels of 8 pieces each)
+    auto issue = [&](int kt) {
+        char* st = smem + (kt % W_SLOTS) * W_SLOT;
+        const int k0 = kt * S4_BK;
+        dma_half<0>(ra, P.lda, m0, k0, wave, lane, st);
+        if (LB == 0) {
+            dma_half<0>(rb, P.ldb, n0, k0, wave, lane, st + 8192);
+            dma_half<0>(rb, P.ldb, n0, k0, wave + 8, lane, st + 8192);
+        } else {
+            dma_half<1>(rb, P.ldb, n0, k0, wave, lane, st + 8192);
+            dma_half<1>(rb, P.ldb, n0 + 128, k0, wave, lane, st + 16384);
+        }
+    };
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const char* la = smem + (kt % W_SLOTS) * W_SLOT;
+        const char* lb = la + 8192;
+        h16x8 fa[NI], fb[NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fa[i] = read_frag_half<0>(la, wm0 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (LB == 0) fb[j] = read_frag_half<0>(lb, wn0 + j * 16, lane);
+            else fb[j] = read_frag<1>(lb + (wn0 >> 7) * 8192, (wn0 & 127) + j * 16, 0, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = MH_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();   // every wave is done reading the ring before it becomes the f32 output tile
+
+    float* cs = (float*)smem;  // [128][128] f32, one 128-column half at a time
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if ((wn0 >> 7) == half) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
+                        const int col = (wn0 & 127) + j * 16 + (lane & 15);
+                        cs[row * BN + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        // (no operand prefetch here: with 64 accumulator registers live it would spill)
+        epilogue_rows<BM, NW * 64, DROP, false>(P, cs, m0, n0 + half * 128, tid, M);
+        __syncthreads();
+    }
+}
+
 int g_variant = -1;  // -1: read MEMEHIP_GEMM_VARIANT once; 0 = register staging, 1 = LDS-DMA 4 waves, 2 = 256x128 ring,
                      // 3 = ping-pong ring, 4 = LDS-DMA 8 waves (default), 5 = LDS-DMA 16 waves
 
@@ -973,6 +1088,24 @@ int launch_s4(const GemmGroup& g, hipStream_t s) {
     if (LA == 0 && LB == 0 && any_drop) return launch_s4b<LA, LB, true>(g, s);
     return launch_s4b<LA, LB, false>(g, s);
 }
+template <int LB, bool DROP>
+int launch_wide2(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<LB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  W_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_wide_kernel<LB, DROP>), dim3(g.total_tiles), dim3(512), W_LDS, s, g);
+    return mh_launch_status();
+}
+template <int LB>
+int launch_wide(const GemmGroup& g, hipStream_t s) {
+    bool any_drop = false;
+    for (int i = 0; i < g.n; ++i) any_drop |= (g.d[i].p.drop_rng != nullptr && g.d[i].p.drop_p > 0.f);
+    if (LB == 0 && any_drop) return launch_wide2<LB, true>(g, s);
+    return launch_wide2<LB, false>(g, s);
+}
 template <int LA, int LB>
 int launch(const GemmGroup& g, hipStream_t s) {
     if (g_variant == 6) return launch_s4<LA, LB>(g, s);
@@ -995,6 +1128,27 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         if (g_variant < 0 || g_variant > 6) g_variant = 4;
     }
     const int tile_m = (g_variant == 2 || g_variant == 3) ? R_BM : BM;
+    // the wide (128x256) kernel: only the default variant, only K-contiguous A, every N a multiple of 256, and only
+    // when the launch does not take more (twice as long) rounds of 512 resident workgroups than with 128x128 tiles
+    static int wide_mode = -1;       // MEMEHIP_GEMM_WIDE: 0 never (default), 1 dgrad layout by the round count, 2 whenever the shape allows
+    if (wide_mode < 0) {             // in the step it loses either way (10.38 vs 10.21 ms with mode 1, 12.1 with mode 2)
+        const char* e = getenv("MEMEHIP_GEMM_WIDE");
+        wide_mode = e ? atoi(e) : 0;
+    }
+    // (measured: forward layout 620 vs 756 TF/s on FFN up -- slower; dgrad layout 805 vs 723 TF/s on FFN-down dgrad)
+    bool wide = (g_variant == 4) && !a_kmajor && wide_mode > 0 && (b_kmajor || wide_mode == 2);
+    if (wide) {
+        long t4 = 0, t7 = 0;
+        for (int i = 0; i < n_problems; ++i) {
+            const MhGemmProblem& p = problems[i];
+            if (p.N < W_BN || (p.N % W_BN) || p.K < S4_BK || (p.K % S4_BK) || p.M < 1) { wide = false; break; }
+            const long rows = (p.M + BM - 1) / BM;
+            t4 += rows * (p.N / BN);
+            t7 += rows * (p.N / W_BN);
+        }
+        if (wide && wide_mode == 1 && 2 * ((t7 + 511) / 512) > (t4 + 511) / 512) wide = false;
+    }
+    const int tile_n = wide ? W_BN : BN;
     GemmGroup g;
     g.n = n_problems;
     int total = 0;
@@ -1010,10 +1164,10 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         if (p.rowsum && !a_kmajor) return MH_EINVAL;
         if ((p.flags & MH_GEMM_ACCUM) && !(p.flags & MH_GEMM_OUT_F32)) return MH_EINVAL;
         g.d[i].p = p;
-        g.d[i].tiles_n = p.N / BN;
+        g.d[i].tiles_n = p.N / tile_n;
         g.d[i].tile_start = total;
         g.d[i].tiles_m = (p.M + tile_m - 1) / tile_m;
-        total += g.d[i].tiles_m * (p.N / BN);
+        total += g.d[i].tiles_m * (p.N / tile_n);
     }
     g.total_tiles = total;
     static int group_m = -1;
@@ -1024,6 +1178,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     }
     g.group_m = group_m;
     hipStream_t s = (hipStream_t)stream;
+    if (wide) return b_kmajor ? launch_wide<1>(g, s) : launch_wide<0>(g, s);
     if (!a_kmajor && !b_kmajor) return launch<0, 0>(g, s);
     if (!a_kmajor && b_kmajor) return launch<0, 1>(g, s);
     if (a_kmajor && b_kmajor) return launch<1, 1>(g, s);
