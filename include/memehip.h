@@ -280,6 +280,15 @@ int mh_head_bwd(const MhHeadParams* p /*host*/, const MhHeadGrads* g /*host*/, c
                 void* d_image_hidden /*bf16 [B][Nt][Di]*/, int text_pool_index, int B, int S, int Nt,
                 int Dt, int Di, int P, int C, float out_scale, const uint32_t* rng, float drop_p,
                 uint32_t drop_stream, const int32_t* text_rows /*as in mh_head_fwd*/, mh_stream_t stream);
+/* The pooling stage on its own, for heads built outside this library (Kevin's Linear+BatchNorm1d+ReLU projections,
+ * ConcatAttention3, the SVM baseline's feature dump: Multimodal_example_task2C.py:590-641, baselines/extract_feat.py):
+ *   mh_pool_fwd: pooled[b] = [ text_hidden[b][pool or text_rows[b]] , image_hidden[b][0] ]  (f32 [B][Dt+Di])
+ *   mh_pool_bwd: the reverse scatter of d_pooled into the 16-bit hidden-state gradient buffers (times out_scale);
+ *                all other rows must be zero-filled by the caller. */
+int mh_pool_fwd(const float* text_hidden, const float* image_hidden, int text_pool_index, float* pooled, int B, int S,
+                int Nt, int Dt, int Di, const int32_t* text_rows, mh_stream_t stream);
+int mh_pool_bwd(const float* d_pooled, void* d_text_hidden, void* d_image_hidden, int text_pool_index, int B, int S,
+                int Nt, int Dt, int Di, float out_scale, const int32_t* text_rows, mh_stream_t stream);
 int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
                   int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream);
 /* sigmoid focal loss over one logit per sample (torchvision.ops.sigmoid_focal_loss(inputs, targets, alpha, gamma,

@@ -241,6 +241,24 @@ void run_bwd(const HeadBwdJobs& H, hipStream_t s) {
     hipLaunchKernelGGL(head_bwd_stage_kernel, dim3(gx, gy, H.n), dim3(256), 0, s, H);
 }
 
+// gradient of the pooled features back into the hidden-state gradient buffers (16-bit, scaled): the pooled text
+// row of each sample and the ViT class-token row; every other row stays as the caller zero-filled it
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ d_pooled, h16* __restrict__ dth,
+                                                       h16* __restrict__ dih, int B, int S, int Nt, int Dt, int Di,
+                                                       int pool, float scale, const int32_t* __restrict__ text_rows) {
+    const int Dp = Dt + Di;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * Dp) return;
+    const int b = idx / Dp, d = idx % Dp;
+    const float v = d_pooled[idx] * scale;
+    if (d < Dt) {
+        const size_t trow = text_rows ? (size_t)text_rows[b] : (size_t)b * S + pool;
+        dth[trow * Dt + d] = mh_f2bf(v);
+    } else {
+        dih[(size_t)b * Nt * Di + (d - Dt)] = mh_f2bf(v);
+    }
+}
+
 }  // namespace
 
 extern "C" int mh_head_fwd(const MhHeadParams* p, const float* text_hidden, const float* image_hidden,
@@ -318,5 +336,25 @@ extern "C" int mh_focal_fwd_bwd(const float* logits, int ld, const float* target
     const int threads = ((B + 63) / 64) * 64;
     hipLaunchKernelGGL(focal_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, logits, ld, targets, loss, dlogits,
                        n_correct, B, alpha, gamma, grad_scale);
+    return mh_launch_status();
+}
+
+extern "C" int mh_pool_fwd(const float* text_hidden, const float* image_hidden, int text_pool_index, float* pooled, int B,
+                           int S, int Nt, int Dt, int Di, const int32_t* text_rows, mh_stream_t stream) {
+    if (!text_hidden || !image_hidden || !pooled) return MH_EINVAL;
+    if (B < 1 || text_pool_index < 0 || text_pool_index >= S || Nt < 1 || Dt < 1 || Di < 1) return MH_ESHAPE;
+    const int Dp = Dt + Di;
+    hipLaunchKernelGGL(pool_kernel, dim3((B * Dp + 255) / 256), dim3(256), 0, (hipStream_t)stream, text_hidden,
+                       image_hidden, pooled, B, S, Nt, Dt, Di, text_pool_index, nullptr, 0.f, 0u, text_rows);
+    return mh_launch_status();
+}
+
+extern "C" int mh_pool_bwd(const float* d_pooled, void* d_text_hidden, void* d_image_hidden, int text_pool_index, int B,
+                           int S, int Nt, int Dt, int Di, float out_scale, const int32_t* text_rows, mh_stream_t stream) {
+    if (!d_pooled || !d_text_hidden || !d_image_hidden) return MH_EINVAL;
+    if (B < 1 || text_pool_index < 0 || text_pool_index >= S || Nt < 1 || Dt < 1 || Di < 1) return MH_ESHAPE;
+    const int Dp = Dt + Di;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((B * Dp + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_pooled,
+                       (h16*)d_text_hidden, (h16*)d_image_hidden, B, S, Nt, Dt, Di, text_pool_index, out_scale, text_rows);
     return mh_launch_status();
 }

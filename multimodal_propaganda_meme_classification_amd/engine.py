@@ -348,18 +348,21 @@ class Engine:
         self._last_bwd_plan = plan
 
     # ---- plan ----------------------------------------------------------------------------------------------
-    def plan(self, B: int, S: int, training: bool = True, gather_world: int = 0) -> Plan:
+    def plan(self, B: int, S: int, training: bool = True, gather_world: int = 0, features: bool = False) -> Plan:
         """Plans differ between train and eval only when some dropout probability is non-zero.
+        features = True: the plan stops at the pooled tower features (text pooled row | ViT class token, f32) and its
+        backward starts from their gradient: the late-fusion head is then whatever the caller builds on top.
         gather_world = W > 0 (data parallel): the embedding-table gradients are built from the all-gathered token ids
         and embedding-gradient rows of all W ranks (6 MB per rank) instead of all-reducing the dense 196-MB table."""
         cfg = self.cfg
         has_drop = (cfg.text.hidden_dropout > 0 or cfg.text.attention_dropout > 0 or cfg.head_dropout > 0)
-        key = (B, S, bool(training and has_drop), int(gather_world), self.pack_text)
+        key = (B, S, bool(training and has_drop), int(gather_world), self.pack_text, bool(features))
         if key not in self.plans:
-            self.plans[key] = self._build(B, S, key[2], key[3], key[4])
+            self.plans[key] = self._build(B, S, key[2], key[3], key[4], key[5])
         return self.plans[key]
 
-    def _build(self, B: int, S: int, dropout_on: bool = False, gather_world: int = 0, pack: bool = False) -> Plan:
+    def _build(self, B: int, S: int, dropout_on: bool = False, gather_world: int = 0, pack: bool = False,
+               features: bool = False) -> Plan:
         cfg, t, v = self.cfg, self.cfg.text, self.cfg.image
         if S > t.max_position:
             raise ValueError(f"sequence length {S} > max_position {t.max_position}")
@@ -553,8 +556,13 @@ class Engine:
         pooled = alloc("h.pooled", (B, Dt + Di), F32)
         feat, fused = alloc("h.feat", (B, 2 * P_), F32), alloc("h.fused", (B, P_), F32)
         logits = alloc("logits", (B, Cn), F32)
-        f.c("mh_head_fwd", C.byref(hp), _ptr(xt_last32), _ptr(xf32), pool_index, _ptr(pooled), _ptr(feat), _ptr(fused),
-            _ptr(logits), B, S, Nt, Dt, Di, P_, Cn, *site_args(p_head, 7), _ptr(pool_rows))
+        pl.features = features
+        if features:
+            d_pooled = alloc("h.d_pooled", (B, Dt + Di), F32, zero=True)
+            f.c("mh_pool_fwd", _ptr(xt_last32), _ptr(xf32), pool_index, _ptr(pooled), B, S, Nt, Dt, Di, _ptr(pool_rows))
+        else:
+            f.c("mh_head_fwd", C.byref(hp), _ptr(xt_last32), _ptr(xf32), pool_index, _ptr(pooled), _ptr(feat), _ptr(fused),
+                _ptr(logits), B, S, Nt, Dt, Di, P_, Cn, *site_args(p_head, 7), _ptr(pool_rows))
 
         # loss
         loss = alloc("loss", (1,), F32, zero=True)
@@ -580,9 +588,18 @@ class Engine:
         dfeat, dfused = alloc("h.dfeat", (B, 2 * P_), F32), alloc("h.dfused", (B, P_), F32)
         s.py(dXt[0].zero_)
         s.py(dXf.zero_)
-        s.c("mh_head_bwd", C.byref(hp), C.byref(hg), _ptr(dlogits), _ptr(pooled), _ptr(feat), _ptr(fused), _ptr(dfeat),
-            _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale),
-            *site_args(p_head, 7), _ptr(pool_rows))
+        if features:
+            # the built-in head is not part of this graph: its gradient slots must not keep stale values
+            h0 = self.layout.spec["bert_fc.weight"].offset
+            h1 = self.layout.spec["output_fc.bias"].offset + self.layout.spec["output_fc.bias"].numel
+            head_grads = self.G[h0:h1]
+            s.py(head_grads.zero_)
+            s.c("mh_pool_bwd", _ptr(d_pooled), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, float(self.gscale),
+                _ptr(pool_rows))
+        else:
+            s.c("mh_head_bwd", C.byref(hp), C.byref(hg), _ptr(dlogits), _ptr(pooled), _ptr(feat), _ptr(fused), _ptr(dfeat),
+                _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale),
+                *site_args(p_head, 7), _ptr(pool_rows))
         # backward temporaries, one set per layer parity
         T_ = [dict(dh=alloc(f"t.dh{i}", (Tt, It)), da=alloc(f"t.da{i}", (Tt, Dt)),
                    dqkv=alloc(f"t.dqkv{i}", (Tt, 3 * Dt)),

@@ -65,6 +65,24 @@ class _ModelFn(torch.autograd.Function):
         return None, None, None
 
 
+class _EncodeFn(torch.autograd.Function):
+    """Opaque autograd node of the two towers alone: forward = a features plan (stops at the pooled features),
+    backward = its segments, started from the gradient of the pooled features."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, plan):
+        ctx.model, ctx.plan = model, plan
+        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        return plan.buf["h.pooled"].clone()
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        model, plan = ctx.model, ctx.plan
+        plan.buf["h.d_pooled"].copy_(d_pooled.to(F32))
+        model._run_backward(plan)
+        return None, None, None
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, crit):
@@ -295,7 +313,7 @@ class MultimodalClassifier(nn.Module):
         host.copy_(torch.tensor([lo, hi, self._rng_step & 0x7FFFFFFF, 0], dtype=torch.int32))
         plan.buf["rng"].copy_(host, non_blocking=True)
 
-    def _prepare(self, text, image, mask, labels=None) -> Plan:
+    def _prepare(self, text, image, mask, labels=None, features: bool = False) -> Plan:
         eng = self._get_engine()
         if text.dim() != 2 or mask.shape != text.shape:
             raise ValueError("text and mask must be [B, S] int64 tensors of the same shape")
@@ -303,7 +321,7 @@ class MultimodalClassifier(nn.Module):
         v = self.config.image
         if tuple(image.shape) != (B, v.channels, v.image_size, v.image_size):
             raise ValueError(f"image must be [B,{v.channels},{v.image_size},{v.image_size}], got {tuple(image.shape)}")
-        plan = eng.plan(B, S, self.training)
+        plan = eng.plan(B, S, self.training, features=features)
         if self._shadow_stale:
             self.refresh_shadow()
         if self.training:
@@ -333,6 +351,35 @@ class MultimodalClassifier(nn.Module):
         return plan.buf["logits"].clone()
 
     # ---- fused step (no autograd): forward + loss + backward ---------------------------------------------------
+    def encode(self, text, image, mask):
+        """The two towers without the built-in head: returns ``(text_features [B, Dt], image_features [B, Di])`` (f32) --
+        the pooled text token (``pool``) and the ViT class token after the final LayerNorm -- differentiable, so any
+        PyTorch head can sit on top: Kevin's ``Linear + BatchNorm1d + ReLU`` projections, ``ConcatAttention3``, the
+        1-logit ``Linear(512, 1) + BatchNorm1d(1)`` with the focal loss (Multimodal_example_task2C.py:590-685).
+        The built-in head's parameters receive zero gradients on this path."""
+        for t_ in (text, image, mask):
+            if not t_.is_cuda:
+                raise _lib.MemehipError("memehip runs on the HIP device only (no CPU fallback): move the batch with .to(device)")
+        plan = self._prepare(text, image, mask, features=True)
+        Dt = self.config.text.hidden
+        if torch.is_grad_enabled() and self.training:
+            pooled = _EncodeFn.apply(self._params[self._names[0]], self, plan)
+        else:
+            plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+            pooled = plan.buf["h.pooled"].clone()
+        return pooled[:, :Dt], pooled[:, Dt:]
+
+    @torch.no_grad()
+    def get_features(self, text, image, mask):
+        """Forward-only feature dump for the SVM baseline (baselines/extract_feat.py:52-67): dict of f32 tensors."""
+        was = self.training
+        self.eval()
+        try:
+            t_, i_ = self.encode(text, image, mask)
+        finally:
+            self.train(was)
+        return {"text": t_.clone(), "image": i_.clone()}
+
     def forward_backward(self, text, image, mask, labels, grad_hook=None):
         """Returns (loss[1], n_correct[1], logits[B,C]) device tensors; gradients land in .grad."""
         plan = self._prepare(text, image, mask, labels)
