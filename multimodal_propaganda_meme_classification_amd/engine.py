@@ -745,9 +745,32 @@ class Engine:
         # (the patch-projection weight gradient is a 36-tile GEMM with a 6272-deep contraction, 115 us on 14 % of the CUs;
         #  moving it to the side stream beside the table gradients measured 0.12 ms SLOWER per step: it delays the join
         #  in front of the optimizer tail)
-        self._gemm(pl, s, [self._wgrad_prob(i_dproj, patches, self.g(IMG + "embeddings.patch_embeddings.projection.weight"),
-                                            self.g(IMG + "embeddings.patch_embeddings.projection.bias"), B * Np, Di, Kp)],
-                   True, True)
+        gw, gb = self.g(IMG + "embeddings.patch_embeddings.projection.weight"), self.g(IMG + "embeddings.patch_embeddings.projection.bias")
+        Tp = B * Np
+        nsplit = min(_lib.MH_GEMM_MAX_GROUP, max(1, Tp // 512))
+        if nsplit > 1:
+            # split-K: the contraction over B*Np patches is cut into `nsplit` grouped problems with their own f32
+            # outputs (288 tiles instead of 36), summed in a fixed order by the partial-sum kernel
+            chunk = -(-Tp // nsplit)
+            chunk = -(-chunk // 8) * 8
+            part_w = alloc("i.dwp_part", (2, nsplit, Di * Kp), F32)       # [which][split][Di*Kp]; which = 1 unused
+            part_b = alloc("i.dbp_part", (2, nsplit, Di), F32)
+            probs = []
+            for i in range(nsplit):
+                k0 = i * chunk
+                kk = min(chunk, Tp - k0)
+                if kk <= 0:
+                    part_w[0, i].zero_(), part_b[0, i].zero_()
+                    continue
+                probs.append(self._wgrad_prob(i_dproj[k0:], patches[k0:], part_w[0, i], part_b[0, i], kk, Di, Kp))
+            self._gemm(pl, s, probs, True, True)
+            for part, out, D_ in ((part_w, gw, Di * Kp), (part_b, gb, Di)):
+                arr = (MhColsumJob * 1)()
+                arr[0].part, arr[0].out0, arr[0].out1 = _ptr(part), _ptr(out), None
+                pl.keep.append(arr)
+                s.c("mh_colsum_partials_f32", arr, 1, nsplit, D_, 1.0)
+        else:
+            self._gemm(pl, s, [self._wgrad_prob(i_dproj, patches, gw, gb, Tp, Di, Kp)], True, True)
         if gather_world <= 0:
             table_grads(s, ids, t_dpre, prev_ids, B)
         # finish every LayerNorm's dgamma / dbeta from the partials
