@@ -223,6 +223,9 @@ int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre /*bf16 [T][D]*/, flo
                       float* dpos /*[P][D]*/, float* dtype0 /*[D] or NULL*/, int B, int S, int D,
                       int vocab, int64_t pad_id, float scale,
                       uint8_t* row_live /*[V] or NULL: set to 1 for every table row that receives a gradient*/,
+                      int32_t* first_pos /*[V], all INT32_MAX*/, int32_t* id_count /*[V], all 0*/
+                      /* both NULL, or a persistent id index (restored to INT32_MAX / 0 on return): makes the duplicate-id
+                         sum linear in the token count instead of quadratic -- the gathered batch of 8 ranks has 32 768 ids */,
                       mh_stream_t stream);
 /* Dropout helpers.  mh_dropout_apply: x[i] *= mask(i)/(1-p) in place (16-bit), e.g. the gradient arriving at a
  * dropped activation.  mh_dropout_mask_u8: the 0/1 mask a site would use for element indices 0..n-1 (tests). */

@@ -130,6 +130,104 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const int64_t*
     }
 }
 
+// ---- the same gradient with an id index (first occurrence + multiplicity per vocabulary row), linear in T:
+// pass 1 marks, for every id of the batch, its first position (atomicMin) and how often it occurs; pass 2 lets the
+// first occurrence own the row: a unique id just converts its own d_pre row, a repeated id walks the later positions
+// (four 64-id chunks in flight) until it has found all its duplicates -- summed in position order, so the result is
+// the same bitwise-reproducible sum as above.  The owner restores the index entries (INT_MAX / 0) for the next call.
+__global__ __launch_bounds__(256) void bert_embed_index_kernel(const int64_t* __restrict__ ids, int T, int vocab,
+                                                               int64_t pad_id, int32_t* __restrict__ first,
+                                                               int32_t* __restrict__ count) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int64_t id = ids[t];
+    if (id == pad_id || id < 0 || id >= vocab) return;
+    atomicMin(&first[id], t);
+    atomicAdd(&count[id], 1);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void bert_embed_bwd_word_indexed_kernel(const int64_t* __restrict__ ids,
+                                                                          const h16* __restrict__ d_pre,
+                                                                          float* __restrict__ dword, int T, int D,
+                                                                          int vocab, int64_t pad_id, float scale,
+                                                                          uint8_t* __restrict__ row_live,
+                                                                          int32_t* __restrict__ first,
+                                                                          int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int64_t id = ids[t];
+    if (id == pad_id || id < 0 || id >= vocab) return;
+    if (first[id] != t) return;                  // a later occurrence: the first one sums it
+    int todo = count[id] - 1;                    // duplicates still to find
+    float acc[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+    // rows are fetched four at a time (independent loads) and added in position order: ids such as [CLS] / [SEP]
+    // occur once per sequence, so their owner sums B rows
+    int pend[4], npend = 0;
+    auto flush = [&]() {
+        Pack8 u[4][NCH];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const h16* row = d_pre + (size_t)pend[k < npend ? k : 0] * D;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = (lane + 64 * i) * 8;
+                u[k][i].v = i32x4{0, 0, 0, 0};
+                if (c < D && k < npend) u[k][i].v = *(const i32x4*)(row + c);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][e] += mh_bf2f(u[k][i].e[e]);     // zero rows (k >= npend) add +0
+        npend = 0;
+    };
+    pend[0] = t;
+    npend = 1;
+    for (int c0 = (t / 64) * 64; todo > 0 && c0 < T; c0 += 256) {
+        unsigned long long m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = c0 + 64 * k + lane;
+            const bool hit = (j > t) && (j < T) && (ids[j] == id);
+            m[k] = __ballot(hit);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned long long mm = m[k];
+            while (mm) {
+                const int bit = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                pend[npend++] = c0 + 64 * k + bit;
+                if (npend == 4) flush();
+                --todo;
+            }
+        }
+    }
+    if (npend > 0) flush();
+    float* out = dword + (size_t)id * D;
+    if (lane == 0) {
+        if (row_live) row_live[id] = 1;
+        first[id] = 0x7fffffff;
+        count[id] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            *(f32x4*)(out + c) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]} * scale;
+            *(f32x4*)(out + c + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]} * scale;
+        }
+    }
+}
+
 // dpos[s] = sum_b d[b][s]  (rows: tokens per sample = S, B samples).  One workgroup per position s: the four waves
 // take the samples b = w, w+4, ... (independent 16-B loads, four in flight per wave) and are summed in wave order
 // through LDS -- a fixed order, so the result is bitwise reproducible.
@@ -327,13 +425,21 @@ extern "C" int mh_bert_embed_fwd(const int64_t* ids, const float* word, const fl
 
 extern "C" int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre, float* dword, float* dpos, float* dtype0,
                                  int B, int S, int D, int vocab, int64_t pad_id, float scale, uint8_t* row_live,
-                                 mh_stream_t stream) {
+                                 int32_t* first_pos, int32_t* id_count, mh_stream_t stream) {
     if (!ids || !d_pre || !dword || !dpos) return MH_EINVAL;
+    if ((first_pos == nullptr) != (id_count == nullptr)) return MH_EINVAL;
     if (B < 1 || S < 1 || D < 8 || (D % 8) || D > 4096 || vocab < 1) return MH_ESHAPE;
     const int T = B * S;
     hipStream_t s = (hipStream_t)stream;
-    NCH_DISPATCH(bert_embed_bwd_word_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, (const h16*)d_pre, dword, T,
-                 D, vocab, pad_id, scale, row_live);
+    if (first_pos) {
+        hipLaunchKernelGGL(bert_embed_index_kernel, dim3((T + 255) / 256), dim3(256), 0, s, ids, T, vocab, pad_id,
+                           first_pos, id_count);
+        NCH_DISPATCH(bert_embed_bwd_word_indexed_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, (const h16*)d_pre,
+                     dword, T, D, vocab, pad_id, scale, row_live, first_pos, id_count);
+    } else {
+        NCH_DISPATCH(bert_embed_bwd_word_kernel, dim3((T + 3) / 4), dim3(256), 0, s, ids, (const h16*)d_pre, dword, T,
+                     D, vocab, pad_id, scale, row_live);
+    }
     NCH_DISPATCH(sum_over_batch_kernel, dim3(S), dim3(256), 0, s, (const h16*)d_pre, dpos, B, S, D, scale);
     if (dtype0)
         hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((D + 63) / 64), dim3(256), 0, s, dpos, dtype0, S, D);

@@ -183,6 +183,9 @@ class Engine:
         # one byte per word-embedding row: has it ever received a gradient?  (rows that have not keep g = m = v = 0,
         # for which Adam is the identity: model.Adam skips them, mh_adam_step_rows)
         self.word_row_live = torch.zeros(cfg.text.vocab_size, dtype=torch.uint8, device=self.dev)
+        # id index of the embedding-gradient kernel (first position / multiplicity per vocabulary row; self-restoring)
+        self.word_first = torch.full((cfg.text.vocab_size,), 0x7fffffff, dtype=torch.int32, device=self.dev)
+        self.word_count = torch.zeros(cfg.text.vocab_size, dtype=torch.int32, device=self.dev)
 
     # ---- parameter / gradient views -----------------------------------------------------------------
     def _slice(self, flat: torch.Tensor, name: str, count: int = 1) -> torch.Tensor:
@@ -736,7 +739,8 @@ class Engine:
             # dense-Adam semantics: the table gradient is dense; only rows touched last step need re-zeroing
             sg.c("mh_zero_rows_f32", _ptr(prev_), _ptr(gword), nb * S, Dt, t.vocab_size)
             sg.c("mh_bert_embed_bwd", _ptr(ids_), _ptr(dpre_), _ptr(gword), _ptr(gpos), _ptr(gtype0), nb, S, Dt, t.vocab_size,
-                 int(t.pad_token_id), 1.0 / self.gscale, self.word_row_live.data_ptr())
+                 int(t.pad_token_id), 1.0 / self.gscale, self.word_row_live.data_ptr(), self.word_first.data_ptr(),
+                 self.word_count.data_ptr())
             sg.py(lambda: prev_.copy_(ids_))
 
         i_dproj = alloc("i.dproj", (B * Np, Di))

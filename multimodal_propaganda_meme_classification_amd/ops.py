@@ -341,13 +341,15 @@ def bert_embed_fwd(ids, word, pos, type0, gamma, beta, eps, pre, y, mean, rstd, 
                                         D, V, float(eps), *_drop(drop), _stream()), "mh_bert_embed_fwd")
 
 
-def bert_embed_bwd(ids, d_pre, dword, dpos, dtype0, pad_id: int, scale: float = 1.0, row_live=None):
+def bert_embed_bwd(ids, d_pre, dword, dpos, dtype0, pad_id: int, scale: float = 1.0, row_live=None, index=None):
+    """index = (first_pos int32[V] filled with INT32_MAX, id_count int32[V] zeros) selects the linear-time kernel."""
     _chk(ids, I64, "ids"), _chk(d_pre, BF16, "d_pre"), _chk(dword, F32, "dword"), _chk(dpos, F32, "dpos")
     B, S = ids.shape
     V, D = dword.shape
     assert d_pre.numel() >= B * S * D and dpos.shape[0] >= S
     check(_L(d_pre).mh_bert_embed_bwd(_p(ids), _p(d_pre), _p(dword), _p(dpos), _p(dtype0), B, S, D, V, int(pad_id),
-                                      float(scale), _p(row_live), _stream()), "mh_bert_embed_bwd")
+                                      float(scale), _p(row_live), _p(index[0]) if index else None,
+                                      _p(index[1]) if index else None, _stream()), "mh_bert_embed_bwd")
 
 
 def zero_rows(ids, table):

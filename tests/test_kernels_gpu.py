@@ -275,6 +275,31 @@ def test_embed_bwd_over_gathered_ranks_equals_sum_of_ranks(ops):
     close(at, tot_t, 1e-5, 1e-4, "gathered dtype0")
 
 
+def test_embed_bwd_indexed_kernel_is_bit_identical_and_restores_its_index(ops):
+    """The linear-time embedding gradient (first-position / multiplicity index per vocabulary row) sums duplicates in
+    the same position order as the owner-scan kernel: bit-identical tables; the index is INT32_MAX / 0 again after."""
+    for (B, S, D, V) in ((3, 16, 128, 40), (64, 128, 256, 500), (8, 512, 768, 64000)):
+        g = torch.Generator().manual_seed(B + S)
+        ids = torch.randint(0, V, (B, S), generator=g).to(dev())
+        ids[:, S // 2:] = torch.where(torch.rand((B, S - S // 2), generator=g).to(dev()) < 0.5, 0, ids[:, S // 2:])   # PAD
+        ids[:, 0] = 2                                                                                               # CLS everywhere
+        d_pre = rnd(B * S, D, seed=3)
+        first = torch.full((V,), 0x7fffffff, dtype=torch.int32, device=dev())
+        count = torch.zeros(V, dtype=torch.int32, device=dev())
+        live = torch.zeros(V, dtype=torch.uint8, device=dev())
+        a, b = torch.zeros((V, D), device=dev()), torch.zeros((V, D), device=dev())
+        pa, pb = torch.zeros((S, D), device=dev()), torch.zeros((S, D), device=dev())
+        ops.bert_embed_bwd(ids, d_pre, a, pa, None, 0)
+        for _ in range(2):          # twice: the second call runs on the restored index
+            b.zero_()
+            ops.bert_embed_bwd(ids, d_pre, b, pb, None, 0, row_live=live, index=(first, count))
+            torch.cuda.synchronize()
+            assert torch.equal(a, b) and torch.equal(pa, pb)
+            assert int((first != 0x7fffffff).sum()) == 0 and int(count.abs().sum()) == 0
+        used = torch.unique(ids[ids != 0])
+        assert int(live.sum()) == used.numel() and bool(live[used.long()].all())
+
+
 def test_patchify_bit_exact_and_assemble(ops, golden_dir):
     z = np.load(os.path.join(golden_dir, "index_fixtures.npz"))
     img = torch.from_numpy(z["counting_image"]).to(dev())
