@@ -281,3 +281,35 @@ def test_grouped_attention_equals_separate_launches(pkg, dtype, packed):
             n = int(plan["n_rows"]) if packed else B * St
             assert torch.equal(pi["out"], oi) and torch.equal(pi["dqkv"], di)
             assert torch.equal(pt["out"][:n], ot[:n]) and torch.equal(pt["dqkv"][:n], dt[:n])
+
+
+def test_one_graph_serves_batches_with_different_masks(pkg):
+    """The packed plan is captured ONCE into a hipGraph; the live row count is read on the device at replay time, so
+    batches with other attention masks (other numbers of live rows) replay the same graph.  Must equal the eager
+    autograd-style loop step for step (same kernels, same order: bit-identical parameters)."""
+    O = _oracle()
+    cfg = O.tiny_config("cls")
+    B, S = 6, 32
+    m_graph, _, _ = _tiny(pkg, O, "cls", seed=5)
+    m_eager, _, _ = _tiny(pkg, O, "cls", seed=5)
+    o_graph = pkg.Adam(m_graph.parameters(), lr=1e-3, model=m_graph)
+    o_eager = pkg.Adam(m_eager.parameters(), lr=1e-3, model=m_eager)
+    gs = pkg.GraphedStep(m_graph, o_graph, B, S, use_graph=True)
+    live = []
+    for step, kind in enumerate(["prefix", "ones", "holes", "single", "prefix"]):
+        text, image, _, labels = O.synthetic_batch(cfg, B, S, seed=50 + step)
+        mask = torch.from_numpy(_masks(B, S, kind, 70 + step))
+        mask[:, 0] = 1
+        text = text * mask
+        dev = [t.cuda() for t in (text, image, mask, labels)]
+        gs.load_batch(*dev)
+        loss_g, _ = gs.step()
+        m_eager.train()
+        loss_e, _, _ = m_eager.forward_backward(*dev)
+        o_eager.step()
+        torch.cuda.synchronize()
+        live.append(int(gs.plan.buf["pk.n_rows"]))
+        assert live[-1] == int(mask.sum())
+        assert float(loss_g) == float(loss_e), (step, kind)
+        assert torch.equal(m_graph.flat_params, m_eager.flat_params), (step, kind)
+    assert len(set(live)) >= 4 and gs.graphs is not None and len(gs.graphs) == 1       # ONE captured graph for all of them
