@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="tiny model (debug only; not a bench line)")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-overlap-opt", action="store_true", help="A/B: whole Adam update after the backward")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="debug: run the data-parallel code path (segmented graphs, RCCL all-reduce) on a 1-rank group")
     ap.add_argument("--dense-text", action="store_true",
                     help="A/B: compute every padded text position like the reference does (default: padding-free text tower)")
     ap.add_argument("--full-masks", action="store_true", help="all-ones attention masks (SURVEY 8d's second input variant)")
@@ -104,9 +106,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29577")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
     import multimodal_propaganda_meme_classification_amd as pkg
     from multimodal_propaganda_meme_classification_amd import ddp
@@ -121,7 +127,7 @@ def main():
     model = pkg.MultimodalClassifier.from_config(cfg, device=device, seed=0)
     model.train()
     reducer = None
-    if world > 1:
+    if world > 1 or args.force_ddp:
         ddp.broadcast_parameters(model.flat_params)
         model.mark_weights_changed()
         reducer = ddp.GradientReducer(model.flat_grads)
@@ -203,7 +209,7 @@ def main():
                                    + (" [TINY DEBUG MODEL]" if args.tiny else ""),
                        "global_batch": args.batch * world, "seq_len": args.seq, "image": "3x224x224",
                        "params": model.layout.n_total, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else ("hipGraph" if world == 1 else "hipGraph per backward segment + RCCL all-reduce"),
+                       "launch": "eager" if args.no_graph else ("hipGraph" if reducer is None else "hipGraph per backward segment + RCCL all-reduce"),
                        "kernel_launches_per_step": plan.n_launches, "final_loss": round(final_loss, 5),
                        "masks": "all ones" if args.full_masks else "ragged, valid length ~ U{8..seq} (SURVEY 8d)",
                        "text_rows": (f"padding-free: {live_rows} of {max_rows} token rows live on rank 0 (attention_mask != 0), "
@@ -222,7 +228,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.seq, args.tiny)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -26,15 +26,18 @@ class GradientReducer:
         self.reduced_elems = 0
 
     def reduce_range(self, rng: Optional[Tuple[int, int]]):
-        """Start the all-reduce (SUM) of G[start:end]; returns immediately."""
+        """Start the all-reduce (SUM) of G[start:end]; returns immediately with the list of work handles started."""
+        started: List = []
         if rng is None or not dist.is_initialized():
-            return
+            return started
         a, b = rng
         while a < b:
             e = min(b, a + self.cap)
-            self.pending.append(dist.all_reduce(self.G[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            started.append(dist.all_reduce(self.G[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.reduced_elems += e - a
             a = e
+        self.pending += started
+        return started
 
     def hook(self, seg_name: str, rng: Optional[Tuple[int, int]]):
         self.reduce_range(rng)

@@ -603,6 +603,10 @@ class GraphedStep:
         # GEMMs on the side stream, under the (MFMA-bound) backward chain of the layers below; only the tail
         # (embeddings, biases, head) is updated after the backward.  Needs no global clip and a single GPU.
         self.opt_in_bwd = bool(overlap_optimizer and self.side is not None and optimizer.max_grad_norm is None)
+        # data parallel: the same idea behind the all-reduce -- as soon as a layer pair's gradient slice has been summed
+        # over the ranks, its Adam update runs on a side stream under the backward of the layers below
+        self.ddp_opt_in_bwd = bool(overlap_optimizer and reducer is not None and optimizer.max_grad_norm is None)
+        self.ddp_side = torch.cuda.Stream() if self.ddp_opt_in_bwd else None
 
     # ---- pieces ------------------------------------------------------------------------------------------
     def _pieces(self):
@@ -642,8 +646,22 @@ class GraphedStep:
                     main.wait_event(ev)
                 self._opt_done = done
             pieces.append(("bwd", bwd, None))
+        if self.ddp_opt_in_bwd:
+            self._opt_done = [p.bucket_after[seg.name] for seg in p.bwd
+                              if seg.name.startswith("bwd_layer_") and p.bucket_after.get(seg.name) is not None]
         pieces.append(("opt", lambda stream: self.opt.launch(skip=getattr(self, "_opt_done", None)), None))
         return pieces
+
+    def _after_segment(self, name, rng):
+        """Data parallel: start the all-reduce of the gradient slice a segment completed and, behind it on the side
+        stream, that slice's Adam update."""
+        works = self.reducer.reduce_range(rng)
+        if self.ddp_opt_in_bwd and rng is not None and name.startswith("bwd_layer_"):
+            self.ddp_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.ddp_side):
+                for w in works:
+                    w.wait()
+                self.opt.launch(only=rng)
 
     def _run_eager(self):
         stream = torch.cuda.current_stream().cuda_stream
@@ -655,7 +673,9 @@ class GraphedStep:
                 self.reducer.wait()
             fn(stream)
             if self.reducer is not None:
-                self.reducer.reduce_range(rng)
+                self._after_segment(name, rng)
+        if self.ddp_side is not None:
+            torch.cuda.current_stream().wait_stream(self.ddp_side)
 
     def load_batch(self, text, image, mask, labels):
         b = self.plan.buf
@@ -687,7 +707,9 @@ class GraphedStep:
                     self.reducer.wait()
                 g.replay()
                 if self.reducer is not None:
-                    self.reducer.reduce_range(rng)
+                    self._after_segment(name, rng)
+            if self.ddp_side is not None:
+                torch.cuda.current_stream().wait_stream(self.ddp_side)
         return self.plan.buf["loss"], self.plan.buf["ncorrect"]
 
     def _capture(self):

@@ -246,9 +246,11 @@ def test_config3_logits_match_golden_and_oracle(pkg, golden_dir):
     print("worst relative grad error", name, worst)
 
 
-def test_ddp_segmented_graph_path_world1(pkg):
+@pytest.mark.parametrize("clip", [1.0, None])
+def test_ddp_segmented_graph_path_world1(pkg, clip):
     """The N > 1 code path (one hipGraph per backward segment, bucketed async all-reduce between them, 1/world
-    folded into Adam) on a 1-rank RCCL group: must reproduce the single-graph step bit for bit."""
+    folded into Adam; without clipping: each slice's Adam update on a side stream behind its all-reduce) on a
+    1-rank RCCL group: must reproduce the single-graph step bit for bit."""
     import torch.distributed as dist
     from multimodal_propaganda_meme_classification_amd import ddp
     O = _oracle()
@@ -256,17 +258,18 @@ def test_ddp_segmented_graph_path_world1(pkg):
     text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=11)
     dev = [t.cuda() for t in (text, image, mask, labels)]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    os.environ["MASTER_PORT"] = str(29600 + (os.getpid() + (0 if clip else 151)) % 300)      # a fresh port per group
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         m1, _ = _make(pkg, O, cfg, 13)
         m2, _ = _make(pkg, O, cfg, 13)
-        o1 = pkg.Adam(m1.parameters(), lr=LR, max_grad_norm=1.0)
-        o2 = pkg.Adam(m2.parameters(), lr=LR, max_grad_norm=1.0)
+        o1 = pkg.Adam(m1.parameters(), lr=LR, max_grad_norm=clip)
+        o2 = pkg.Adam(m2.parameters(), lr=LR, max_grad_norm=clip)
         ddp.broadcast_parameters(m2.flat_params)
         red = ddp.GradientReducer(m2.flat_grads, bucket_cap_elems=1 << 16)
         g1 = pkg.GraphedStep(m1, o1, 4, 16)
         g2 = pkg.GraphedStep(m2, o2, 4, 16, reducer=red)
+        assert g2.ddp_opt_in_bwd == (clip is None)
         end = ddp.check_bucket_cover(g2.plan.bucket_after, m2.layout.n_total)
         assert end == m2.layout.spec["bert.embeddings.token_type_embeddings.weight"].offset   # tables go by gather
         for _ in range(3):
