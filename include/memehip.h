@@ -227,6 +227,12 @@ int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre /*bf16 [T][D]*/, flo
                       /* both NULL, or a persistent id index (restored to INT32_MAX / 0 on return): makes the duplicate-id
                          sum linear in the token count instead of quadratic -- the gathered batch of 8 ranks has 32 768 ids */,
                       mh_stream_t stream);
+/* Input pipeline on the device: ToTensor + Normalize of the reference transform
+ * (Multimodal_example_task2C.txt:37-41) from decoded / resized / cropped uint8 pixels.
+ *   src uint8 [B][H][W][3] (device) -> dst f32 [B][3][H][W] = (src/255 - mean[c]) / std[c]; W % 4 == 0; bit-exact
+ *   with torchvision's float32 arithmetic.  mean / std: three host floats each. */
+int mh_image_normalize_u8(const uint8_t* src, float* dst, int B, int H, int W, const float* mean3 /*host*/,
+                          const float* std3 /*host*/, mh_stream_t stream);
 /* Dropout helpers.  mh_dropout_apply: x[i] *= mask(i)/(1-p) in place (16-bit), e.g. the gradient arriving at a
  * dropped activation.  mh_dropout_mask_u8: the 0/1 mask a site would use for element indices 0..n-1 (tests). */
 int mh_dropout_apply(void* x, int64_t n, const uint32_t* rng, float p, uint32_t stream_id, mh_stream_t stream);

@@ -633,3 +633,50 @@ extern "C" int mh_unpack_rows(const void* src, const int32_t* inv_map, void* dst
                        inv_map, (h16*)dst, max_rows, D);
     return mh_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Input pipeline on the device: ToTensor + Normalize of the reference's transform
+// (Multimodal_example_task2C.txt:37-41: x/255 then (x - mean)/std per channel) from the decoded, resized and cropped
+// uint8 image.  The host ships 1 byte per sample instead of 4 and no longer spends a core on the arithmetic.
+// Same float32 operations in the same order as torchvision (IEEE division): bit-exact.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void image_normalize_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                              int B, int H, int W, float m0, float m1, float m2, float s0,
+                                                              float s1, float s2) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;     // one group of 4 pixels of a row
+    const int w4 = W / 4;
+    const size_t total = (size_t)B * H * w4;
+    if (q >= total) return;
+    const int x4 = (int)(q % w4);
+    const size_t by = q / w4;                  // b * H + y
+    const int y = (int)(by % H);
+    const size_t b = by / H;
+    const uint8_t* p = src + (by * W + (size_t)x4 * 4) * 3;
+    const i32x2 lo = *(const i32x2*)p;          // 12 bytes: 4 pixels x RGB (rows are 12-byte multiples, base 16-B aligned)
+    const int hi = *(const int*)(p + 8);
+    uint8_t px[12];
+    *(i32x2*)px = lo;
+    *(int*)(px + 8) = hi;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ((float)px[3 * k + c] / 255.0f - mean[c]) / sd[c];
+        *(f32x4*)(dst + ((b * 3 + c) * H + y) * (size_t)W + (size_t)x4 * 4) = v;
+    }
+}
+}  // namespace
+
+extern "C" int mh_image_normalize_u8(const uint8_t* src, float* dst, int B, int H, int W, const float* mean3_host,
+                                     const float* std3_host, mh_stream_t stream) {
+    if (!src || !dst || !mean3_host || !std3_host) return MH_EINVAL;
+    if (B < 1 || H < 1 || W < 4 || (W % 4)) return MH_ESHAPE;
+    if (((uintptr_t)src & 3) || ((uintptr_t)dst & 15)) return MH_EINVAL;
+    const size_t total = (size_t)B * H * (W / 4);
+    hipLaunchKernelGGL(image_normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, B, H, W, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1],
+                       std3_host[2]);
+    return mh_launch_status();
+}

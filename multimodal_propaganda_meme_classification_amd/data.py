@@ -70,6 +70,32 @@ class HashTokenizer:
         return {"input_ids": torch.tensor([ids], dtype=torch.long), "attention_mask": torch.tensor([mask], dtype=torch.long)}
 
 
+def load_image_u8(path: str, image_size: int = 224, resize: int = 256) -> torch.Tensor:
+    """Resize(256) -> CenterCrop(224) only: uint8 [H, W, 3].  ToTensor + Normalize then run on the device
+    (``normalize_images``): the host ships a quarter of the bytes and skips the float arithmetic."""
+    from PIL import Image
+    img = Image.open(path).convert("RGB")
+    w, h = img.size
+    if w <= h:
+        nw, nh = resize, max(1, int(round(h * resize / w)))
+    else:
+        nw, nh = max(1, int(round(w * resize / h))), resize
+    img = img.resize((nw, nh), Image.BILINEAR)
+    left, top = (nw - image_size) // 2, (nh - image_size) // 2
+    img = img.crop((left, top, left + image_size, top + image_size))
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(img, dtype=np.uint8)))
+
+
+def normalize_images(images: torch.Tensor) -> torch.Tensor:
+    """Batch of images as the Dataset yields them -> f32 [B,3,H,W] on the device.  uint8 [B,H,W,3] batches
+    (``MultimodalDataset(..., device_normalize=True)``) get ToTensor + Normalize(ImageNet) from a HIP kernel, bit-exact
+    with the host transform; float batches pass through."""
+    if images.dtype != torch.uint8:
+        return images
+    from . import ops
+    return ops.image_normalize_u8(images.contiguous(), IMAGENET_MEAN, IMAGENET_STD)
+
+
 def load_image(path: str, image_size: int = 224, resize: int = 256) -> torch.Tensor:
     """PIL restatement of Resize(256) -> CenterCrop(224) -> ToTensor -> Normalize(ImageNet)."""
     from PIL import Image
@@ -99,7 +125,8 @@ class MultimodalDataset(Dataset):
 
     def __init__(self, ids: Sequence, text_data: Sequence, image_data: Sequence, labels: Optional[Sequence],
                  is_test: bool = False, tokenizer=None, max_seq_len: int = 128, image_size: int = 224,
-                 image_root: str = "", synthetic_images: bool = False, vocab_size: int = 64000):
+                 image_root: str = "", synthetic_images: bool = False, vocab_size: int = 64000,
+                 device_normalize: bool = False):
         self.ids = list(ids)
         self.text_data = list(text_data)
         self.image_data = list(image_data)
@@ -110,6 +137,7 @@ class MultimodalDataset(Dataset):
         self.image_size = image_size
         self.image_root = image_root
         self.synthetic_images = synthetic_images
+        self.device_normalize = device_normalize      # yield uint8 [H,W,3]; ToTensor + Normalize run on the device
 
     def __len__(self):
         return len(self.ids)
@@ -121,7 +149,7 @@ class MultimodalDataset(Dataset):
                                          return_tensors="pt")
         path = os.path.join(self.image_root, self.image_data[index])
         if os.path.exists(path):
-            image = load_image(path, self.image_size)
+            image = (load_image_u8 if self.device_normalize else load_image)(path, self.image_size)
         elif self.synthetic_images:
             image = synthetic_image(str(id_), self.image_size)
         else:

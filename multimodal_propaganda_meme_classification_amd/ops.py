@@ -358,6 +358,19 @@ def zero_rows(ids, table):
     check(_lib.load().mh_zero_rows_f32(_p(ids), _p(table), ids.numel(), D, V, _stream()), "mh_zero_rows_f32")
 
 
+def image_normalize_u8(images_u8, mean, std, out=None):
+    """uint8 [B,H,W,3] (device) -> f32 [B,3,H,W] = (x/255 - mean)/std: ToTensor + Normalize on the device."""
+    if not (images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+            and images_u8.is_contiguous()):
+        raise _lib.MemehipError("image_normalize_u8: expected a contiguous uint8 [B,H,W,3] tensor on the HIP device")
+    B, H, W, _ = images_u8.shape
+    out = torch.empty((B, 3, H, W), dtype=F32, device=images_u8.device) if out is None else _chk(out, F32, "out")
+    m = (C.c_float * 3)(*[float(x) for x in mean])
+    sd = (C.c_float * 3)(*[float(x) for x in std])
+    check(_lib.load().mh_image_normalize_u8(_p(images_u8), _p(out), B, H, W, m, sd, _stream()), "mh_image_normalize_u8")
+    return out
+
+
 def patchify(image, patch: int, out=None, dtype=BF16):
     _chk(image, F32, "image")
     B, Cc, H, W = image.shape

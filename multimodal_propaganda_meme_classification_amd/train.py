@@ -13,7 +13,7 @@ from typing import Tuple
 
 import torch
 
-from .data import id2l
+from .data import id2l, normalize_images
 
 
 def train(model, train_loader, criterion, optimizer, device, sync_every_step: bool = False) -> Tuple[float, float]:
@@ -23,7 +23,7 @@ def train(model, train_loader, criterion, optimizer, device, sync_every_step: bo
     for data in train_loader:
         optimizer.zero_grad()
         text = data["text"].to(device)
-        image = data["image"].to(device)
+        image = normalize_images(data["image"].to(device, non_blocking=True))
         mask = data["text_mask"].to(device)
         labels = data["label"].to(device)
         output = model(text, image, mask)
@@ -46,7 +46,7 @@ def test(model, test_loader, criterion, device) -> Tuple[float, float]:
     with torch.no_grad():
         for data in test_loader:
             text = data["text"].to(device)
-            image = data["image"].to(device)
+            image = normalize_images(data["image"].to(device, non_blocking=True))
             mask = data["text_mask"].to(device)
             labels = data["label"].to(device)
             output = model(text, image, mask)
@@ -64,7 +64,7 @@ def evaluate(model, test_loader, device, out_path: str = "task2C_TeamName.tsv", 
     with torch.no_grad():
         for data in test_loader:
             text = data["text"].to(device)
-            image = data["image"].to(device)
+            image = normalize_images(data["image"].to(device, non_blocking=True))
             mask = data["text_mask"].to(device)
             output = model(text, image, mask)
             _, predicted = torch.max(output, 1)

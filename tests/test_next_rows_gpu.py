@@ -208,3 +208,33 @@ def test_encode_with_external_head_matches_oracle(pool, head_kind):
     feats = model.get_features(text.cuda(), image.cuda(), mask.cuda())
     assert feats["text"].shape == (16, cfg.text.hidden) and feats["image"].shape == (16, cfg.image.hidden)
     assert model.training
+
+
+def test_device_side_totensor_normalize_is_bit_exact(tmp_path):
+    """ToTensor + Normalize on the device from the resized / cropped uint8 pixels must give the
+    host transform's float32 values bit for bit (Multimodal_example_task2C.txt:37-41), also through the Dataset."""
+    import multimodal_propaganda_meme_classification_amd as pkg
+    from multimodal_propaganda_meme_classification_amd import data as D, ops
+    g = torch.Generator().manual_seed(4)
+    u8 = torch.randint(0, 256, (5, 224, 224, 3), generator=g, dtype=torch.uint8)
+    u8[0] = 0
+    u8[1] = 255
+    mean = torch.tensor(D.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(D.IMAGENET_STD).view(1, 3, 1, 1)
+    ref = (torch.from_numpy(u8.numpy().astype(np.float32) / 255.0).permute(0, 3, 1, 2) - mean) / std
+    got = pkg.normalize_images(u8.cuda())
+    assert got.dtype == torch.float32 and tuple(got.shape) == (5, 3, 224, 224)
+    assert torch.equal(got.cpu(), ref)
+    assert pkg.normalize_images(ref.cuda()).data_ptr() != 0          # float batches pass through
+    with pytest.raises(pkg.MemehipError):
+        ops.image_normalize_u8(u8, D.IMAGENET_MEAN, D.IMAGENET_STD)  # CPU tensor: no fallback
+    # through the Dataset, from an image file
+    from PIL import Image
+    arr = torch.randint(0, 256, (300, 400, 3), generator=g, dtype=torch.uint8).numpy()
+    Image.fromarray(arr).save(tmp_path / "m.png")
+    host = D.load_image(str(tmp_path / "m.png"))
+    ds = pkg.MultimodalDataset(["a"], ["some text"], ["m.png"], [0], image_root=str(tmp_path), device_normalize=True)
+    item = ds[0]
+    assert item["image"].dtype == torch.uint8 and tuple(item["image"].shape) == (224, 224, 3)
+    dev = pkg.normalize_images(item["image"][None].cuda())[0].cpu()
+    assert torch.equal(dev, host)
