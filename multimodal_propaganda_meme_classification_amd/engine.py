@@ -49,14 +49,6 @@ class Segment:
         """On a multi-stream run: the main stream waits for the lane-1 work of segment `key`."""
         self.calls.append((None, key, "wait", "wait", 0.0, 0))
 
-    def fork(self):
-        """Marks the point on the main stream that the next lane-2 calls depend on."""
-        self.calls.append((None, None, "fork", "fork", 0.0, 0))
-
-    def join(self):
-        """The main stream waits for every lane-2 call issued since the last join."""
-        self.calls.append((None, None, "join", "join", 0.0, 0))
-
     def run(self, stream: int):
         for fn, args, name, _, _, _ in self.calls:
             if fn is None:
@@ -67,19 +59,15 @@ class Segment:
                 if st != 0:
                     _lib.check(st, name)
 
-    def run2(self, main: "torch.cuda.Stream", side: "torch.cuda.Stream", events: Dict[str, "torch.cuda.Event"],
-             aux: Optional["torch.cuda.Stream"] = None):
-        """Multi-stream replay (single GPU).  lane 1 = the weight-gradient GEMMs, which nothing later in the
-        backward chain reads: they go to `side`, forked behind everything issued so far on `main`, and their
-        completion event is stored under this segment's name for a later wait().  lane 2 = the image tower's
-        small kernels (LayerNorm, attention), which run on `aux` beside the text tower's between fork()
-        and join()."""
+    def run2(self, main: "torch.cuda.Stream", side: Optional["torch.cuda.Stream"], events: Dict[str, "torch.cuda.Event"]):
+        """Two-stream replay (single GPU).  lane 1 = the weight-gradient GEMMs, which nothing later in the backward
+        chain reads: they go to `side`, forked behind everything issued so far on `main`, and their completion event
+        is stored under this segment's name for a later wait().  (A third stream for the image tower's LayerNorm /
+        attention beside the text tower's was measured slower -- the cross-stream edges cost more than the overlap of
+        those short kernels returned -- and removed; both towers now share grouped launches instead.)"""
         mp = main.cuda_stream
         sp = side.cuda_stream if side is not None else mp      # side=None: lane-1 work stays on the main stream
-        ap = aux.cuda_stream if aux is not None else mp
         forked1 = False
-        fork_ev = None
-        aux_dirty = False
         for fn, args, name, _, _, lane in self.calls:
             if fn is None:
                 if name == "py":
@@ -87,14 +75,6 @@ class Segment:
                 elif name == "wait":
                     if args in events:
                         main.wait_event(events.pop(args))
-                elif name == "fork" and aux is not None:
-                    fork_ev = torch.cuda.Event()
-                    fork_ev.record(main)
-                elif name == "join" and aux is not None and aux_dirty:
-                    d = torch.cuda.Event()
-                    d.record(aux)
-                    main.wait_event(d)
-                    aux_dirty = False
                 continue
             if lane == 1 and side is not None:
                 if not forked1:
@@ -103,17 +83,10 @@ class Segment:
                     side.wait_event(e)
                     forked1 = True
                 st = fn(*args, sp)
-            elif lane == 2 and aux is not None:
-                if fork_ev is not None:
-                    aux.wait_event(fork_ev)
-                    fork_ev = None
-                aux_dirty = True
-                st = fn(*args, ap)
             else:
                 st = fn(*args, mp)
             if st != 0:
                 _lib.check(st, name)
-        assert not aux_dirty, f"segment {self.name}: lane-2 work without a closing join()"
         if forked1:
             d = torch.cuda.Event()
             d.record(side)

@@ -580,7 +580,7 @@ class GraphedStep:
     """
 
     def __init__(self, model: MultimodalClassifier, optimizer: Adam, batch: int, seq_len: int, use_graph: bool = True,
-                 reducer=None, overlap_wgrad: bool = True, overlap_towers: bool = False, overlap_optimizer: bool = True):
+                 reducer=None, overlap_wgrad: bool = True, overlap_optimizer: bool = True):
         self.model, self.opt = model, optimizer
         optimizer._model = model
         eng = model._get_engine()
@@ -595,10 +595,6 @@ class GraphedStep:
         # single GPU: weight-gradient GEMMs run on a second stream beside the LayerNorm / attention / dgrad chain
         self.side = torch.cuda.Stream() if ((overlap_wgrad or overlap_optimizer) and reducer is None) else None
         self.wgrad_side = bool(overlap_wgrad)
-        # optional third stream for the image tower's LayerNorm / attention beside the text tower's.  Measured on
-        # MI355X (hipGraph, config 3): 13.68 ms/step with it vs 13.32 without -- the ~70 extra cross-stream
-        # edges cost more than the overlap of these short kernels returns -- so it is off by default.
-        self.aux = torch.cuda.Stream() if (self.side is not None and overlap_towers) else None
         # optimizer-in-backward: the (HBM-bound) Adam update of a layer pair's matrices follows their weight-gradient
         # GEMMs on the side stream, under the (MFMA-bound) backward chain of the layers below; only the tail
         # (embeddings, biases, head) is updated after the backward.  Needs no global clip and a single GPU.
@@ -615,7 +611,7 @@ class GraphedStep:
             if self.side is None:
                 p.fwd.run(stream)
             else:
-                p.fwd.run2(torch.cuda.current_stream(), None, {}, self.aux)
+                p.fwd.run2(torch.cuda.current_stream(), None, {})
             p.loss.run(stream)
         pieces = [("fwd", fwd, None)]
         if self.side is None:
@@ -629,7 +625,7 @@ class GraphedStep:
                 events = {}
                 done = []
                 for seg in p.bwd:
-                    seg.run2(main, self.side if self.wgrad_side else None, events, self.aux)
+                    seg.run2(main, self.side if self.wgrad_side else None, events)
                     rng = p.bucket_after.get(seg.name)
                     if self.opt_in_bwd and seg.name.startswith("bwd_layer_") and rng is not None:
                         if seg.name not in events:      # weight gradients ran on the main stream: fork behind them
