@@ -3,13 +3,14 @@
 A ``Plan`` is built once per (batch, seq_len): every activation / gradient workspace is allocated
 up front (288 GB of HBM: nothing is recomputed, nothing is freed) and every kernel launch is
 recorded as a prepared C-ABI call.  Running a step is then a replay of prepared calls -- eagerly,
-or captured once into a hipGraph (model.GraphedStep) so the ~600 launches cost one host call.
+or captured once into a hipGraph (model.GraphedStep) so the ~220 launches cost one host call.
 
 The two towers run in LOCKSTEP: layer l of the text encoder and layer l of the image encoder
-issue the same GEMM sequence, so each GEMM launch is a *grouped* launch carrying both towers'
-problems (and all eight weight-gradient GEMMs of a layer pair go out as one launch).  That is
-what fills 256 CUs with 128x128 tiles at these small N (768-wide projections give only 192-300
-tiles per tower).
+issue the same kernel sequence, so every launch is a *grouped* launch carrying both towers'
+problems: GEMMs (forward, dgrad; the weight gradients as one launch per tower), LayerNorms and
+attention.  That is what fills 256 CUs at these sizes (768-wide projections give only 100-300
+128x128 tiles per tower).  The text tower is padding-free: its launches are sized for B*S rows and
+clamp themselves to the live row count on the device (see the "pk.*" buffers in _build).
 
 Reference for the math: BertModel / timm ViT as called at
 example_scripts/Multimodal_example_task2C.txt:175,183 and the step at :200-223.
