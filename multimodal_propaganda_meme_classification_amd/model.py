@@ -370,15 +370,22 @@ class MultimodalClassifier(nn.Module):
         return pooled[:, :Dt], pooled[:, Dt:]
 
     @torch.no_grad()
-    def get_features(self, text, image, mask):
-        """Forward-only feature dump for the SVM baseline (baselines/extract_feat.py:52-67): dict of f32 tensors."""
+    def get_features(self, text, image, mask, pooler=None):
+        """Forward-only feature dump for the SVM baseline (baselines/extract_feat.py:52-67): dict of f32 tensors.
+        ``pooler = (weight [D, D], bias [D])`` of the checkpoint's ``bert.pooler.dense`` additionally yields BertModel's
+        ``pooler_output`` = tanh(W h_cls + b), which is what the baseline script stores for the text side (the pooler
+        is not part of the fine-tune path, so its two tensors are not model parameters here)."""
         was = self.training
         self.eval()
         try:
             t_, i_ = self.encode(text, image, mask)
         finally:
             self.train(was)
-        return {"text": t_.clone(), "image": i_.clone()}
+        out = {"text": t_.clone(), "image": i_.clone()}
+        if pooler is not None:
+            w, b = (x.to(t_.device, F32) for x in pooler)
+            out["pooler_output"] = torch.tanh(torch.addmm(b, out["text"], w.t()))
+        return out
 
     def forward_backward(self, text, image, mask, labels, grad_hook=None):
         """Returns (loss[1], n_correct[1], logits[B,C]) device tensors; gradients land in .grad."""

@@ -205,8 +205,13 @@ def test_encode_with_external_head_matches_oracle(pool, head_kind):
     if tower_tol is not None:
         assert (num / den) ** 0.5 <= tower_tol, (num / den) ** 0.5
 
-    feats = model.get_features(text.cuda(), image.cuda(), mask.cuda())
+    g = torch.Generator().manual_seed(1)
+    pw, pb = torch.randn((cfg.text.hidden, cfg.text.hidden), generator=g) * 0.05, torch.randn(cfg.text.hidden, generator=g) * 0.05
+    feats = model.get_features(text.cuda(), image.cuda(), mask.cuda(), pooler=(pw, pb))
     assert feats["text"].shape == (16, cfg.text.hidden) and feats["image"].shape == (16, cfg.image.hidden)
+    if strict:      # BertModel.pooler_output = tanh(dense(h[:, 0])) on the pooled token
+        want = torch.tanh(th.detach() @ pw.t() + pb)
+        assert float((feats["pooler_output"].cpu() - want).abs().max()) <= 5e-3
     assert model.training
 
 
