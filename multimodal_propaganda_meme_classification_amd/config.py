@@ -14,7 +14,7 @@ bf16 shadow copy of the GEMM operands is one prefix ``[0, n_shadow)`` of the buf
 from __future__ import annotations
 
 from dataclasses import asdict, dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 
 @dataclass

@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import math
 import weakref
-from typing import Dict, Iterable, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
