@@ -325,21 +325,26 @@ class Engine:
         self._last_bwd_plan = plan
 
     # ---- plan ----------------------------------------------------------------------------------------------
-    def plan(self, B: int, S: int, training: bool = True, gather_world: int = 0, features: bool = False) -> Plan:
+    def plan(self, B: int, S: int, training: bool = True, gather_world: int = 0, features=False) -> Plan:
         """Plans differ between train and eval only when some dropout probability is non-zero.
         features = True: the plan stops at the pooled tower features (text pooled row | ViT class token, f32) and its
         backward starts from their gradient: the late-fusion head is then whatever the caller builds on top.
+        features = "sequence": the same with the towers' whole last hidden states ([B,S,Dt] and [B,Nt,Di], f32) as the
+        boundary -- for poolings that read every position (max / mean / attention / conv1d); the reference pools over the
+        padded positions too, so this plan computes them (no row packing).
         gather_world = W > 0 (data parallel): the embedding-table gradients are built from the all-gathered token ids
         and embedding-gradient rows of all W ranks (6 MB per rank) instead of all-reducing the dense 196-MB table."""
         cfg = self.cfg
         has_drop = (cfg.text.hidden_dropout > 0 or cfg.text.attention_dropout > 0 or cfg.head_dropout > 0)
-        key = (B, S, bool(training and has_drop), int(gather_world), self.pack_text, bool(features))
+        features = features if features == "sequence" else bool(features)
+        pack = self.pack_text and features != "sequence"
+        key = (B, S, bool(training and has_drop), int(gather_world), pack, features)
         if key not in self.plans:
             self.plans[key] = self._build(B, S, key[2], key[3], key[4], key[5])
         return self.plans[key]
 
     def _build(self, B: int, S: int, dropout_on: bool = False, gather_world: int = 0, pack: bool = False,
-               features: bool = False) -> Plan:
+               features=False) -> Plan:
         cfg, t, v = self.cfg, self.cfg.text, self.cfg.image
         if S > t.max_position:
             raise ValueError(f"sequence length {S} > max_position {t.max_position}")
@@ -534,7 +539,10 @@ class Engine:
         feat, fused = alloc("h.feat", (B, 2 * P_), F32), alloc("h.fused", (B, P_), F32)
         logits = alloc("logits", (B, Cn), F32)
         pl.features = features
-        if features:
+        if features == "sequence":
+            assert not pack
+            d_seq_t, d_seq_i = alloc("h.d_seq_t", (Tt, Dt), F32, zero=True), alloc("h.d_seq_i", (Ti, Di), F32, zero=True)
+        elif features:
             d_pooled = alloc("h.d_pooled", (B, Dt + Di), F32, zero=True)
             f.c("mh_pool_fwd", _ptr(xt_last32), _ptr(xf32), pool_index, _ptr(pooled), B, S, Nt, Dt, Di, _ptr(pool_rows))
         else:
@@ -571,8 +579,12 @@ class Engine:
             h1 = self.layout.spec["output_fc.bias"].offset + self.layout.spec["output_fc.bias"].numel
             head_grads = self.G[h0:h1]
             s.py(head_grads.zero_)
-            s.c("mh_pool_bwd", _ptr(d_pooled), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, float(self.gscale),
-                _ptr(pool_rows))
+            if features == "sequence":      # the caller's gradient w.r.t. every hidden state (already times the stream scale)
+                s.c("mh_cast_f32_bf16", _ptr(d_seq_t), _ptr(dXt[0]), Tt * Dt)
+                s.c("mh_cast_f32_bf16", _ptr(d_seq_i), _ptr(dXf), Ti * Di)
+            else:
+                s.c("mh_pool_bwd", _ptr(d_pooled), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, float(self.gscale),
+                    _ptr(pool_rows))
         else:
             s.c("mh_head_bwd", C.byref(hp), C.byref(hg), _ptr(dlogits), _ptr(pooled), _ptr(feat), _ptr(fused), _ptr(dfeat),
                 _ptr(dfused), _ptr(dXt[0]), _ptr(dXf), pool_index, B, S, Nt, Dt, Di, P_, Cn, float(self.gscale),

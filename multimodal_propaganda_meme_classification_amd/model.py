@@ -83,6 +83,26 @@ class _EncodeFn(torch.autograd.Function):
         return None, None, None
 
 
+class _SequenceFn(torch.autograd.Function):
+    """The towers with their whole last hidden states as the boundary (a "sequence" features plan)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, plan):
+        ctx.model, ctx.plan = model, plan
+        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        B, S = plan.B, plan.S
+        return plan.buf["t.xlast32"].view(B, S, -1).clone(), plan.buf["i.xf32"].view(B, -1, model.config.image.hidden).clone()
+
+    @staticmethod
+    def backward(ctx, d_text, d_image):
+        model, plan = ctx.model, ctx.plan
+        scale = model.config.stream_scale          # the 16-bit gradient streams carry this power of two (fp16 build)
+        plan.buf["h.d_seq_t"].copy_((d_text.to(F32) * scale).reshape(plan.buf["h.d_seq_t"].shape))
+        plan.buf["h.d_seq_i"].copy_((d_image.to(F32) * scale).reshape(plan.buf["h.d_seq_i"].shape))
+        model._run_backward(plan)
+        return None, None, None
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, crit):
@@ -313,7 +333,7 @@ class MultimodalClassifier(nn.Module):
         host.copy_(torch.tensor([lo, hi, self._rng_step & 0x7FFFFFFF, 0], dtype=torch.int32))
         plan.buf["rng"].copy_(host, non_blocking=True)
 
-    def _prepare(self, text, image, mask, labels=None, features: bool = False) -> Plan:
+    def _prepare(self, text, image, mask, labels=None, features=False) -> Plan:
         eng = self._get_engine()
         if text.dim() != 2 or mask.shape != text.shape:
             raise ValueError("text and mask must be [B, S] int64 tensors of the same shape")
@@ -368,6 +388,22 @@ class MultimodalClassifier(nn.Module):
             plan.fwd.run(torch.cuda.current_stream().cuda_stream)
             pooled = plan.buf["h.pooled"].clone()
         return pooled[:, :Dt], pooled[:, Dt:]
+
+    def encode_sequence(self, text, image, mask):
+        """Like ``encode`` but returns the towers' whole last hidden states, ``(text [B,S,Dt], image [B,Nt,Di])`` f32 and
+        differentiable, for the poolings of ``LLMWithClassificationHead`` that read every position -- max, masked mean,
+        tanh-attention, conv1d-max (Multimodal_example_task2C.py:356-392) -- written in PyTorch on top.  Every position is
+        computed, padded ones included (the reference's max / conv poolings read them)."""
+        for t_ in (text, image, mask):
+            if not t_.is_cuda:
+                raise _lib.MemehipError("memehip runs on the HIP device only (no CPU fallback): move the batch with .to(device)")
+        plan = self._prepare(text, image, mask, features="sequence")
+        if torch.is_grad_enabled() and self.training:
+            return _SequenceFn.apply(self._params[self._names[0]], self, plan)
+        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        B, S = plan.B, plan.S
+        return (plan.buf["t.xlast32"].view(B, S, -1).clone(),
+                plan.buf["i.xf32"].view(B, -1, self.config.image.hidden).clone())
 
     @torch.no_grad()
     def get_features(self, text, image, mask, pooler=None):
