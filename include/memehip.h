@@ -298,6 +298,17 @@ int mh_pool_fwd(const float* text_hidden, const float* image_hidden, int text_po
                 int Nt, int Dt, int Di, const int32_t* text_rows, mh_stream_t stream);
 int mh_pool_bwd(const float* d_pooled, void* d_text_hidden, void* d_image_hidden, int text_pool_index, int B, int S,
                 int Nt, int Dt, int Di, float out_scale, const int32_t* text_rows, mh_stream_t stream);
+/* BatchNorm1d over f32 [B][F] (+ optional fused ReLU): Kevin's `Linear + BatchNorm1d + ReLU` projections and the 1-logit
+ * `Linear(512,1) + BatchNorm1d(1)` (Multimodal_example_task2C.py:603-605, :641-643).  Training: batch statistics
+ * (biased variance), running statistics updated with momentum (unbiased variance), mean / rstd saved for the
+ * backward.  Eval (training = 0): running statistics.  bwd (training mode): dx, dgamma, dbeta (overwritten); with relu,
+ * y (the forward output) masks the incoming gradient.  B <= 1024. */
+int mh_bn1d_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                float* y, int ldy, float* save_mean, float* save_rstd, int B, int F, float eps, float momentum,
+                int training, int relu, mh_stream_t stream);
+int mh_bn1d_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, const float* gamma,
+                const float* save_mean, const float* save_rstd, float* dx, int lddx, float* dgamma, float* dbeta, int B,
+                int F, int relu, mh_stream_t stream);
 int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
                   int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream);
 /* sigmoid focal loss over one logit per sample (torchvision.ops.sigmoid_focal_loss(inputs, targets, alpha, gamma,

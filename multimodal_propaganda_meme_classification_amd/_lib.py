@@ -95,6 +95,10 @@ _PROTOS = {
     "mh_head_bwd": [C.POINTER(MhHeadParams), C.POINTER(MhHeadGrads)] + [c_void_p] * 8 + [c_int] * 8 + [c_float, c_void_p, c_float, C.c_uint32, c_void_p, c_void_p],
     "mh_pool_fwd": [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_void_p],
     "mh_pool_bwd": [c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 5 + [c_float, c_void_p, c_void_p],
+    "mh_bn1d_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                    c_float, c_float, c_int, c_int, c_void_p],
+    "mh_bn1d_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                    c_void_p, c_int, c_int, c_int, c_void_p],
     "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
     "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],

@@ -358,3 +358,97 @@ extern "C" int mh_pool_bwd(const float* d_pooled, void* d_text_hidden, void* d_i
                        (h16*)d_text_hidden, (h16*)d_image_hidden, B, S, Nt, Dt, Di, text_pool_index, out_scale, text_rows);
     return mh_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm1d over [B][F] f32 (+ optional ReLU), the building block of Kevin's head
+// (Multimodal_example_task2C.py:603-605 Linear+BatchNorm1d+ReLU, :641-643 Linear(512,1)+BatchNorm1d(1)).
+// One thread per feature (B <= 1024 rows are walked twice: mean, then centred variance -- the two-pass form
+// torch uses); training mode normalises with the biased batch variance and updates the running statistics with
+// the unbiased one (momentum form of nn.BatchNorm1d); eval mode uses the running statistics.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                       float* __restrict__ run_var, float* __restrict__ y, int ldy,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd, int B,
+                                                       int F, float eps, float momentum, int training, int relu) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    float mu, rs;
+    if (training) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += x[(size_t)b * ldx + f];
+        mu = s / (float)B;
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float d = x[(size_t)b * ldx + f] - mu;
+            v += d * d;
+        }
+        const float var = v / (float)B;
+        rs = 1.0f / sqrtf(var + eps);
+        if (run_mean) run_mean[f] = (1.0f - momentum) * run_mean[f] + momentum * mu;
+        if (run_var) run_var[f] = (1.0f - momentum) * run_var[f] + momentum * (B > 1 ? v / (float)(B - 1) : var);
+    } else {
+        mu = run_mean[f];
+        rs = 1.0f / sqrtf(run_var[f] + eps);
+    }
+    if (save_mean) save_mean[f] = mu;
+    if (save_rstd) save_rstd[f] = rs;
+    const float g = gamma ? gamma[f] : 1.f, bt = beta ? beta[f] : 0.f;
+    for (int b = 0; b < B; ++b) {
+        float o = (x[(size_t)b * ldx + f] - mu) * rs * g + bt;
+        if (relu) o = fmaxf(o, 0.f);
+        y[(size_t)b * ldy + f] = o;
+    }
+}
+
+// dx = gamma rstd (dy' - mean(dy') - xhat mean(dy' xhat)),  dy' = dy * (y > 0) with ReLU;  dgamma, dbeta overwritten
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                       int ldx, const float* __restrict__ y, int ldy,
+                                                       const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_rstd, float* __restrict__ dx,
+                                                       int lddx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                       int B, int F, int relu) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    const float mu = save_mean[f], rs = save_rstd[f], g = gamma ? gamma[f] : 1.f;
+    float sb = 0.f, sg = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float d = dy[(size_t)b * lddy + f];
+        if (relu && !(y[(size_t)b * ldy + f] > 0.f)) d = 0.f;
+        sb += d;
+        sg += d * (x[(size_t)b * ldx + f] - mu) * rs;
+    }
+    if (dgamma) dgamma[f] = sg;
+    if (dbeta) dbeta[f] = sb;
+    const float mb = sb / (float)B, mg = sg / (float)B;
+    for (int b = 0; b < B; ++b) {
+        float d = dy[(size_t)b * lddy + f];
+        if (relu && !(y[(size_t)b * ldy + f] > 0.f)) d = 0.f;
+        const float xh = (x[(size_t)b * ldx + f] - mu) * rs;
+        dx[(size_t)b * lddx + f] = g * rs * (d - mb - xh * mg);
+    }
+}
+}  // namespace
+
+extern "C" int mh_bn1d_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* y, int ldy, float* save_mean, float* save_rstd, int B, int F,
+                           float eps, float momentum, int training, int relu, mh_stream_t stream) {
+    if (!x || !y) return MH_EINVAL;
+    if (!training && (!running_mean || !running_var)) return MH_EINVAL;
+    if (B < 1 || B > 1024 || F < 1 || ldx < F || ldy < F) return MH_ESHAPE;
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                       running_mean, running_var, y, ldy, save_mean, save_rstd, B, F, eps, momentum, training, relu);
+    return mh_launch_status();
+}
+
+extern "C" int mh_bn1d_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, const float* gamma,
+                           const float* save_mean, const float* save_rstd, float* dx, int lddx, float* dgamma, float* dbeta,
+                           int B, int F, int relu, mh_stream_t stream) {
+    if (!dy || !x || !save_mean || !save_rstd || !dx) return MH_EINVAL;
+    if (relu && !y) return MH_EINVAL;
+    if (B < 1 || B > 1024 || F < 1 || lddy < F || ldx < F || lddx < F || (relu && ldy < F)) return MH_ESHAPE;
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, y, ldy,
+                       gamma, save_mean, save_rstd, dx, lddx, dgamma, dbeta, B, F, relu);
+    return mh_launch_status();
+}

@@ -159,6 +159,42 @@ class _FocalFn(torch.autograd.Function):
         return (ctx.dl * gout).view(ctx.shape), None, None
 
 
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod, relu):
+        x = x.contiguous().to(F32)
+        training = mod.training or mod.running_mean is None
+        y, sm, sr = ops.bn1d_fwd(x, gamma, beta, mod.running_mean, mod.running_var, mod.eps, mod.momentum, training, relu)
+        if training and mod.num_batches_tracked is not None:
+            mod.num_batches_tracked += 1
+        ctx.save_for_backward(x, y, gamma, sm, sr)
+        ctx.relu, ctx.training = relu, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, sm, sr = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("memehip.BatchNorm1d: backward in eval mode is not supported")
+        dx, dg, db = ops.bn1d_bwd(dy.contiguous().to(F32), x, y, gamma, sm, sr, ctx.relu)
+        return dx, dg, db, None, None
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d over [B, F] running the HIP kernels (mh_bn1d_fwd / mh_bn1d_bwd); ``relu=True`` fuses the ReLU that
+    follows it in Kevin's ``Linear + BatchNorm1d + ReLU`` projections (Multimodal_example_task2C.py:603-605).  Same
+    parameters, buffers and state_dict keys as the torch module (affine, running statistics, momentum 0.1)."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: float = 0.1, relu: bool = False):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=True, track_running_stats=True)
+        self.relu = relu
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 2 or not x.is_cuda:
+            raise _lib.MemehipError("memehip.BatchNorm1d: expected a [B, F] tensor on the HIP device (no CPU fallback)")
+        return _BatchNormFn.apply(x, self.weight, self.bias, self, self.relu)
+
+
 class SigmoidFocalLoss(nn.Module):
     """``criterion = sigmoid_focal_loss`` of Multimodal_example_task2C.py:167 called as
     ``criterion(output, labels, alpha=0.25, gamma=2.0, reduction='mean')`` (:711), on one logit per sample

@@ -431,6 +431,28 @@ def head_bwd(params, grads, dlogits, pooled, feat, fused, dfeat, dfused, d_text_
                                         Cn, float(out_scale), *_drop(drop), _p(text_rows), _stream()), "mh_head_bwd")
 
 
+def bn1d_fwd(x, gamma, beta, running_mean, running_var, eps: float, momentum: float, training: bool, relu: bool = False):
+    """mh_bn1d_fwd on f32 [B,F]. Returns (y, save_mean, save_rstd)."""
+    _chk(x, F32, "x")
+    B, Fn = x.shape
+    y = torch.empty_like(x)
+    sm, sr = torch.empty(Fn, device=x.device), torch.empty(Fn, device=x.device)
+    check(_lib.load().mh_bn1d_fwd(_p(x), Fn, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), Fn, _p(sm), _p(sr),
+                                  B, Fn, float(eps), float(momentum), int(training), int(relu), _stream()), "mh_bn1d_fwd")
+    return y, sm, sr
+
+
+def bn1d_bwd(dy, x, y, gamma, save_mean, save_rstd, relu: bool = False):
+    """mh_bn1d_bwd. Returns (dx, dgamma, dbeta)."""
+    _chk(dy, F32, "dy"), _chk(x, F32, "x")
+    B, Fn = x.shape
+    dx = torch.empty_like(x)
+    dg, db = torch.empty(Fn, device=x.device), torch.empty(Fn, device=x.device)
+    check(_lib.load().mh_bn1d_bwd(_p(dy), Fn, _p(x), Fn, _p(y), Fn, _p(gamma), _p(save_mean), _p(save_rstd), _p(dx), Fn, _p(dg),
+                                  _p(db), B, Fn, int(relu), _stream()), "mh_bn1d_bwd")
+    return dx, dg, db
+
+
 def ce_fwd_bwd(logits, labels, loss, dlogits, n_correct=None, grad_scale: float = 1.0):
     _chk(logits, F32, "logits"), _chk(labels, I64, "labels"), _chk(loss, F32, "loss"), _chk(dlogits, F32, "dlogits")
     B, Cn = logits.shape

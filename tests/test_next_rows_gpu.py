@@ -322,3 +322,45 @@ def test_encode_sequence_with_the_pooling_zoo_matches_oracle(with_max):
         model.eval()
         h2, _ = model.encode_sequence(text.cuda(), image.cuda(), mask.cuda())
         assert float((h2 - h.detach()).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,Fn,relu", [(32, 512, True), (32, 1, False), (7, 96, True), (200, 33, False)])
+def test_batchnorm1d_kernel_matches_torch(B, Fn, relu):
+    """memehip.BatchNorm1d (mh_bn1d_fwd / mh_bn1d_bwd, optional fused ReLU) against torch.nn.BatchNorm1d (+ ReLU) in
+    fp32 on the CPU: outputs, input / affine gradients, running statistics over several steps, eval mode."""
+    import multimodal_propaganda_meme_classification_amd as pkg
+    g = torch.Generator().manual_seed(B + Fn)
+    ref = torch.nn.BatchNorm1d(Fn)
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.2 * torch.randn(Fn, generator=g))
+        ref.bias.copy_(0.1 * torch.randn(Fn, generator=g))
+    mine = pkg.BatchNorm1d(Fn, relu=relu)
+    mine.load_state_dict(ref.state_dict())
+    mine.cuda()
+    for step in range(3):
+        x = torch.randn((B, Fn), generator=g) * 2 + 0.5
+        dy = torch.randn((B, Fn), generator=g)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        if relu:
+            yr = torch.relu(yr)
+        yr.backward(dy)
+        xm = x.cuda().requires_grad_(True)
+        ym = mine(xm)
+        ym.backward(dy.cuda())
+        np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(xm.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(mine.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(mine.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(mine.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(mine.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+        for m in (mine, ref):
+            m.zero_grad()
+    ref.eval(), mine.eval()
+    x = torch.randn((B, Fn), generator=g)
+    ye = ref(x)
+    if relu:
+        ye = torch.relu(ye)
+    np.testing.assert_allclose(mine(x.cuda()).detach().cpu().numpy(), ye.detach().numpy(), rtol=2e-5, atol=2e-5)
+    assert sorted(mine.state_dict().keys()) == sorted(ref.state_dict().keys())
