@@ -27,7 +27,10 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-MH_DEV int row_img_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// (key (row ^ (row >> 3)) & 7 instead of row & 7: ds_read_b128 serves a wave in the lane groups {0-3,12-15,20-27}, ...;
+//  a fragment read touches rows rb + (lane & 31) at one chunk, and with the plain key rows 12 / 20 (and 0 / 24) of a
+//  group land on the same banks -- 19-27 % of the LDS cycles of these kernels were conflicts)
+MH_DEV int row_img_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row ^ (row >> 3)) & 7)) << 4); }
 MH_DEV int tr_img_off(int row, int unit) { return row * 128 + ((unit ^ (((row >> 1) & 1) << 1)) << 5); }
 
 // stage one [64][64] h16 tile (rows row0.., clipped at nrows -> zeros) into a row image and/or tr image
