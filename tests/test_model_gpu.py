@@ -283,3 +283,19 @@ def test_ddp_segmented_graph_path_world1(pkg, clip):
         assert red.reduced_elems == 3 * end and len(g2.graphs) == len(g2.plan.bwd) + 3   # + fwd, opt, gather marker
     finally:
         dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_on_one_gpu_match_the_global_batch():
+    """N = 2 for real: two processes (gloo backend, both on device 0) run the data-parallel step -- parameter broadcast,
+    per-segment all-reduce, the gathered embedding-table gradient, 1/world in Adam, Adam slices behind each bucket --
+    on the two halves of a batch; rank 0 checks every step against ONE process stepping on the whole batch
+    (tools/ddp2_check.py asserts losses, parameters within 2.05 * k * lr / mean 2e-5, and identical ranks)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "ddp2_check.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "DDP2 OK" in out.stdout, out.stdout[-2000:]
