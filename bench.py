@@ -103,6 +103,8 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("MEMEHIP_BENCH_SHARE_DEVICE") == "1":      # rehearsal of the N > 1 path on a 1-GPU box (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -110,7 +112,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         if world > 1:
-            dist.init_process_group("nccl", device_id=device)
+            backend = os.environ.get("MEMEHIP_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(backend)
         else:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
 
