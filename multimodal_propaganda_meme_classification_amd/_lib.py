@@ -128,6 +128,8 @@ def load(kind: str = "bf16") -> C.CDLL:
     if kind not in LIB_PATHS:
         raise ValueError(f"compute dtype must be 'bf16' or 'fp16', got {kind!r}")
     path = LIB_PATHS[kind]
+    if kind == "bf16" and os.environ.get("MEMEHIP_LIB"):      # A/B of two builds of the library in one session
+        path = os.environ["MEMEHIP_LIB"]
     if not os.path.exists(path):
         raise MemehipError(
             f"{path} is missing: build the HIP extension first "

@@ -146,6 +146,13 @@ MH_DEV h16x8 read_frag(const char* lds, int rb, int kk, int lane) {
     }
 }
 
+// f32 staging tile [rows][128]: the accumulator layout makes the four 16-lane groups of a wave write rows r, r+4, r+8,
+// r+12 of the SAME 16 columns -- with 512-B rows that is the same 16 banks four times.  The 16-column block index is
+// therefore XOR-ed with (row >> 2) & 3: the four groups land on four different 16-bank quarters (conflict-free), and a
+// row-wise 32-B read stays inside one (permuted) block.  Odd rows also swap the two 16-B halves of every 32 B, so the
+// 16-B epilogue reads of rows r and r+1 (one ds_read_b128 lane group spans both) use different banks.
+MH_DEV int cs_index(int row, int col) { return row * BN + (col ^ (((row >> 2) & 3) << 4) ^ ((row & 1) << 2)); }
+
 // ---- epilogue: f32 tile in LDS -> bias / GELU / gelu' / residual -> 16-B coalesced stores ----------
 // The 16-bit epilogue operands (residual, gelu' pre-activation) are fetched BEFORE the accumulators go through
 // LDS (epilogue_prefetch), so their HBM latency hides behind the LDS transpose + barrier instead of stalling
@@ -187,8 +194,8 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
         if (gm >= M) continue;
         float v[8];
         {
-            const f32x4 x0 = *(const f32x4*)(cs + row * BN + cc * 8);
-            const f32x4 x1 = *(const f32x4*)(cs + row * BN + cc * 8 + 4);
+            const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
+            const f32x4 x1 = *(const f32x4*)(cs + cs_index(row, cc * 8 + 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = x0[e] * alpha; v[4 + e] = x1[e] * alpha; }
         }
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
             for (int r = 0; r < 4; ++r) {
                 const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
                 const int col = wn0 + j * 16 + (lane & 15);
-                cs[row * BN + col] = acc[i][j][r];
+                cs[cs_index(row, col)] = acc[i][j][r];
             }
     __syncthreads();
 
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
             for (int r = 0; r < 4; ++r) {
                 const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
                 const int col = wn0 + j * 16 + (lane & 15);
-                cs[row * BN + col] = acc[i][j][r];
+                cs[cs_index(row, col)] = acc[i][j][r];
             }
     __syncthreads();
     epilogue_rows<R_BM>(P, cs, m0, n0, tid, M);
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
             for (int r = 0; r < 4; ++r) {
                 const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
                 const int col = wn0 + j * 16 + (lane & 15);
-                cs[row * BN + col] = acc[i][j][r];
+                cs[cs_index(row, col)] = acc[i][j][r];
             }
     __syncthreads();
     epilogue_rows<R_BM>(P, cs, m0, n0, tid, M);
@@ -885,7 +892,7 @@ __global__ __launch_bounds__(512, 4) void gemm_s4_kernel(const GemmGroup g) {
             for (int r = 0; r < 4; ++r) {
                 const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
                 const int col = wn0 + j * 16 + (lane & 15);
-                cs[row * BN + col] = acc[i][j][r];
+                cs[cs_index(row, col)] = acc[i][j][r];
             }
     __syncthreads();
     epilogue_rows<BM, NW * 64, DROP, true>(P, cs, m0, n0, tid, M, &pf);
@@ -996,7 +1003,7 @@ __global__ __launch_bounds__(512, 4) void gemm_wide_kernel(const GemmGroup g) {
                     for (int r = 0; r < 4; ++r) {
                         const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
                         const int col = (wn0 & 127) + j * 16 + (lane & 15);
-                        cs[row * BN + col] = acc[i][j][r];
+                        cs[cs_index(row, col)] = acc[i][j][r];
                     }
         }
         __syncthreads();
