@@ -326,7 +326,8 @@ int mh_focal_fwd_bwd(const float* logits, int ld, const float* targets /*f32 [B]
  *     scalar is read from DEVICE memory so a captured hipGraph of the step can be replayed:
  *     hyper = f32[8] {lr, beta1, beta2, eps, weight_decay, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale}
  *     g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq)*|grad_scale| + 1e-6)) (clip only
- *          when gnorm_sq != NULL)
+ *          when gnorm_sq != NULL and max_norm > 0); a NON-FINITE *gnorm_sq skips the update altogether
+ *          (parameters and moments untouched), as GradScaler.step does after an fp16 overflow
  *     m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
  *     (L2 wd folds into g', decoupled wd scales p first); also refreshes the bf16 shadow copy
  *     p_bf16[i] for i < n_shadow (the GEMM operands).  n, n_shadow multiples of 4.

@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     float gs = hyper[7];
     if (gnorm_sq) {
         const float nrm = sqrtf(gnorm_sq[0]) * fabsf(gs);
-        gs *= fminf(1.0f, max_norm / (nrm + 1e-6f));
+        // a non-finite gradient norm (an overflowed 16-bit gradient stream): the whole step is skipped, parameters and
+        // moments untouched -- what torch.cuda.amp.GradScaler.step does (Multimodal_example_task2C.py:712-717)
+        if (!(nrm <= 3.0e38f)) return;
+        if (max_norm > 0.f) gs *= fminf(1.0f, max_norm / (nrm + 1e-6f));
     }
     const float step = lr * inv_bc1;
     const float decay = decoupled ? 1.0f - lr * wd : 1.0f;
@@ -92,7 +95,10 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
     float gs = hyper[7];
     if (gnorm_sq) {
         const float nrm = sqrtf(gnorm_sq[0]) * fabsf(gs);
-        gs *= fminf(1.0f, max_norm / (nrm + 1e-6f));
+        // a non-finite gradient norm (an overflowed 16-bit gradient stream): the whole step is skipped, parameters and
+        // moments untouched -- what torch.cuda.amp.GradScaler.step does (Multimodal_example_task2C.py:712-717)
+        if (!(nrm <= 3.0e38f)) return;
+        if (max_norm > 0.f) gs *= fminf(1.0f, max_norm / (nrm + 1e-6f));
     }
     const float step = lr * inv_bc1;
     const float decay = decoupled ? 1.0f - lr * wd : 1.0f;

@@ -499,11 +499,17 @@ class Adam(torch.optim.Optimizer):
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, decoupled_weight_decay: bool = False, max_grad_norm: Optional[float] = None,
-                 model: Optional[MultimodalClassifier] = None, skip_untouched_embedding_rows: bool = True):
+                 model: Optional[MultimodalClassifier] = None, skip_untouched_embedding_rows: bool = True,
+                 skip_nonfinite: bool = False):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.decoupled = decoupled_weight_decay
         self.max_grad_norm = max_grad_norm
+        # skip_nonfinite: compute the gradient norm every step even without clipping and skip the update when it is
+        # inf / nan (an overflowed fp16 gradient stream) -- GradScaler's behaviour, Multimodal_example_task2C.py:712-717.
+        # Clipping implies it.  It needs every gradient before any update, so it turns the optimizer-in-backward
+        # overlap off, like clipping does.
+        self.skip_nonfinite = bool(skip_nonfinite)
         self._model = model
         self._flat = None
         self._step = 0
@@ -581,8 +587,8 @@ class Adam(torch.optim.Optimizer):
         model = self._model
         n_shadow = model.layout.n_shadow if model is not None else 0
         nrm = None
-        if self.max_grad_norm is not None:
-            assert only is None, "clipping needs the global gradient norm before any update"
+        if self.max_grad_norm is not None or self.skip_nonfinite:
+            assert only is None, "clipping / the non-finite check need the global gradient norm before any update"
             ops.sumsq(f["G"], f["ws"], f["nrm"])
             nrm = f["nrm"]
         runs = []
@@ -677,10 +683,12 @@ class GraphedStep:
         # optimizer-in-backward: the (HBM-bound) Adam update of a layer pair's matrices follows their weight-gradient
         # GEMMs on the side stream, under the (MFMA-bound) backward chain of the layers below; only the tail
         # (embeddings, biases, head) is updated after the backward.  Needs no global clip and a single GPU.
-        self.opt_in_bwd = bool(overlap_optimizer and self.side is not None and optimizer.max_grad_norm is None)
+        self.opt_in_bwd = bool(overlap_optimizer and self.side is not None and optimizer.max_grad_norm is None
+                               and not optimizer.skip_nonfinite)
         # data parallel: the same idea behind the all-reduce -- as soon as a layer pair's gradient slice has been summed
         # over the ranks, its Adam update runs on a side stream under the backward of the layers below
-        self.ddp_opt_in_bwd = bool(overlap_optimizer and reducer is not None and optimizer.max_grad_norm is None)
+        self.ddp_opt_in_bwd = bool(overlap_optimizer and reducer is not None and optimizer.max_grad_norm is None
+                                   and not optimizer.skip_nonfinite)
         self.ddp_side = torch.cuda.Stream() if self.ddp_opt_in_bwd else None
 
     # ---- pieces ------------------------------------------------------------------------------------------

@@ -364,3 +364,34 @@ def test_batchnorm1d_kernel_matches_torch(B, Fn, relu):
         ye = torch.relu(ye)
     np.testing.assert_allclose(mine(x.cuda()).detach().cpu().numpy(), ye.detach().numpy(), rtol=2e-5, atol=2e-5)
     assert sorted(mine.state_dict().keys()) == sorted(ref.state_dict().keys())
+
+
+@pytest.mark.parametrize("clip", [None, 1.0])
+def test_adam_skips_the_step_on_nonfinite_gradients(clip):
+    """GradScaler.step of the reference's AMP path (Multimodal_example_task2C.py:712-717) skips the optimizer step
+    when a gradient overflowed; the fused Adam does the same when the gradient norm is inf / nan (skip_nonfinite, or
+    any clipping): parameters, moments and the 16-bit shadow stay bit-identical, the next clean step proceeds."""
+    import multimodal_propaganda_meme_classification_amd as pkg
+    from oracle import meme_oracle as O
+    cfg = O.tiny_config("cls")
+    model = pkg.MultimodalClassifier.from_config(pkg.ModelConfig.from_dict(cfg.to_dict()), init=False)
+    model.load_state_dict(O.init_params(cfg, 2))
+    model.to("cuda").train()
+    opt = pkg.Adam(model.parameters(), lr=1e-3, model=model, max_grad_norm=clip, skip_nonfinite=True)
+    text, image, mask, labels = (t.cuda() for t in O.synthetic_batch(cfg, 4, 16, seed=1))
+    model.forward_backward(text, image, mask, labels)
+    opt.step()                                             # a clean step first (moments become non-zero)
+    torch.cuda.synchronize()
+    p0, m0, v0 = model.flat_params.clone(), opt._flat["M"].clone(), opt._flat["V"].clone()
+    sh0 = model.flat_shadow.clone()
+    model.forward_backward(text, image, mask, labels)
+    for bad in (float("inf"), float("nan")):
+        model.flat_grads[12345] = bad                      # an overflowed gradient element
+        opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(model.flat_params, p0) and torch.equal(opt._flat["M"], m0) and torch.equal(opt._flat["V"], v0)
+        assert torch.equal(model.flat_shadow, sh0)
+    model.forward_backward(text, image, mask, labels)      # clean gradients again
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(model.flat_params, p0) and bool(torch.isfinite(model.flat_params).all())
