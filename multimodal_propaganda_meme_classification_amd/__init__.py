@@ -7,6 +7,6 @@ from . import _lib  # noqa: F401
 from ._lib import MemehipError  # noqa: F401
 from .config import ImageConfig, Layout, ModelConfig, TextConfig  # noqa: F401
 from .model import (Adam, BatchNorm1d, CrossEntropyLoss, GraphedStep, MultimodalClassifier, SigmoidFocalLoss,  # noqa: F401
-                    get_linear_schedule_with_warmup)
+                    TextEncoder, get_linear_schedule_with_warmup)
 from .data import HashTokenizer, MultimodalDataset, id2l, l2id, normalize_images, read_data  # noqa: F401
 from .train import evaluate, test, train  # noqa: F401

@@ -489,6 +489,51 @@ class MultimodalClassifier(nn.Module):
         return self._SH
 
 
+class TextEncoder(nn.Module):
+    """A text tower on its own -- e.g. the caption tower of Kevin's three-tower model
+    (``LLMWithClassificationHead(english_text_model, "cls")``, Multimodal_example_task2C.py:608-611, forward :668-670).
+
+    The launch plan is built for two lockstep towers, so this wraps a ``MultimodalClassifier`` whose image side is a
+    stub ViT (one 128-wide layer over a single 16x16 patch: a few microseconds of kernels inside the grouped
+    launches) fed with a constant image, and exposes only the text half:
+    ``forward(input_ids, attention_mask) -> pooled [B, D]`` (f32, differentiable), ``hidden_states(...)`` for the
+    non-cls poolings.  ``state_dict()`` / ``load_state_dict()`` use the BertModel key names without the ``bert.``
+    prefix of the two-tower module; the stub's parameters get zero gradients (the head on top never reads them), so one
+    fused ``Adam(encoder.parameters())`` leaves them unchanged."""
+
+    def __init__(self, text: "TextConfig", pool: str = "cls", compute_dtype: str = "bf16", seed: int = 0):
+        super().__init__()
+        from .config import ImageConfig
+        stub = ImageConfig(image_size=16, patch=16, hidden=128, layers=1, heads=2, intermediate=128)
+        cfg = ModelConfig(text=text, image=stub, proj=128, num_classes=2, pool=pool, compute_dtype=compute_dtype)
+        self.inner = MultimodalClassifier.from_config(cfg, seed=seed)
+        self._image = None
+
+    def _stub_image(self, B, device):
+        if self._image is None or self._image.shape[0] != B or self._image.device != device:
+            self._image = torch.zeros((B, 3, 16, 16), dtype=F32, device=device)
+        return self._image
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        t, _ = self.inner.encode(input_ids, self._stub_image(input_ids.shape[0], input_ids.device), attention_mask)
+        return t
+
+    def hidden_states(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        h, _ = self.inner.encode_sequence(input_ids, self._stub_image(input_ids.shape[0], input_ids.device), attention_mask)
+        return h
+
+    def state_dict(self, *args, **kwargs):
+        return {k[len("bert."):]: v for k, v in self.inner.state_dict(*args, **kwargs).items() if k.startswith("bert.")}
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = {("bert." + k): v for k, v in state_dict.items()}
+        res = self.inner.load_state_dict(sd, strict=False)
+        missing = [k[len("bert."):] for k in res.missing_keys if k.startswith("bert.")]
+        if strict and (missing or res.unexpected_keys):
+            raise RuntimeError(f"load_state_dict: missing {missing[:4]} unexpected {list(res.unexpected_keys)[:4]}")
+        return nn.modules.module._IncompatibleKeys(missing, list(res.unexpected_keys))
+
+
 class Adam(torch.optim.Optimizer):
     """torch.optim.Adam / AdamW semantics over the model's flat buffers in fused HIP launches (dense over all
     parameters, as the reference's optim.Adam is): one launch per contiguous run of a parameter group, so
