@@ -747,10 +747,42 @@ class GraphedStep:
             p.loss.run(stream)
         pieces = [("fwd", fwd, None)]
         if self.side is None:
+            # data parallel: `ddp_group` consecutive layer segments share one hipGraph and one all-reduce bucket (their
+            # gradient ranges are adjacent in the flat buffer): fewer graph boundaries, larger RCCL messages
+            import os
+            # (measured on a 1-rank RCCL group: 11.21 ms/step with one graph per layer, 10.99 in pairs, 10.97 in threes).
+            # The last two layers keep their own buckets, so the all-reduce left exposed after the backward stays small.
+            group = max(1, int(os.environ.get("MEMEHIP_DDP_GROUP", "2")))
+            n_layer_segs = sum(1 for sg in p.bwd if sg.name.startswith("bwd_layer_"))
+            seen = 0
+            pend = []
+
+            def flush():
+                if not pend:
+                    return
+                segs = list(pend)
+                pend.clear()
+                rngs = [p.bucket_after[sg.name] for sg in segs if p.bucket_after.get(sg.name) is not None]
+                rng = (min(r[0] for r in rngs), max(r[1] for r in rngs)) if rngs else None
+
+                def run(stream, segs=segs):
+                    for sg in segs:
+                        sg.run(stream)
+                pieces.append((segs[0].name, run, rng))
+
             for seg in p.bwd:
+                if seg.name.startswith("bwd_layer_"):
+                    seen += 1
+                if seg.name.startswith("bwd_layer_") and group > 1 and seen <= n_layer_segs - 2:
+                    pend.append(seg)
+                    if len(pend) == group:
+                        flush()
+                    continue
+                flush()
                 if seg.name == "bwd_embed_tables":      # needs every rank's token ids + embedding-gradient rows first
                     pieces.append(("gather", None, None))
                 pieces.append((seg.name, seg.run, p.bucket_after.get(seg.name)))
+            flush()
         else:
             def bwd(stream):
                 main = torch.cuda.current_stream()

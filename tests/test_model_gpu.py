@@ -280,7 +280,7 @@ def test_ddp_segmented_graph_path_world1(pkg, clip):
             torch.cuda.synchronize()
             assert float(l1) == float(l2)
             assert torch.equal(m1.flat_params, m2.flat_params)
-        assert red.reduced_elems == 3 * end and len(g2.graphs) == len(g2.plan.bwd) + 3   # + fwd, opt, gather marker
+        assert red.reduced_elems == 3 * end and 4 <= len(g2.graphs) <= len(g2.plan.bwd) + 3   # fwd, opt, gather marker + segments (paired)
     finally:
         dist.destroy_process_group()
 
