@@ -735,6 +735,7 @@ class GraphedStep:
         self.ddp_opt_in_bwd = bool(overlap_optimizer and reducer is not None and optimizer.max_grad_norm is None
                                    and not optimizer.skip_nonfinite)
         self.ddp_side = torch.cuda.Stream() if self.ddp_opt_in_bwd else None
+        self.ddp_wside = torch.cuda.Stream() if (reducer is not None and overlap_wgrad) else None
 
     # ---- pieces ------------------------------------------------------------------------------------------
     def _pieces(self):
@@ -766,8 +767,18 @@ class GraphedStep:
                 rng = (min(r[0] for r in rngs), max(r[1] for r in rngs)) if rngs else None
 
                 def run(stream, segs=segs):
+                    if self.ddp_wside is None or len(segs) < 2:
+                        for sg in segs:
+                            sg.run(stream)
+                        return
+                    # inside a pair the first layer's weight-gradient GEMMs run on a side stream beside the second layer's
+                    # chain (the buffers they read belong to the other layer parity); everything is joined at the end of
+                    # the graph, before the pair's gradient slice goes to the all-reduce
+                    main, events = torch.cuda.current_stream(), {}
                     for sg in segs:
-                        sg.run(stream)
+                        sg.run2(main, self.ddp_wside, events)
+                    for ev in events.values():
+                        main.wait_event(ev)
                 pieces.append((segs[0].name, run, rng))
 
             for seg in p.bwd:
