@@ -225,6 +225,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"gemm_kernel{dom[4:]} (grouped {args.dtype} MFMA GEMM)",
                          "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "method": "HIP events around every launch of the kernel on its launch stream, in an eager one-stream "
+                                   "replay of the step's prepared launches right after the timed region (3 replays averaged)",
                          "launches_per_step": d["launches"], "avg_launch_us": round(d["total_ms"] / d["launches"] * 1e3, 2),
                          "flops_per_launch": round(d["flops"] / d["launches"]),
                          "all_gemm_kernels": {k: {"ms_per_step": round(v["total_ms"], 3),
