@@ -52,7 +52,8 @@ const char* mh_status_str(int status);
  *   dgrad    dx = dy W      : (0,1)  A=dy[T][N']    B=W[N'][K']   (contracts over N')
  *   wgrad    dW = dy^T x    : (1,1)  A=dy[T][N']    B=x[T][K']    (contracts over T)
  *
- * Epilogue order:  v = alpha * acc (+ bias[n]);  if drop_rng: v = dropout(v);  if aux: aux[m,n] = bf16(v);  if GELU: v = gelu_erf(v);
+ * Epilogue order:  v = alpha * acc (+ bias[n]);  if drop_rng: v = dropout(v);  if aux: aux[m,n] = bf16(v);  if GELU: v = gelu_erf(v)
+ *                  (quick-GELU x*sigmoid(1.702x) with MH_GEMM_QUICK_GELU, which also selects the derivative for `mul`);
  *                  if mul_dgelu: v *= gelu'(mul[m,n]);  if residual: v += residual[m,n];
  *                  C[m,n] = v  (bf16, or f32 when MH_GEMM_OUT_F32; += when MH_GEMM_ACCUM with f32).
  * rowsum (wgrad only, a_kmajor==1): rowsum[m] = sum_k A(m,k)  -- the bias gradient.
@@ -64,6 +65,7 @@ const char* mh_status_str(int status);
 #define MH_GEMM_GELU 1
 #define MH_GEMM_OUT_F32 2
 #define MH_GEMM_ACCUM 4
+#define MH_GEMM_QUICK_GELU 8 /* the activation (MH_GEMM_GELU) and the derivative (mul) are quick-GELU x*sigmoid(1.702x): CLIP towers */
 
 typedef struct MhGemmProblem {
     const void* A;        /* bf16 */
@@ -249,6 +251,15 @@ int mh_zero_rows_f32(const int64_t* ids, float* table, int n_ids, int D, int voc
  *   mh_vit_assemble_bwd: dproj[b][p] = dx[b][1+p] (bf16); dpos[t] = sum_b dx[b][t]; dcls = sum_b dx[b][0]
  * ------------------------------------------------------------------------------------------ */
 int mh_patchify(const float* image, void* patches, int B, int C, int H, int W, int P, mh_stream_t stream);
+/* Generic patch gather: any patch size (CLIP ViT-L/14: 14), row pitch ld >= C*P*P elements; the columns C*P*P .. ld-1
+ * are zero-filled, so the patch-projection GEMM can run with its contraction padded to a multiple of 64 (588 -> 640).
+ * Same patch / feature order as mh_patchify; bit-exact gather + RNE. */
+int mh_patchify_ld(const float* image, void* patches /*bf16 [B*gh*gw][ld]*/, int B, int C, int H, int W, int P, int ld,
+                   mh_stream_t stream);
+/* 2-D copy of 32-bit words with zero padding: dst[r][c] = c < cols ? src[r][c] : 0 for c < pad_to (ld_* in words).
+ * Pads the [D][C*P*P] patch-projection weight (two 16-bit elements per word) to the GEMM's K, and un-pads its
+ * f32 gradient. */
+int mh_copy2d_u32(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, int pad_to, mh_stream_t stream);
 int mh_vit_assemble_fwd(const void* proj /*bf16 [B*Np][D]*/, const float* cls, const float* pos,
                         void* x /*bf16 [B][Np+1][D]*/, int B, int Np, int D, mh_stream_t stream);
 int mh_vit_assemble_bwd(const void* dx /*bf16 [B][Np+1][D]*/, void* dproj /*bf16 [B*Np][D]*/,

@@ -18,6 +18,7 @@ MH_GEMM_MAX_GROUP = 8
 MH_GEMM_GELU = 1
 MH_GEMM_OUT_F32 = 2
 MH_GEMM_ACCUM = 4
+MH_GEMM_QUICK_GELU = 8
 MH_COLSUM_MAX_JOBS = 64
 MH_LN_MAX_JOBS = 4
 MH_ATTN_MAX_GROUP = 2
@@ -89,6 +90,8 @@ _PROTOS = {
     "mh_bert_embed_bwd": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mh_zero_rows_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mh_patchify": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
+    "mh_patchify_ld": [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
+    "mh_copy2d_u32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "mh_vit_assemble_fwd": [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
     "mh_vit_assemble_bwd": [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p],
     "mh_head_fwd": [C.POINTER(MhHeadParams), c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_float, C.c_uint32, c_void_p, c_void_p],

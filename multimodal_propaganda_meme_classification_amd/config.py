@@ -42,6 +42,19 @@ class ImageConfig:
     heads: int = 12
     intermediate: int = 3072
     ln_eps: float = 1e-6
+    # CLIP vision tower (BASELINE.json configs[4]: openai/clip-vit-large-patch14-336; transformers CLIPVisionModel):
+    act: str = "gelu"            # "gelu" (erf; timm / HF ViT) | "quick_gelu" (x * sigmoid(1.702 x))
+    pre_ln: bool = False         # CLIP's pre_layrnorm: a LayerNorm on the embeddings, in front of the first block
+    patch_bias: bool = True      # CLIP's patch conv has no bias
+
+    @property
+    def patch_dim(self) -> int:
+        return self.channels * self.patch * self.patch
+
+    @property
+    def patch_dim_padded(self) -> int:
+        """Contraction length of the patch-projection GEMM: C*p*p rounded up to the GEMM's K tile (588 -> 640 at p = 14)."""
+        return (self.patch_dim + 63) // 64 * 64
 
     @property
     def n_patches(self) -> int:
@@ -66,6 +79,8 @@ class ModelConfig:
     grad_stream_scale: float = 0.0      # 0 = automatic: 1 for bf16, 8192 for fp16
     pack_text: bool = True              # padding-free text tower: positions with attention_mask == 0 are never computed
                                         # (they influence neither logits nor gradients); False = dense [B,S] rows
+    image_fc_name: str = "image_fc"     # state_dict name of the image projection: "resnet_fc" round-trips checkpoints of the
+                                        # organizers' module (Multimodal_example_task2C.txt:165); both are accepted on load
     head_dropout: float = 0.0           # nn.Dropout(0.3) on the pooled text features (...task2C.txt:160); the
                                         # parity / measurement plan runs every dropout at p = 0
 
@@ -79,7 +94,7 @@ class ModelConfig:
         return ModelConfig(text=TextConfig(**d["text"]), image=ImageConfig(**d["image"]), proj=d["proj"],
                            num_classes=d["num_classes"], pool=d["pool"], compute_dtype=d.get("compute_dtype", "bf16"),
                            grad_stream_scale=d.get("grad_stream_scale", 0.0), head_dropout=d.get("head_dropout", 0.0),
-                           pack_text=d.get("pack_text", True))
+                           pack_text=d.get("pack_text", True), image_fc_name=d.get("image_fc_name", "image_fc"))
 
     @property
     def stream_scale(self) -> float:
@@ -93,6 +108,8 @@ class ModelConfig:
     def validate(self):
         if self.pool not in ("cls", "last"):
             raise ValueError(f"Unsupported pooling type: {self.pool}")
+        if self.image_fc_name not in ("image_fc", "resnet_fc"):
+            raise ValueError(f"image_fc_name must be 'image_fc' or 'resnet_fc', got {self.image_fc_name!r}")
         if self.compute_dtype not in ("bf16", "fp16"):
             raise ValueError(f"compute_dtype must be 'bf16' or 'fp16', got {self.compute_dtype!r}")
         for pr in (self.text.hidden_dropout, self.text.attention_dropout, self.head_dropout):
@@ -103,10 +120,12 @@ class ModelConfig:
                 raise ValueError(f"{nm}: hidden and intermediate sizes must be multiples of 128 (GEMM tile)")
             if c.hidden != c.heads * 64:
                 raise ValueError(f"{nm}: head dim must be 64 (hidden == heads * 64)")
-        if self.image.patch % 8 or self.image.image_size % self.image.patch:
-            raise ValueError("image: patch must be a multiple of 8 and divide image_size")
-        if (self.image.channels * self.image.patch ** 2) % 64:
-            raise ValueError("image: C*patch*patch must be a multiple of 64")
+        if self.image.image_size % self.image.patch:
+            raise ValueError("image: patch must divide image_size")
+        if self.image.patch_dim % 2:
+            raise ValueError("image: C*patch*patch must be even (two 16-bit elements per 32-bit word)")
+        if self.image.act not in ("gelu", "quick_gelu"):
+            raise ValueError(f"image: unsupported activation {self.image.act!r}")
 
 
 @dataclass
@@ -192,7 +211,11 @@ class Layout:
             self._add(L + "output.dense.bias", (v.hidden,), "zeros")
         self._add("image_model.layernorm.weight", (v.hidden,), "ones")
         self._add("image_model.layernorm.bias", (v.hidden,), "zeros")
-        self._add("image_model.embeddings.patch_embeddings.projection.bias", (v.hidden,), "zeros")
+        if v.pre_ln:
+            self._add("image_model.pre_layernorm.weight", (v.hidden,), "ones")
+            self._add("image_model.pre_layernorm.bias", (v.hidden,), "zeros")
+        if v.patch_bias:
+            self._add("image_model.embeddings.patch_embeddings.projection.bias", (v.hidden,), "zeros")
         self._add("image_model.embeddings.cls_token", (1, 1, v.hidden), "normal")
         self._add("image_model.embeddings.position_embeddings", (1, v.n_tokens, v.hidden), "normal")
         self._add("bert.embeddings.LayerNorm.weight", (t.hidden,), "ones")
@@ -229,8 +252,11 @@ class Layout:
                       L + "output.LayerNorm.weight", L + "output.LayerNorm.bias"]
         names += ["bert_fc.weight", "bert_fc.bias"]
         names += ["image_model.embeddings.cls_token", "image_model.embeddings.position_embeddings",
-                  "image_model.embeddings.patch_embeddings.projection.weight",
-                  "image_model.embeddings.patch_embeddings.projection.bias"]
+                  "image_model.embeddings.patch_embeddings.projection.weight"]
+        if v.patch_bias:
+            names.append("image_model.embeddings.patch_embeddings.projection.bias")
+        if v.pre_ln:
+            names += ["image_model.pre_layernorm.weight", "image_model.pre_layernorm.bias"]
         for l in range(v.layers):
             L = f"image_model.encoder.layer.{l}."
             names += [L + "layernorm_before.weight", L + "layernorm_before.bias"]

@@ -94,6 +94,14 @@ MH_DEV float dgelu_f(float x) {
     return g.cdf + x * g.pdf;
 }
 
+// quick-GELU of the CLIP towers (transformers QuickGELUActivation: x * sigmoid(1.702 x)) and its derivative
+MH_DEV float qgelu_sig(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x)); }  // 1.702 * log2(e)
+MH_DEV float qgelu_f(float x) { return x * qgelu_sig(x); }
+MH_DEV float dqgelu_f(float x) {
+    const float s = qgelu_sig(x);
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
 // ---- dropout: stateless counter-based mask ------------------------------------------------------------
 // keep(idx) for element `idx` of dropout site `stream` under the step's rng words {seed_lo, seed_hi, step, -}:
 // two rounds of the lowbias32 integer hash over (seed, step, stream, idx).  The same function regenerates the

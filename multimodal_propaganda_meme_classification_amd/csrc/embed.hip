@@ -341,6 +341,36 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     *(i32x4*)(out + row * Kp + col) = u.v;
 }
 
+// Generic form (any patch size, e.g. CLIP's 14): one thread per (patch row, c, i) copies the P pixels of one patch line and,
+// for (c, i) == last, zero-fills the padding columns Kp .. ld-1 (the GEMM's contraction needs a multiple of 64).
+__global__ __launch_bounds__(256) void patchify_ld_kernel(const float* __restrict__ img, h16* __restrict__ out, int B,
+                                                          int C, int H, int W, int P, int ld) {
+    const int gh = H / P, gw = W / P, lines = C * P, Kp = C * P * P;
+    const size_t total = (size_t)B * gh * gw * lines;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ln = (int)(idx % lines);
+    const size_t row = idx / lines;
+    const int pw = (int)(row % gw), ph = (int)((row / gw) % gh), b = (int)(row / ((size_t)gw * gh));
+    const int c = ln / P, i = ln % P;
+    const float* src = img + (((size_t)b * C + c) * H + (ph * P + i)) * W + pw * P;
+    h16* dst = out + row * ld + (size_t)ln * P;
+    for (int j = 0; j < P; ++j) dst[j] = mh_f2bf(src[j]);
+    if (ln == lines - 1)
+        for (int k = Kp; k < ld; ++k) out[row * ld + k] = mh_f2bf(0.f);
+}
+
+// 2-D copy of 32-bit words: dst[r][0..cols) = src[r][0..cols), dst[r][cols..pad_to) = 0
+__global__ __launch_bounds__(256) void copy2d_u32_kernel(const uint32_t* __restrict__ src, int ld_src,
+                                                         uint32_t* __restrict__ dst, int ld_dst, int rows, int cols,
+                                                         int pad_to) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)rows * pad_to) return;
+    const int c = (int)(idx % pad_to);
+    const size_t r = idx / pad_to;
+    dst[r * ld_dst + c] = c < cols ? src[r * ld_src + c] : 0u;
+}
+
 __global__ __launch_bounds__(256) void vit_assemble_fwd_kernel(const h16* __restrict__ proj,
                                                                const float* __restrict__ cls,
                                                                const float* __restrict__ pos, h16* __restrict__ x,
@@ -461,6 +491,27 @@ extern "C" int mh_patchify(const float* image, void* patches, int B, int C, int 
     const size_t total = (size_t)B * (H / P) * (W / P) * (C * P * P / 8);
     hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        image, (h16*)patches, B, C, H, W, P);
+    return mh_launch_status();
+}
+
+extern "C" int mh_patchify_ld(const float* image, void* patches, int B, int C, int H, int W, int P, int ld,
+                              mh_stream_t stream) {
+    if (!image || !patches) return MH_EINVAL;
+    if (B < 1 || C < 1 || P < 1 || (H % P) || (W % P) || ld < C * P * P) return MH_ESHAPE;
+    const size_t total = (size_t)B * (H / P) * (W / P) * C * P;
+    hipLaunchKernelGGL(patchify_ld_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       image, (h16*)patches, B, C, H, W, P, ld);
+    return mh_launch_status();
+}
+
+extern "C" int mh_copy2d_u32(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, int pad_to,
+                             mh_stream_t stream) {
+    if (!src || !dst) return MH_EINVAL;
+    if (rows < 1 || cols < 1 || pad_to < cols || ld_src < cols || ld_dst < pad_to) return MH_ESHAPE;
+    if (((uintptr_t)src | (uintptr_t)dst) & 3) return MH_EINVAL;
+    const size_t total = (size_t)rows * pad_to;
+    hipLaunchKernelGGL(copy2d_u32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t*)src, ld_src, (uint32_t*)dst, ld_dst, rows, cols, pad_to);
     return mh_launch_status();
 }
 

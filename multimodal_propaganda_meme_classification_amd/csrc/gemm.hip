@@ -218,15 +218,25 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
             *(i32x4*)((h16*)P.aux + o) = u.v;
         }
         if (flags & MH_GEMM_GELU) {
+            if (flags & MH_GEMM_QUICK_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = qgelu_f(v[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            }
         }
         if (P.mul) {
             Pack8 u;
             if (PREF) u.v = pf->mul[it];
             else u.v = *(const i32x4*)((const h16*)P.mul + o);
+            if (flags & MH_GEMM_QUICK_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(mh_bf2f(u.e[e]));
+                for (int e = 0; e < 8; ++e) v[e] *= dqgelu_f(mh_bf2f(u.e[e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(mh_bf2f(u.e[e]));
+            }
         }
         if (P.residual) {
             Pack8 u;

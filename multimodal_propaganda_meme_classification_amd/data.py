@@ -70,19 +70,37 @@ class HashTokenizer:
         return {"input_ids": torch.tensor([ids], dtype=torch.long), "attention_mask": torch.tensor([mask], dtype=torch.long)}
 
 
+def resized_size(w: int, h: int, resize: int = 256):
+    """torchvision.transforms.Resize(int) (0.17.2, _compute_resized_output_size): the SHORT side becomes `resize`, the
+    long side int(resize * long / short) -- truncated, not rounded."""
+    short, long = (w, h) if w <= h else (h, w)
+    new_long = int(resize * long / short)
+    return (resize, new_long) if w <= h else (new_long, resize)
+
+
+def center_crop_box(w: int, h: int, size: int):
+    """torchvision.transforms.CenterCrop (functional.center_crop): top-left = int(round((dim - size) / 2.0))
+    (Python's round: half to even)."""
+    top = int(round((h - size) / 2.0))
+    left = int(round((w - size) / 2.0))
+    return left, top, left + size, top + size
+
+
+def _resize_center_crop(img, image_size: int, resize: int):
+    """Resize(256) -> CenterCrop(224) of the reference transform (Multimodal_example_task2C.txt:37-39) on a PIL image."""
+    from PIL import Image
+    w, h = img.size
+    nw, nh = resized_size(w, h, resize)
+    img = img.resize((nw, nh), Image.BILINEAR)
+    return img.crop(center_crop_box(nw, nh, image_size))
+
+
 def load_image_u8(path: str, image_size: int = 224, resize: int = 256) -> torch.Tensor:
     """Resize(256) -> CenterCrop(224) only: uint8 [H, W, 3].  ToTensor + Normalize then run on the device
     (``normalize_images``): the host ships a quarter of the bytes and skips the float arithmetic."""
     from PIL import Image
     img = Image.open(path).convert("RGB")
-    w, h = img.size
-    if w <= h:
-        nw, nh = resize, max(1, int(round(h * resize / w)))
-    else:
-        nw, nh = max(1, int(round(w * resize / h))), resize
-    img = img.resize((nw, nh), Image.BILINEAR)
-    left, top = (nw - image_size) // 2, (nh - image_size) // 2
-    img = img.crop((left, top, left + image_size, top + image_size))
+    img = _resize_center_crop(img, image_size, resize)
     return torch.from_numpy(np.ascontiguousarray(np.asarray(img, dtype=np.uint8)))
 
 
@@ -100,14 +118,7 @@ def load_image(path: str, image_size: int = 224, resize: int = 256) -> torch.Ten
     """PIL restatement of Resize(256) -> CenterCrop(224) -> ToTensor -> Normalize(ImageNet)."""
     from PIL import Image
     img = Image.open(path).convert("RGB")
-    w, h = img.size
-    if w <= h:
-        nw, nh = resize, max(1, int(round(h * resize / w)))
-    else:
-        nw, nh = max(1, int(round(w * resize / h))), resize
-    img = img.resize((nw, nh), Image.BILINEAR)
-    left, top = (nw - image_size) // 2, (nh - image_size) // 2
-    img = img.crop((left, top, left + image_size, top + image_size))
+    img = _resize_center_crop(img, image_size, resize)
     x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
     mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
     std = torch.tensor(IMAGENET_STD).view(3, 1, 1)

@@ -23,7 +23,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhAttnProblem, MhColsumJob, MhGemmProblem, MhHeadGrads,
+from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MH_GEMM_QUICK_GELU, MhAttnProblem, MhColsumJob, MhGemmProblem, MhHeadGrads,
                    MhHeadParams, MhLnBwdJob, MhLnFwdJob)
 from .config import Layout, ModelConfig
 
@@ -202,7 +202,7 @@ class Engine:
             e.mul, e.rowsum = _ptr(d.get("mul")), _ptr(d.get("rowsum"))
             e.M, e.N, e.K, e.lda, e.ldb, e.ldc = M, N, K, lda, ldb, ldc
             e.flags = (MH_GEMM_GELU if d.get("gelu") else 0) | (MH_GEMM_OUT_F32 if Cm.dtype == F32 else 0) | \
-                      (MH_GEMM_ACCUM if d.get("accum") else 0)
+                      (MH_GEMM_ACCUM if d.get("accum") else 0) | (MH_GEMM_QUICK_GELU if d.get("quick") else 0)
             e.alpha = float(d.get("alpha", 1.0))
             if d.get("drop") is not None:
                 e.drop_rng, e.drop_p, e.drop_stream = d["drop"]
@@ -426,15 +426,32 @@ class Engine:
             return dict(base, key_mask=mask)
 
         # image embeddings
-        patches = alloc("i.patches", (B * Np, Kp))
+        Kpp = v.patch_dim_padded                      # contraction of the patch projection (588 -> 640 for CLIP's 14x14 patches)
+        patches = alloc("i.patches", (B * Np, Kpp))
         proj = alloc("i.proj", (B * Np, Di))
         xi = [alloc("i.x0", (Ti, Di))]
-        f.c("mh_patchify", _ptr(image), _ptr(patches), B, v.channels, v.image_size, v.image_size, v.patch)
         wp = self.w(IMG + "embeddings.patch_embeddings.projection.weight")
-        self._gemm(pl, f, [self._fwd_prob(patches, wp, proj, B * Np, Di, Kp,
-                                          bias=self.p(IMG + "embeddings.patch_embeddings.projection.bias"))], False, False)
-        f.c("mh_vit_assemble_fwd", _ptr(proj), _ptr(self.p(IMG + "embeddings.cls_token")),
-            _ptr(self.p(IMG + "embeddings.position_embeddings")), _ptr(xi[0]), B, Np, Di)
+        if Kpp == Kp and v.patch % 8 == 0:
+            f.c("mh_patchify", _ptr(image), _ptr(patches), B, v.channels, v.image_size, v.image_size, v.patch)
+        else:
+            f.c("mh_patchify_ld", _ptr(image), _ptr(patches), B, v.channels, v.image_size, v.image_size, v.patch, Kpp)
+        if Kpp != Kp:       # zero-padded copy of the [Di][Kp] weight shadow (two 16-bit elements per word)
+            wpad = alloc("i.wp_pad", (Di, Kpp))
+            f.c("mh_copy2d_u32", _ptr(wp), Kp // 2, _ptr(wpad), Kpp // 2, Di, Kp // 2, Kpp // 2)
+            wp = wpad
+        pbias = self.p(IMG + "embeddings.patch_embeddings.projection.bias") if v.patch_bias else None
+        self._gemm(pl, f, [self._fwd_prob(patches, wp, proj, B * Np, Di, Kpp, bias=pbias)], False, False)
+        if v.pre_ln:        # CLIP: embeddings -> pre_layrnorm -> blocks
+            x0pre = alloc("i.x0pre", (Ti, Di))
+            m_pre, r_pre = alloc("i.mpre", (Ti,), F32), alloc("i.rpre", (Ti,), F32)
+            f.c("mh_vit_assemble_fwd", _ptr(proj), _ptr(self.p(IMG + "embeddings.cls_token")),
+                _ptr(self.p(IMG + "embeddings.position_embeddings")), _ptr(x0pre), B, Np, Di)
+            self._ln_fwd(pl, f, [self._ln_fwd_job(x0pre, IMG + "pre_layernorm.weight", IMG + "pre_layernorm.bias", xi[0],
+                                                  m_pre, r_pre, Ti, Di, v.ln_eps)])
+        else:
+            f.c("mh_vit_assemble_fwd", _ptr(proj), _ptr(self.p(IMG + "embeddings.cls_token")),
+                _ptr(self.p(IMG + "embeddings.position_embeddings")), _ptr(xi[0]), B, Np, Di)
+        quick = dict(quick=True) if v.act == "quick_gelu" else {}
 
         xt_last32 = alloc("t.xlast32", (Tt, Dt), F32)   # unrounded tower outputs for the fp32 head
         xf32 = alloc("i.xf32", (Ti, Di), F32)
@@ -509,7 +526,7 @@ class Engine:
                                          bias=self.p(LT + "intermediate.dense.bias"), aux=a["h"], gelu=True, **tp))
             if has_i:
                 pr.append(self._fwd_prob(b_["w"], self.w(LI + "intermediate.dense.weight"), b_["g"], Ti, Ii, Di,
-                                         bias=self.p(LI + "intermediate.dense.bias"), aux=b_["h"], gelu=True))
+                                         bias=self.p(LI + "intermediate.dense.bias"), aux=b_["h"], gelu=True, **quick))
             self._gemm(pl, f, pr, False, False)
             # FFN down + residual
             pr = []
@@ -639,7 +656,7 @@ class Engine:
             if has_t:
                 pr.append(self._dgrad_prob(t_dfm, self.w(LT + "output.dense.weight"), t_dh, Tt, Dt, It, mul=a["h"], **tp))
             if has_i:
-                pr.append(self._dgrad_prob(dXi[ci], self.w(LI + "output.dense.weight"), i_dh, Ti, Di, Ii, mul=b_["h"]))
+                pr.append(self._dgrad_prob(dXi[ci], self.w(LI + "output.dense.weight"), i_dh, Ti, Di, Ii, mul=b_["h"], **quick))
             self._gemm(pl, s, pr, False, True)
             # through W1 (text adds the residual branch df)
             pr = []
@@ -730,12 +747,21 @@ class Engine:
             sg.py(lambda: prev_.copy_(ids_))
 
         i_dproj = alloc("i.dproj", (B * Np, Di))
-        s.c("mh_vit_assemble_bwd", _ptr(dXi[ci]), _ptr(i_dproj), _ptr(self.g(IMG + "embeddings.cls_token")),
+        d_x0 = dXi[ci]
+        if v.pre_ln:        # through CLIP's pre_layrnorm
+            d_x0 = alloc("i.dx0pre", (Ti, Di))
+            self._ln_bwd(pl, s, [self._ln_bwd_job(pl, dXi[ci], pl.buf["i.x0pre"], IMG + "pre_layernorm.weight",
+                                                  IMG + "pre_layernorm.bias", pl.buf["i.mpre"], pl.buf["i.rpre"], d_x0, Ti, Di)])
+        s.c("mh_vit_assemble_bwd", _ptr(d_x0), _ptr(i_dproj), _ptr(self.g(IMG + "embeddings.cls_token")),
             _ptr(self.g(IMG + "embeddings.position_embeddings")), B, Np, Di, 1.0 / self.gscale)
         # (the patch-projection weight gradient is a 36-tile GEMM with a 6272-deep contraction, 115 us on 14 % of the CUs;
         #  moving it to the side stream beside the table gradients measured 0.12 ms SLOWER per step: it delays the join
         #  in front of the optimizer tail)
-        gw, gb = self.g(IMG + "embeddings.patch_embeddings.projection.weight"), self.g(IMG + "embeddings.patch_embeddings.projection.bias")
+        gw = self.g(IMG + "embeddings.patch_embeddings.projection.weight")
+        gb = self.g(IMG + "embeddings.patch_embeddings.projection.bias") if v.patch_bias else None
+        gw_out = gw
+        if Kpp != Kp:       # the GEMM writes a [Di][Kpp] gradient; its first Kp columns are copied into the flat buffer
+            gw = alloc("i.dwp_pad", (Di * Kpp,), F32)
         Tp = B * Np
         nsplit = min(_lib.MH_GEMM_MAX_GROUP, max(1, Tp // 512))
         if nsplit > 1:
@@ -743,7 +769,7 @@ class Engine:
             # outputs (288 tiles instead of 36), summed in a fixed order by the partial-sum kernel
             chunk = -(-Tp // nsplit)
             chunk = -(-chunk // 8) * 8
-            part_w = alloc("i.dwp_part", (2, nsplit, Di * Kp), F32)       # [which][split][Di*Kp]; which = 1 unused
+            part_w = alloc("i.dwp_part", (2, nsplit, Di * Kpp), F32)      # [which][split][Di*Kpp]; which = 1 unused
             part_b = alloc("i.dbp_part", (2, nsplit, Di), F32)
             probs = []
             for i in range(nsplit):
@@ -752,15 +778,19 @@ class Engine:
                 if kk <= 0:
                     part_w[0, i].zero_(), part_b[0, i].zero_()
                     continue
-                probs.append(self._wgrad_prob(i_dproj[k0:], patches[k0:], part_w[0, i], part_b[0, i], kk, Di, Kp))
+                probs.append(self._wgrad_prob(i_dproj[k0:], patches[k0:], part_w[0, i], part_b[0, i], kk, Di, Kpp))
             self._gemm(pl, s, probs, True, True)
-            for part, out, D_ in ((part_w, gw, Di * Kp), (part_b, gb, Di)):
+            for part, out, D_ in ((part_w, gw, Di * Kpp), (part_b, gb, Di)):
+                if out is None:
+                    continue
                 arr = (MhColsumJob * 1)()
                 arr[0].part, arr[0].out0, arr[0].out1 = _ptr(part), _ptr(out), None
                 pl.keep.append(arr)
                 s.c("mh_colsum_partials_f32", arr, 1, nsplit, D_, 1.0)
         else:
-            self._gemm(pl, s, [self._wgrad_prob(i_dproj, patches, gw, gb, Tp, Di, Kp)], True, True)
+            self._gemm(pl, s, [self._wgrad_prob(i_dproj, patches, gw, gb, Tp, Di, Kpp)], True, True)
+        if Kpp != Kp:
+            s.c("mh_copy2d_u32", _ptr(gw), Kpp, _ptr(gw_out), Kp, Di, Kp, Kp)
         if gather_world <= 0:
             table_grads(s, ids, t_dpre, prev_ids, B)
         # finish every LayerNorm's dgamma / dbeta from the partials

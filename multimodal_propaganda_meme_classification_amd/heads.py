@@ -1,0 +1,235 @@
+"""The reference's other module surfaces over the HIP towers.
+
+* ``TextClassifier`` -- ``LLMWithClassificationHead(model_name, pooling_type, num_classes)`` of
+  example_scripts/DistilBERT_example_task2A.py:140-210: the HF-Trainer protocol (``model(**batch)`` with ``labels``
+  returns ``(loss, logits)``, without them ``logits``), poolings cls / max / mean / attention / cnn, ``ValueError`` for
+  anything else (:173).  ``head="distilbert"`` is the stock ``DistilBertForSequenceClassification`` head of the
+  notebook variant (pre_classifier + ReLU + classifier; 135 326 210 parameters with DistilBERT-multilingual,
+  DistilBERT_example_task2A.ipynb:4301).
+* ``TrainerModel`` -- the two-tower ``MultimodalClassifier`` behind the same protocol with the batch keys of
+  ResNet_example_task2B.py:206-210 (``pixel_values``, ``labels``) plus ``input_ids`` / ``attention_mask``.
+* ``KevinMultimodalClassifier`` -- ``MultimodalClassifier(fusion_method)`` of Multimodal_example_task2C.py:587-685: the
+  five-argument ``forward(text, image, mask, caption_text, caption_text_mask) -> [B]``, ``get_params(lr)`` with the
+  reference's grouping (:645-664), ``ConcatAttention3`` (:476-499), ``Linear + BatchNorm1d + ReLU`` projections
+  (:599-612), ``Linear(512, 1) + BatchNorm1d(1)`` (:641-643).
+
+The encoders run in libmemehip (model.MultimodalClassifier / TextEncoder); poolings, projections and the fusion run in
+the HIP kernels of ops.py (pool_* / linear_bn_act_* / softmax_gate_*).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, fused
+from .config import ImageConfig, ModelConfig, TextConfig
+from .model import CrossEntropyLoss, MultimodalClassifier, TextEncoder, flatten_parameters
+
+POOLINGS = ("cls", "max", "mean", "attention", "cnn")
+
+
+class SequencePooling(nn.Module):
+    """The pooling branches of ``LLMWithClassificationHead`` (Multimodal_example_task2C.py:339-392,
+    DistilBERT_example_task2A.py:162-210) over a last hidden state [B, S, D] (f32, device) and the attention mask."""
+
+    def __init__(self, pooling_type: str, hidden_size: int = 768, attention_hidden_size: int = 512, cnn_kernel_size: int = 3):
+        super().__init__()
+        self.pooling_type = pooling_type
+        if pooling_type == "attention":
+            self.attention = nn.Sequential(nn.Linear(hidden_size, attention_hidden_size), nn.Tanh(),
+                                           nn.Linear(attention_hidden_size, 1))
+        elif pooling_type == "cnn":
+            self.conv1d = nn.Conv1d(hidden_size, hidden_size, kernel_size=cnn_kernel_size, padding=cnn_kernel_size // 2)
+
+    def forward(self, hidden: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        kind = self.pooling_type
+        if kind == "cls":
+            return hidden[:, 0]
+        if kind == "max":
+            return fused.max_pool(hidden)
+        if kind == "mean":
+            return fused.masked_mean_pool(hidden, attention_mask)
+        if kind == "attention":
+            a = self.attention
+            return fused.attention_pool(hidden, attention_mask, a[0].weight, a[0].bias, a[2].weight, a[2].bias)
+        if kind == "cnn":
+            return fused.conv1d_relu_max_pool(hidden, self.conv1d.weight, self.conv1d.bias)
+        raise ValueError(f"Unsupported pooling type: {kind}")
+
+
+class TextClassifier(nn.Module):
+    """``LLMWithClassificationHead`` with the HF-Trainer protocol (DistilBERT_example_task2A.py:140-183).
+
+    ``text`` is the encoder's shape (DistilBERT-multilingual: ``TextConfig(vocab_size=119547, layers=6, type_vocab=0)``).
+    ``forward(input_ids, attention_mask, labels=None)``: ``(loss, logits)`` when ``labels`` is given, else ``logits``."""
+
+    def __init__(self, text: TextConfig, pooling_type: str = "attention", num_classes: int = 2, hidden_size: Optional[int] = None,
+                 attention_hidden_size: int = 512, cnn_kernel_size: int = 3, head: str = "linear", compute_dtype: str = "bf16",
+                 seed: int = 0):
+        super().__init__()
+        if pooling_type not in POOLINGS:
+            raise ValueError(f"Unsupported pooling type: {pooling_type}")
+        if head not in ("linear", "distilbert"):
+            raise ValueError(f"head must be 'linear' or 'distilbert', got {head!r}")
+        D = hidden_size or text.hidden
+        self.pooling_type, self.hidden_size, self.num_classes, self.head = pooling_type, D, num_classes, head
+        self.model = TextEncoder(text, pool="cls", compute_dtype=compute_dtype, seed=seed)
+        self.pool = SequencePooling(pooling_type, D, attention_hidden_size, cnn_kernel_size)
+        if head == "distilbert":        # DistilBertForSequenceClassification: pooled -> pre_classifier -> ReLU -> (dropout) -> classifier
+            self.pre_classifier = nn.Linear(D, D)
+            self.classifier = nn.Linear(D, num_classes)
+        else:
+            self.output_layer = nn.Linear(D, num_classes)
+        self.loss_fct = CrossEntropyLoss()
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        return self
+
+    def forward(self, input_ids=None, attention_mask=None, labels=None, **unused):
+        if input_ids is None or attention_mask is None:
+            raise ValueError("TextClassifier.forward needs input_ids and attention_mask")
+        if self.pooling_type == "cls":
+            pooled = self.model(input_ids, attention_mask)
+        else:
+            pooled = self.pool(self.model.hidden_states(input_ids, attention_mask), attention_mask)
+        if self.head == "distilbert":
+            logits = self.classifier(torch.relu(self.pre_classifier(pooled)))
+        else:
+            logits = self.output_layer(pooled)
+        if labels is not None:
+            loss = self.loss_fct(logits.view(-1, self.num_classes), labels.view(-1))
+            return loss, logits
+        return logits
+
+    def n_parameters(self) -> int:
+        """Trainable parameters of the classifier the reference counts (DistilBERT_example_task2A.ipynb:4301): the text
+        encoder + head, without the inert stub image side of the lockstep launch plan."""
+        enc = sum(v.numel() for v in self.model.state_dict().values())
+        own = sum(p.numel() for n, p in self.named_parameters() if not n.startswith("model."))
+        return enc + own
+
+
+class TrainerModel(nn.Module):
+    """The Subtask-2C two-tower classifier behind the HF-Trainer protocol: ``model(**batch)`` with the collator's keys
+    ``input_ids, attention_mask, pixel_values[, labels]`` (ResNet_example_task2B.py:206-210 for the image side,
+    DistilBERT_example_task2A.py:159 for the text side) -> ``(loss, logits)`` / ``logits``."""
+
+    def __init__(self, model: MultimodalClassifier):
+        super().__init__()
+        self.model = model
+        self.loss_fct = CrossEntropyLoss()
+
+    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, labels=None, **unused):
+        if input_ids is None or attention_mask is None or pixel_values is None:
+            raise ValueError("TrainerModel.forward needs input_ids, attention_mask and pixel_values")
+        logits = self.model(input_ids, pixel_values, attention_mask)
+        if labels is not None:
+            return self.loss_fct(logits, labels.view(-1)), logits
+        return logits
+
+
+class LinearBNReLU(nn.Sequential):
+    """``nn.Sequential(nn.Linear(i, o), nn.BatchNorm1d(o), nn.ReLU())`` (Multimodal_example_task2C.py:599-601) with the
+    reference's state_dict keys (``0.weight``, ``1.running_mean`` ...), run as ONE fused HIP op."""
+
+    def __init__(self, in_features: int, out_features: int, relu: bool = True):
+        mods = [nn.Linear(in_features, out_features), nn.BatchNorm1d(out_features)]
+        if relu:
+            mods.append(nn.ReLU())
+        super().__init__(*mods)
+        self.relu = relu
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return fused.linear_bn_act(x, self[0], self[1], self.relu)
+
+
+class ConcatAttention3(nn.Module):
+    """Multimodal_example_task2C.py:476-499: softmax-gated concat of the three towers' features + reduce."""
+
+    def __init__(self, input_dim: int, attention_dim: int):
+        super().__init__()
+        self.attention_layer = nn.Sequential(nn.Linear(input_dim, input_dim), nn.BatchNorm1d(input_dim), nn.ReLU(),
+                                             nn.Softmax(dim=1))
+        self.reduce = LinearBNReLU(input_dim, attention_dim)
+
+    def forward(self, text_features, image_features, caption_features):
+        concatenated = torch.cat((text_features, image_features, caption_features), dim=1)
+        gate_in = fused.linear_bn_act(concatenated, self.attention_layer[0], self.attention_layer[1], True)
+        attended = fused.softmax_gate(gate_in, concatenated)        # softmax(gate_in, dim=1) * concatenated
+        return self.reduce(attended)
+
+
+class KevinMultimodalClassifier(nn.Module):
+    """``MultimodalClassifier(fusion_method)`` of Multimodal_example_task2C.py:587-685 on the HIP towers.
+
+    text tower + image tower = one lockstep ``MultimodalClassifier`` (``towers``; the reference's ``text_model`` and
+    ``image_model.image_model``), caption tower = ``TextEncoder`` (``caption_text_model``).  The image tower's
+    ``fine_tune`` MLP of ``CustomDenseNet161`` (:571-574) takes the tower's feature width instead of the hard-coded 512
+    (the reference shape-errors for anything but ResNet-18/34)."""
+
+    def __init__(self, fusion_method: str = "concatenation", text: Optional[TextConfig] = None,
+                 image: Optional[ImageConfig] = None, caption: Optional[TextConfig] = None, proj: int = 512,
+                 compute_dtype: str = "bf16", seed: int = 0):
+        super().__init__()
+        if fusion_method != "concatenation":
+            raise ValueError(f"Unsupported fusion method: {fusion_method}")
+        tc, ic = text or TextConfig(), image or ImageConfig()
+        cc = caption or TextConfig(vocab_size=30522)
+        self.fusion_method = fusion_method
+        self.towers = MultimodalClassifier.from_config(ModelConfig(text=tc, image=ic, compute_dtype=compute_dtype), seed=seed)
+        self.caption_text_model = TextEncoder(cc, pool="cls", compute_dtype=compute_dtype, seed=seed + 1)
+        self.text_dropout, self.caption_text_dropout = nn.Dropout(0.3), nn.Dropout(0.3)
+        self.text_fc = LinearBNReLU(tc.hidden, proj)
+        self.caption_text_fc = LinearBNReLU(cc.hidden, proj)
+        self.image_fine_tune = nn.Sequential(nn.Linear(ic.hidden, proj), nn.ReLU(inplace=True), nn.Dropout(p=0.35),
+                                             nn.Linear(proj, proj))
+        self.fusion_layer = ConcatAttention3(3 * proj, proj)
+        self.output_fc = LinearBNReLU(proj, 1, relu=False)
+        self._head_flat = False
+
+    def head_modules(self):
+        return [self.text_fc, self.caption_text_fc, self.image_fine_tune, self.fusion_layer, self.output_fc]
+
+    def _flatten_head(self):
+        """The head's parameters live in one flat buffer (flatten_parameters), so the ONE fused ``memehip.Adam`` over
+        ``get_params(lr)`` updates them in a single launch and counts them in the global clip norm."""
+        if not self._head_flat and next(self.output_fc.parameters()).is_cuda:
+            holder = nn.ModuleList(self.head_modules())
+            flatten_parameters(holder)
+            self._head_holder_flat = holder._memehip_flat
+            self._head_flat = True
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self._head_flat = False
+        self._flatten_head()
+        return self
+
+    def get_params(self, lr: float):
+        """Multimodal_example_task2C.py:645-664: fusion layer and everything that is neither text nor image model at
+        ``lr``; ``text_model`` parameters (the caption tower's name ``caption_text_model`` contains it too) and
+        ``image_model`` parameters (the whole CustomDenseNet161, its fine_tune MLP included) at ``0.8 * lr``."""
+        self._flatten_head()
+        attention, text, image = [], [], []
+        for name, p in self.towers.named_parameters():
+            (text if name.startswith("bert.") else image if name.startswith("image_model.") else attention).append(p)
+        text += list(self.caption_text_model.parameters())
+        image += list(self.image_fine_tune.parameters())
+        for m in (self.text_fc, self.caption_text_fc, self.fusion_layer, self.output_fc):
+            attention += list(m.parameters())
+        return [{"params": attention, "lr": lr}, {"params": text, "lr": lr * 0.8}, {"params": image, "lr": lr * 0.8}]
+
+    def forward(self, text, image, mask, caption_text, caption_text_mask):
+        for t_ in (text, image, mask, caption_text, caption_text_mask):
+            if not t_.is_cuda:
+                raise _lib.MemehipError("memehip runs on the HIP device only (no CPU fallback): move the batch with .to(device)")
+        t, v = self.towers.encode(text, image, mask)
+        c = self.caption_text_model(caption_text, caption_text_mask)
+        text_output = self.text_fc(self.text_dropout(t))
+        caption_output = self.caption_text_fc(self.caption_text_dropout(c))
+        image_output = self.image_fine_tune(v)
+        fused_output = self.fusion_layer(text_output, image_output, caption_output)
+        return self.output_fc(fused_output).squeeze(1)

@@ -32,6 +32,8 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 # flat-parameter storage address -> owning model (lets Adam(model.parameters()) find the bf16 shadow)
 _REGISTRY: "weakref.WeakValueDictionary[int, MultimodalClassifier]" = weakref.WeakValueDictionary()
+# flat-parameter storage address of a flatten_parameters() head -> its flat gradient buffer (zeroed by Adam.zero_grad)
+_LOOSE: "weakref.WeakValueDictionary[int, torch.Tensor]" = weakref.WeakValueDictionary()
 
 
 class _Node(nn.Module):
@@ -48,18 +50,36 @@ def _register(root: nn.Module, dotted: str, param: nn.Parameter):
     node.register_parameter(parts[-1], param)
 
 
+def _run_forward(plan: Plan) -> int:
+    """Run the plan's forward launches; returns the plan's forward generation.  The activations a backward needs live
+    in the plan's static buffers, so a second forward of the same shape before that backward would silently replace
+    them: every forward bumps the generation and the autograd nodes refuse a backward whose generation is stale."""
+    plan.generation = getattr(plan, "generation", 0) + 1
+    plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+    return plan.generation
+
+
+def _check_generation(ctx):
+    if ctx.generation != ctx.plan.generation:
+        raise RuntimeError(
+            "memehip: backward() of a forward whose activations were overwritten by a later forward of the same shape "
+            "(the launch plan keeps ONE set of activations per (batch, seq_len)); run backward before the next forward. "
+            "Gradient accumulation over micro-batches is not supported: every backward overwrites .grad.")
+
+
 class _ModelFn(torch.autograd.Function):
     """Opaque autograd node: forward = Plan.fwd, backward = the backward segments."""
 
     @staticmethod
     def forward(ctx, anchor, model, plan):
         ctx.model, ctx.plan = model, plan
-        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        ctx.generation = _run_forward(plan)
         return plan.buf["logits"].clone()
 
     @staticmethod
     def backward(ctx, dlogits):
         model, plan = ctx.model, ctx.plan
+        _check_generation(ctx)
         plan.buf["dlogits"].copy_(dlogits.to(F32))
         model._run_backward(plan)
         return None, None, None
@@ -72,12 +92,13 @@ class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, plan):
         ctx.model, ctx.plan = model, plan
-        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        ctx.generation = _run_forward(plan)
         return plan.buf["h.pooled"].clone()
 
     @staticmethod
     def backward(ctx, d_pooled):
         model, plan = ctx.model, ctx.plan
+        _check_generation(ctx)
         plan.buf["h.d_pooled"].copy_(d_pooled.to(F32))
         model._run_backward(plan)
         return None, None, None
@@ -89,13 +110,14 @@ class _SequenceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, plan):
         ctx.model, ctx.plan = model, plan
-        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        ctx.generation = _run_forward(plan)
         B, S = plan.B, plan.S
         return plan.buf["t.xlast32"].view(B, S, -1).clone(), plan.buf["i.xf32"].view(B, -1, model.config.image.hidden).clone()
 
     @staticmethod
     def backward(ctx, d_text, d_image):
         model, plan = ctx.model, ctx.plan
+        _check_generation(ctx)
         scale = model.config.stream_scale          # the 16-bit gradient streams carry this power of two (fp16 build)
         plan.buf["h.d_seq_t"].copy_((d_text.to(F32) * scale).reshape(plan.buf["h.d_seq_t"].shape))
         plan.buf["h.d_seq_i"].copy_((d_image.to(F32) * scale).reshape(plan.buf["h.d_seq_i"].shape))
@@ -257,20 +279,28 @@ class MultimodalClassifier(nn.Module):
         self._T16 = torch.float16 if cfg.compute_dtype == "fp16" else BF16
         self._SH = torch.zeros(self.layout.n_shadow, dtype=self._T16, device=device)
         self._names = self.layout.state_dict_order()
-        self._params: Dict[str, nn.Parameter] = {}
+        self._params: Dict[str, nn.Parameter] = {}      # keyed by the layout's (internal) names
         for name in self._names:
             s = self.layout.spec[name]
             prm = nn.Parameter(self._P[s.offset:s.offset + s.numel].view(s.shape), requires_grad=True)
             self._params[name] = prm
-            _register(self, name, prm)
+            _register(self, self._external_name(name), prm)
         self._engine: Optional[Engine] = None
         self._shadow_stale = True
+        self._shadow_version = -1       # self._P._version the 16-bit shadow was cast from (see weights_changed)
         self._rng_seed, self._rng_step = 0x5EED1234, 0
         self._rng_ring = None
         if init:
             self.reset_parameters(seed)
         self._attach_grads()
         _REGISTRY[self._P.untyped_storage().data_ptr()] = self
+
+    def _external_name(self, name: str) -> str:
+        """state_dict / named_parameters name of a layout entry: the image projection is ``image_fc`` or, with
+        ``config.image_fc_name = "resnet_fc"``, the organizers' ``resnet_fc`` (Multimodal_example_task2C.txt:165)."""
+        if name.startswith("image_fc."):
+            return self.config.image_fc_name + name[len("image_fc"):]
+        return name
 
     # ---- construction helpers -------------------------------------------------------------------------
     @classmethod
@@ -320,8 +350,8 @@ class MultimodalClassifier(nn.Module):
         return self
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        sd = {("image_fc" + k[len("resnet_fc"):] if k.startswith("resnet_fc") else k): v for k, v in state_dict.items()}
-        missing = [k for k in self._names if k not in sd]
+        sd = {("image_fc" + k[len("resnet_fc"):] if k.startswith("resnet_fc.") else k): v for k, v in state_dict.items()}
+        missing = [self._external_name(k) for k in self._names if k not in sd]
         unexpected = [k for k in sd if k not in self._params]
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing {missing[:4]} unexpected {unexpected[:4]}")
@@ -347,10 +377,22 @@ class MultimodalClassifier(nn.Module):
         """bf16 copy of the GEMM matrices (kept in sync by Adam.step(); call after editing weights by hand)."""
         self._get_engine()
         ops.cast_f32_bf16(self._P[:self.layout.n_shadow], self._SH)
-        self._shadow_stale = False
+        self._shadow_synced()
 
     def mark_weights_changed(self):
         self._shadow_stale = True
+
+    def _shadow_synced(self):
+        self._shadow_stale = False
+        self._shadow_version = self._P._version
+
+    def weights_changed(self) -> bool:
+        """True when the fp32 master weights were edited since the 16-bit shadow (what every tower GEMM reads) was last
+        cast from them.  The parameters are views of one flat buffer and share its autograd version counter, so ANY
+        in-place update through torch -- ``torch.optim.Adam(model.parameters()).step()``, HF Trainer's AdamW,
+        ``p.data.mul_()``, ``clip``-free SGD -- is seen here without a hook; the fused ``memehip.Adam`` rewrites the
+        shadow itself (mh_adam_step) and re-syncs the version."""
+        return self._shadow_stale or self._P._version != self._shadow_version
 
     def manual_seed(self, seed: int):
         """Seed of the dropout masks (stateless counter RNG: mask = f(seed, step, site, element))."""
@@ -378,7 +420,7 @@ class MultimodalClassifier(nn.Module):
         if tuple(image.shape) != (B, v.channels, v.image_size, v.image_size):
             raise ValueError(f"image must be [B,{v.channels},{v.image_size},{v.image_size}], got {tuple(image.shape)}")
         plan = eng.plan(B, S, self.training, features=features)
-        if self._shadow_stale:
+        if self.weights_changed():
             self.refresh_shadow()
         if self.training:
             self._advance_rng(plan)
@@ -403,7 +445,7 @@ class MultimodalClassifier(nn.Module):
         if torch.is_grad_enabled() and self.training:
             anchor = self._params[self._names[0]]
             return _ModelFn.apply(anchor, self, plan)
-        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        _run_forward(plan)
         return plan.buf["logits"].clone()
 
     # ---- fused step (no autograd): forward + loss + backward ---------------------------------------------------
@@ -421,7 +463,7 @@ class MultimodalClassifier(nn.Module):
         if torch.is_grad_enabled() and self.training:
             pooled = _EncodeFn.apply(self._params[self._names[0]], self, plan)
         else:
-            plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+            _run_forward(plan)
             pooled = plan.buf["h.pooled"].clone()
         return pooled[:, :Dt], pooled[:, Dt:]
 
@@ -436,7 +478,7 @@ class MultimodalClassifier(nn.Module):
         plan = self._prepare(text, image, mask, features="sequence")
         if torch.is_grad_enabled() and self.training:
             return _SequenceFn.apply(self._params[self._names[0]], self, plan)
-        plan.fwd.run(torch.cuda.current_stream().cuda_stream)
+        _run_forward(plan)
         B, S = plan.B, plan.S
         return (plan.buf["t.xlast32"].view(B, S, -1).clone(),
                 plan.buf["i.xf32"].view(B, -1, self.config.image.hidden).clone())
@@ -463,7 +505,7 @@ class MultimodalClassifier(nn.Module):
         """Returns (loss[1], n_correct[1], logits[B,C]) device tensors; gradients land in .grad."""
         plan = self._prepare(text, image, mask, labels)
         stream = torch.cuda.current_stream().cuda_stream
-        plan.fwd.run(stream)
+        _run_forward(plan)
         plan.loss.run(stream)
         self._run_backward(plan, grad_hook)
         return plan.buf["loss"], plan.buf["ncorrect"], plan.buf["logits"]
@@ -564,48 +606,86 @@ class Adam(torch.optim.Optimizer):
         self.skip_untouched_rows = bool(skip_untouched_embedding_rows)
 
     def _bind(self):
+        """Group the parameters by the flat buffer they live in.  Usually that is ONE MultimodalClassifier; Kevin's
+        three-tower model (Multimodal_example_task2C.py:645-664: ONE optim.Adam over fusion head + text + caption + image
+        parameters) spans several: the two-tower buffer, the caption TextEncoder's, and the head's
+        (``flatten_parameters(head)``).  Each buffer is a *bucket* with its own moments; the gradient norm used for
+        clipping is the GLOBAL one over all buckets, as clip_grad_norm_(model.parameters(), .) is (...task2C.py:713-715)."""
         if self._flat is not None:
             return
-        ps = [p for g in self.param_groups for p in g["params"]]
-        base = min(ps, key=lambda p: p.data_ptr())
-        storage = base.untyped_storage()
-        n = storage.nbytes() // 4
-        P = torch.empty(0, dtype=F32, device=base.device).set_(storage, 0, (n,), (1,))
-        if not P.is_cuda:
-            raise _lib.MemehipError("Adam: parameters must live on the HIP device (no CPU fallback)")
-        for p in ps:
-            if p.untyped_storage().data_ptr() != storage.data_ptr():
-                raise ValueError("the fused Adam needs the parameters of ONE MultimodalClassifier (one flat buffer)")
-        g0 = base.grad
-        if g0 is None:
-            raise RuntimeError("Adam.step() before any backward")
-        gs = g0.untyped_storage()
-        G = torch.empty(0, dtype=F32, device=base.device).set_(gs, 0, (n,), (1,))
-        if self._model is None:
-            self._model = _REGISTRY.get(storage.data_ptr())
-        dev = base.device
-        # contiguous runs (in elements, 4-aligned) of every parameter group
-        runs = []
+        by_storage: Dict[int, list] = {}
         for gi, g in enumerate(self.param_groups):
-            spans = sorted((p.storage_offset(), p.storage_offset() + (p.numel() + 3) // 4 * 4) for p in g["params"])
-            cur = None
-            for a, b in spans:
-                if cur is not None and a <= cur[1]:
-                    cur[1] = max(cur[1], b)
-                else:
-                    if cur is not None:
-                        runs.append((gi, cur[0], cur[1]))
-                    cur = [a, b]
-            if cur is not None:
-                runs.append((gi, cur[0], cur[1]))
-        self._flat = dict(P=P, G=G, M=torch.zeros(n, device=dev), V=torch.zeros(n, device=dev),
-                          hyper=[torch.zeros(8, device=dev) for _ in self.param_groups], ws=torch.zeros(1024, device=dev),
-                          nrm=torch.zeros(1, device=dev), runs=runs,
-                          ring=[torch.zeros((len(self.param_groups), 8), dtype=F32).pin_memory() for _ in range(32)])
+            for p in g["params"]:
+                by_storage.setdefault(p.untyped_storage().data_ptr(), []).append((gi, p))
+        buckets = []
+        for sptr, items in by_storage.items():
+            base = min((p for _, p in items), key=lambda p: p.data_ptr())
+            storage = base.untyped_storage()
+            n = storage.nbytes() // 4
+            if not base.is_cuda:
+                raise _lib.MemehipError("Adam: parameters must live on the HIP device (no CPU fallback)")
+            if n % 4:
+                raise ValueError(f"memehip.Adam: a parameter buffer of {n} elements is not a multiple of 4 (16-byte kernel "
+                                 "accesses): re-home loose parameters with memehip.flatten_parameters(module) first")
+            P = torch.empty(0, dtype=F32, device=base.device).set_(storage, 0, (n,), (1,))
+            if base.grad is None:
+                raise RuntimeError("Adam.step() before any backward")
+            gs = base.grad.untyped_storage()
+            for _, p in items:
+                if p.grad is None or p.grad.untyped_storage().data_ptr() != gs.data_ptr() or \
+                        p.grad.storage_offset() != p.storage_offset():
+                    raise ValueError("memehip.Adam: the gradients must mirror the parameters' flat buffer (the parameters of a "
+                                     "MultimodalClassifier / TextEncoder, or of a module passed through flatten_parameters)")
+            G = torch.empty(0, dtype=F32, device=base.device).set_(gs, 0, (n,), (1,))
+            dev = base.device
+            # contiguous runs (in elements, 4-aligned) of every parameter group
+            runs = []
+            for gi in sorted({gi for gi, _ in items}):
+                spans = sorted((p.storage_offset(), p.storage_offset() + (p.numel() + 3) // 4 * 4) for g2, p in items if g2 == gi)
+                cur = None
+                for a, b in spans:
+                    if cur is not None and a <= cur[1]:
+                        cur[1] = max(cur[1], b)
+                    else:
+                        if cur is not None:
+                            runs.append((gi, cur[0], cur[1]))
+                        cur = [a, b]
+                if cur is not None:
+                    runs.append((gi, cur[0], cur[1]))
+            model = _REGISTRY.get(storage.data_ptr())
+            buckets.append(dict(P=P, G=G, M=torch.zeros(n, device=dev), V=torch.zeros(n, device=dev),
+                                ws=torch.zeros(1024, device=dev), nrm=torch.zeros(1, device=dev), runs=runs, model=model))
+        # the bucket of the (first) two-tower model is the primary one: GraphedStep and the optimizer-in-backward slices
+        # address it by flat offsets
+        buckets.sort(key=lambda bk: 0 if (self._model is not None and bk["model"] is self._model) else
+                     (1 if isinstance(bk["model"], MultimodalClassifier) else 2))
+        if self._model is None:
+            self._model = buckets[0]["model"]
+        dev = buckets[0]["P"].device
+        shared = dict(hyper=[torch.zeros(8, device=dev) for _ in self.param_groups],
+                      ring=[torch.zeros((len(self.param_groups), 8), dtype=F32).pin_memory() for _ in range(32)],
+                      nrm_total=torch.zeros(1, device=dev))
+        for bk in buckets:
+            bk.update(shared)
+        self._buckets = buckets
+        self._flat = buckets[0]
 
     def zero_grad(self, set_to_none: bool = False):
-        # every gradient is overwritten by the next backward (the embedding table re-zeroes the rows
-        # it touched), so there is nothing to clear; the views stay attached.
+        # every tower gradient is overwritten by the next backward (the embedding table re-zeroes the rows
+        # it touched), so there is nothing to clear; the views stay attached.  Heads re-homed by
+        # flatten_parameters() receive their gradients from autograd, which ACCUMULATES: zero those buffers.
+        if self._flat is not None:
+            for f in self._buckets:
+                if f["model"] is None:
+                    f["G"].zero_()
+        else:
+            seen = set()
+            for g in self.param_groups:
+                for p in g["params"]:
+                    sp = p.untyped_storage().data_ptr()
+                    if sp not in seen and sp in _LOOSE:
+                        seen.add(sp)
+                        _LOOSE[sp].zero_()
         return None
 
     def _write_hyper(self):
@@ -626,16 +706,36 @@ class Adam(torch.optim.Optimizer):
 
     def launch(self, only: Optional[tuple] = None, skip: Optional[list] = None):
         """Enqueue grad-norm (if clipping) + the fused update(s); hyper-parameters are read from device memory.
-        ``only=(a, b)`` updates just that slice of the flat buffer (optimizer-in-backward: a layer's matrices are
+        ``only=(a, b)`` updates just that slice of the primary flat buffer (optimizer-in-backward: a layer's matrices are
         updated on the side stream as soon as their gradients are complete); ``skip`` = slices already done."""
-        f = self._flat
-        model = self._model
-        n_shadow = model.layout.n_shadow if model is not None else 0
         nrm = None
         if self.max_grad_norm is not None or self.skip_nonfinite:
             assert only is None, "clipping / the non-finite check need the global gradient norm before any update"
+            nrm = self._global_norm_sq()
+        for bi, f in enumerate(self._buckets):
+            if bi > 0 and only is not None:
+                break
+            self._launch_bucket(f, nrm, only if bi == 0 else None, skip if bi == 0 else None)
+
+    def _global_norm_sq(self) -> torch.Tensor:
+        """Sum of squares of every gradient this optimizer owns (device f32[1]): one mh_sumsq_f32 per flat buffer."""
+        for f in self._buckets:
             ops.sumsq(f["G"], f["ws"], f["nrm"])
-            nrm = f["nrm"]
+        if len(self._buckets) == 1:
+            return self._buckets[0]["nrm"]
+        total = self._flat["nrm_total"]
+        torch.stack([f["nrm"][0] for f in self._buckets]).sum(dim=0, keepdim=True, out=total)
+        return total
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm of the gradients times the data-parallel scale, what ``clip_grad_norm_(model.parameters(),
+        float("inf"))`` returns in the reference's loop (Multimodal_example_task2C.py:713): a device scalar, no sync."""
+        self._bind()
+        return self._global_norm_sq().sqrt()[0] * abs(self.grad_scale)
+
+    def _launch_bucket(self, f, nrm, only, skip):
+        model = f["model"]
+        n_shadow = model.layout.n_shadow if model is not None else 0
         runs = []
         for gi, a, b in f["runs"]:
             pieces = [(a, b)]
@@ -653,7 +753,7 @@ class Adam(torch.optim.Optimizer):
                             nxt.append((sb, y))
                 pieces = nxt
             runs += [(gi, x, y) for x, y in pieces if y > x]
-        table = self._word_table()
+        table = self._word_table(f)
         if table is not None:       # carve the word-embedding table out of its run: it goes through the row-skipping kernel
             ta, tb, V, D, touched = table
             nxt = []
@@ -673,15 +773,15 @@ class Adam(torch.optim.Optimizer):
             shadow = model.flat_shadow[a:a + sh_n] if (model is not None and sh_n > 0) else None
             ops.adam_step(f["P"][a:b], f["M"][a:b], f["V"][a:b], f["G"][a:b], shadow, sh_n, f["hyper"][gi], self.decoupled,
                           nrm, float(self.max_grad_norm or 0.0))
-        if model is not None:
-            model._shadow_stale = False
+        if model is not None and only is None:
+            model._shadow_synced()
 
-    def _word_table(self):
-        """(start, end, rows, D, touched-row bytes) of the word-embedding table in the flat buffer, or None."""
-        model = self._model
+    def _word_table(self, f=None):
+        """(start, end, rows, D, touched-row bytes) of the word-embedding table in a bucket's flat buffer, or None."""
+        f = self._flat if f is None else f
+        model = f["model"]
         if not self.skip_untouched_rows or model is None:
             return None
-        f = self._flat
         if "row_live" not in f:
             sp = model.layout.spec["bert.embeddings.word_embeddings.weight"]
             V, D = sp.shape
@@ -695,9 +795,71 @@ class Adam(torch.optim.Optimizer):
         return f["table"] + (model._get_engine().word_row_live,)
 
     def state_dict(self):
+        """Checkpoint of the optimizer: step count, the moment buffers (copies, flat over each parameter buffer; plain
+        tensors for the usual single-model case, lists when the optimizer spans several buffers) and the per-group
+        hyper-parameters."""
         self._bind()
-        return dict(step=self._step, exp_avg=self._flat["M"], exp_avg_sq=self._flat["V"],
+        ms = [f["M"].clone() for f in self._buckets]
+        vs = [f["V"].clone() for f in self._buckets]
+        one = len(self._buckets) == 1
+        return dict(step=self._step, exp_avg=ms[0] if one else ms, exp_avg_sq=vs[0] if one else vs,
                     param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
+
+    def load_state_dict(self, state_dict):
+        """Restore ``state_dict()``'s output: moments, step count (the bias corrections follow from it), group
+        hyper-parameters; the word-embedding rows with optimizer history are rebuilt from the moments."""
+        self._bind()
+        for key in ("step", "exp_avg", "exp_avg_sq"):
+            if key not in state_dict:
+                raise KeyError(f"memehip.Adam.load_state_dict: missing {key!r} (expected the dict Adam.state_dict() returns)")
+        ms, vs = state_dict["exp_avg"], state_dict["exp_avg_sq"]
+        ms = ms if isinstance(ms, (list, tuple)) else [ms]
+        vs = vs if isinstance(vs, (list, tuple)) else [vs]
+        if len(ms) != len(self._buckets) or len(vs) != len(self._buckets):
+            raise ValueError("optimizer state covers a different number of parameter buffers")
+        for f, m, v in zip(self._buckets, ms, vs):
+            if m.numel() != f["M"].numel() or v.numel() != f["V"].numel():
+                raise ValueError(f"optimizer state has {m.numel()} elements, the flat buffer {f['M'].numel()}")
+            f["M"].copy_(m.to(f["M"].device, F32).view(-1))
+            f["V"].copy_(v.to(f["V"].device, F32).view(-1))
+            table = self._word_table(f)
+            if table is not None:       # rows whose moments are non-zero have history: they must keep being updated
+                ta, tb, V, D, _ = table
+                live = ((f["M"][ta:tb].view(V, D) != 0) | (f["V"][ta:tb].view(V, D) != 0)).any(dim=1)
+                f["row_live"].copy_(live.to(torch.uint8))
+        self._step = int(state_dict["step"])
+        groups = state_dict.get("param_groups")
+        if groups is not None:
+            if len(groups) != len(self.param_groups):
+                raise ValueError("loaded state dict has a different number of parameter groups")
+            for g, sg in zip(self.param_groups, groups):
+                g.update({k: val for k, val in sg.items() if k != "params"})
+
+
+def flatten_parameters(module: nn.Module) -> nn.Module:
+    """Re-home every parameter of ``module`` (a PyTorch head: Linear / BatchNorm layers ...) into ONE flat fp32 buffer
+    with a mirrored gradient buffer, in place: ``p.data`` and ``p.grad`` become views, 16-byte aligned.  The fused
+    ``memehip.Adam`` then updates the whole head in one launch and includes it in its global gradient norm.  Call it
+    after ``module.to(device)``; gradients are accumulated into the views by autograd (``zero_grad()`` of memehip.Adam
+    zeroes the buffer instead of dropping it)."""
+    ps = [p for p in module.parameters() if p.requires_grad]
+    if not ps:
+        return module
+    dev = ps[0].device
+    offs, n = [], 0
+    for p in ps:
+        offs.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    P = torch.zeros(n, dtype=F32, device=dev)
+    G = torch.zeros(n, dtype=F32, device=dev)
+    with torch.no_grad():
+        for p, o in zip(ps, offs):
+            P[o:o + p.numel()].copy_(p.detach().reshape(-1).to(F32))
+            p.data = P[o:o + p.numel()].view(p.shape)
+            p.grad = G[o:o + p.numel()].view(p.shape)
+    module._memehip_flat = (P, G)
+    _LOOSE[P.untyped_storage().data_ptr()] = G
+    return module
 
 
 class GraphedStep:
@@ -715,7 +877,7 @@ class GraphedStep:
         optimizer._model = model
         eng = model._get_engine()
         self.plan = eng.plan(batch, seq_len, True, gather_world=(reducer.world if reducer is not None else 0))
-        if model._shadow_stale:
+        if model.weights_changed():
             model.refresh_shadow()
         self.use_graph = use_graph
         self.reducer = reducer
@@ -861,6 +1023,8 @@ class GraphedStep:
         if opt._flat is None:
             self.model._attach_grads()
             opt._bind()
+        if self.model.weights_changed():      # the master weights were edited outside the fused optimizer
+            self.model.refresh_shadow()
         opt._step += 1
         opt._write_hyper()
         self.model._advance_rng(self.plan)

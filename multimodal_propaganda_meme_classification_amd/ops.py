@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MhColsumJob, MhGemmProblem, MhHeadGrads,
+from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MH_GEMM_QUICK_GELU, MhColsumJob, MhGemmProblem, MhHeadGrads,
                    MhHeadParams, check)
 
 BF16, F16, F32, I64 = torch.bfloat16, torch.float16, torch.float32, torch.int64
@@ -61,7 +61,7 @@ class Gemm:
                  "flags", "alpha", "drop", "rows_dev", "drop_rows")
 
     def __init__(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, residual=None, aux=None, mul=None,
-                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None, rows_dev=None, drop_rows=None):
+                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None, rows_dev=None, drop_rows=None, quick=False):
         self.alpha = alpha
         self.rows_dev, self.drop_rows = rows_dev, drop_rows     # packed token rows: device int32 [1] / int32 [M]
         self.drop = drop            # (rng u32[4] device tensor, p, site id) or None
@@ -69,7 +69,7 @@ class Gemm:
         self.bias, self.residual, self.aux, self.mul, self.rowsum = bias, residual, aux, mul, rowsum
         self.M, self.N, self.K, self.lda, self.ldb, self.ldc = M, N, K, lda, ldb, ldc
         self.flags = (MH_GEMM_GELU if gelu else 0) | (MH_GEMM_OUT_F32 if C.dtype == F32 else 0) | \
-                     (MH_GEMM_ACCUM if accum else 0)
+                     (MH_GEMM_ACCUM if accum else 0) | (MH_GEMM_QUICK_GELU if quick else 0)
 
 
 def _rng(t: Optional[torch.Tensor]):
@@ -140,25 +140,25 @@ def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
     check(_L(problems[0].A).mh_gemm_bf16_grouped(arr, n, int(a_kmajor), int(b_kmajor), _stream()), "mh_gemm_bf16_grouped")
 
 
-def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False, drop=None):
+def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False, drop=None, quick=False):
     """y[T,N] = epi(x[T,K] @ w[N,K]^T)"""
     T, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((T, N), dtype=x.dtype, device=x.device)
     gemm_grouped([Gemm(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual,
-                       aux=aux, gelu=gelu, drop=drop)], False, False)
+                       aux=aux, gelu=gelu, drop=drop, quick=quick)], False, False)
     return out
 
 
-def linear_dgrad(dy, w, out=None, mul=None, residual=None):
+def linear_dgrad(dy, w, out=None, mul=None, residual=None, quick=False):
     """dx[T,K] = dy[T,N] @ w[N,K]  (optionally * gelu'(mul), + residual)"""
     T, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = torch.empty((T, K), dtype=dy.dtype, device=dy.device)
-    gemm_grouped([Gemm(dy, w, out, T, K, N, dy.stride(0), w.stride(0), out.stride(0), mul=mul, residual=residual)],
-                 False, True)
+    gemm_grouped([Gemm(dy, w, out, T, K, N, dy.stride(0), w.stride(0), out.stride(0), mul=mul, residual=residual,
+                       quick=quick)], False, True)
     return out
 
 
@@ -371,14 +371,32 @@ def image_normalize_u8(images_u8, mean, std, out=None):
     return out
 
 
-def patchify(image, patch: int, out=None, dtype=BF16):
+def patchify(image, patch: int, out=None, dtype=BF16, ld=None):
+    """ld = None: the fast path (patch % 8 == 0, rows of exactly C*p*p elements); ld >= C*p*p: the generic gather with
+    zero-filled padding columns (mh_patchify_ld; CLIP's 14x14 patches, 588 -> 640)."""
     _chk(image, F32, "image")
     B, Cc, H, W = image.shape
     rows, K = B * (H // patch) * (W // patch), Cc * patch * patch
-    out = torch.empty((rows, K), dtype=dtype, device=image.device) if out is None else _chk(out, BF16, "patches")
-    assert out.numel() >= rows * K
-    check(_L(out).mh_patchify(_p(image), _p(out), B, Cc, H, W, patch, _stream()), "mh_patchify")
+    pitch = K if ld is None else int(ld)
+    out = torch.empty((rows, pitch), dtype=dtype, device=image.device) if out is None else _chk(out, BF16, "patches")
+    assert out.numel() >= rows * pitch
+    if ld is None:
+        check(_L(out).mh_patchify(_p(image), _p(out), B, Cc, H, W, patch, _stream()), "mh_patchify")
+    else:
+        check(_L(out).mh_patchify_ld(_p(image), _p(out), B, Cc, H, W, patch, pitch, _stream()), "mh_patchify_ld")
     return out
+
+
+def copy2d_words(src, ld_src, dst, ld_dst, rows, cols, pad_to):
+    """mh_copy2d_u32: dst[r][c] = src[r][c] (c < cols) or 0 (cols <= c < pad_to), in 32-bit words."""
+    for nm, t in (("src", src), ("dst", dst)):
+        if not t.is_cuda:
+            raise _lib.MemehipError(f"{nm}: memehip kernels need a HIP device tensor; no CPU fallback")
+    assert src.element_size() == dst.element_size()
+    wpe = 4 // src.element_size()          # elements per word
+    assert src.numel() >= ((rows - 1) * ld_src + cols) * wpe and dst.numel() >= ((rows - 1) * ld_dst + pad_to) * wpe
+    check(_lib.load().mh_copy2d_u32(_p(src), ld_src, _p(dst), ld_dst, rows, cols, pad_to, _stream()), "mh_copy2d_u32")
+    return dst
 
 
 def vit_assemble_fwd(proj, cls, pos, x, B, Np, D):

@@ -103,14 +103,24 @@ def checksum(p: O.Params) -> np.ndarray:
 SAMPLE = 6
 
 
+def sample_index(n: int) -> torch.Tensor:
+    """SAMPLE evenly spaced flat indices of an n-element tensor (float32 linspace, as the first fixtures were made;
+    exact integer arithmetic once float32 can no longer represent n)."""
+    if n <= (1 << 24):
+        return torch.linspace(0, n - 1, SAMPLE).long()
+    return (torch.arange(SAMPLE, dtype=torch.int64) * (n - 1)) // (SAMPLE - 1)
+
+
 def sample_of(t: torch.Tensor) -> np.ndarray:
     f = t.detach().reshape(-1)
-    idx = torch.linspace(0, f.numel() - 1, SAMPLE).long()
-    return f[idx].numpy().astype(np.float32)
+    return f[sample_index(f.numel())].numpy().astype(np.float32)
 
 
 def gen_case(name: str, cfg: O.OracleConfig, batch: int, seq: int, seed: int, steps: int,
-             with_grads: bool, all_ones_mask: bool = False):
+             with_grads: bool, all_ones_mask: bool = False, store_inputs: bool = True):
+    """store_inputs=False: the batch is NOT stored (a 32-image batch is 19 MB); the test regenerates it with
+    O.synthetic_batch(cfg, batch, seq, seed=1234 + seed) (torch's CPU generator is deterministic) and checks it against
+    the stored checksums."""
     torch.manual_seed(0)
     p = O.init_params(cfg, seed)
     text, image, mask, labels = O.synthetic_batch(cfg, batch, seq, seed=1234 + seed,
@@ -118,8 +128,13 @@ def gen_case(name: str, cfg: O.OracleConfig, batch: int, seq: int, seed: int, st
     model = HFReferenceModel(cfg)
     load_oracle_params(model, p)
     model.train()
-    out = {"text": text.numpy(), "image": image.numpy(), "mask": mask.numpy(), "labels": labels.numpy(),
-           "param_checksum": checksum(p), "seed": np.array(seed), "pool": np.array(cfg.pool)}
+    out = {"param_checksum": checksum(p), "seed": np.array(seed), "pool": np.array(cfg.pool),
+           "batch": np.array(batch), "seq": np.array(seq)}
+    if store_inputs:
+        out.update({"text": text.numpy(), "image": image.numpy(), "mask": mask.numpy(), "labels": labels.numpy()})
+    else:
+        out["input_checksum"] = np.array([float(image.double().sum()), float(image.double().abs().sum()),
+                                          float(text.sum()), float(mask.sum()), float(labels.sum())])
     if not with_grads:
         with torch.no_grad():
             out["logits"] = model(text, image, mask).numpy()
@@ -158,6 +173,74 @@ def gen_case(name: str, cfg: O.OracleConfig, batch: int, seq: int, seed: int, st
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+_CLIP_RENAMES = (   # oracle (ViT-style) name -> transformers CLIPVisionModel name
+    (r"^image_model\.embeddings\.cls_token$", "vision_model.embeddings.class_embedding"),
+    (r"^image_model\.embeddings\.position_embeddings$", "vision_model.embeddings.position_embedding.weight"),
+    (r"^image_model\.embeddings\.patch_embeddings\.projection\.weight$", "vision_model.embeddings.patch_embedding.weight"),
+    (r"^image_model\.pre_layernorm\.", "vision_model.pre_layrnorm."),
+    (r"^image_model\.layernorm\.", "vision_model.post_layernorm."),
+    (r"^image_model\.encoder\.layer\.(\d+)\.attention\.attention\.query\.", r"vision_model.encoder.layers.\1.self_attn.q_proj."),
+    (r"^image_model\.encoder\.layer\.(\d+)\.attention\.attention\.key\.", r"vision_model.encoder.layers.\1.self_attn.k_proj."),
+    (r"^image_model\.encoder\.layer\.(\d+)\.attention\.attention\.value\.", r"vision_model.encoder.layers.\1.self_attn.v_proj."),
+    (r"^image_model\.encoder\.layer\.(\d+)\.attention\.output\.dense\.", r"vision_model.encoder.layers.\1.self_attn.out_proj."),
+    (r"^image_model\.encoder\.layer\.(\d+)\.layernorm_before\.", r"vision_model.encoder.layers.\1.layer_norm1."),
+    (r"^image_model\.encoder\.layer\.(\d+)\.layernorm_after\.", r"vision_model.encoder.layers.\1.layer_norm2."),
+    (r"^image_model\.encoder\.layer\.(\d+)\.intermediate\.dense\.", r"vision_model.encoder.layers.\1.mlp.fc1."),
+    (r"^image_model\.encoder\.layer\.(\d+)\.output\.dense\.", r"vision_model.encoder.layers.\1.mlp.fc2."),
+)
+
+
+def clip_name(k: str) -> str:
+    for pat, rep in _CLIP_RENAMES:
+        k2 = re.sub(pat, rep, k)
+        if k2 != k:
+            return k2
+    raise KeyError(k)
+
+
+def gen_clip_case(name: str = "clip_l14_336_2layer", layers: int = 2, batch: int = 2, seed: int = 9):
+    """Pins the oracle's CLIP branch (quick-GELU, pre_layrnorm, bias-free 14x14 patch conv, eps 1e-5; BASELINE config 5's
+    image tower at its true widths, `layers` blocks) against transformers' CLIPVisionModel: pooler_output and the
+    gradient of sum(pooler_output * r) w.r.t. every parameter.  Inputs are regenerated from the seed by the test."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    cfg = O.config5("cls", layers=layers)
+    v = cfg.image
+    p_all = O.init_params(cfg, seed)
+    p = {k: t for k, t in p_all.items() if k.startswith("image_model.")}
+    cc = CLIPVisionConfig(hidden_size=v.hidden, intermediate_size=v.intermediate, num_hidden_layers=v.layers,
+                          num_attention_heads=v.heads, image_size=v.image_size, patch_size=v.patch, num_channels=v.channels,
+                          hidden_act="quick_gelu", layer_norm_eps=v.ln_eps, attention_dropout=0.0)
+    cc._attn_implementation = "eager"
+    model = CLIPVisionModel(cc)
+    sd = model.state_dict()
+    mapped = {}
+    strip = "vision_model.embeddings.class_embedding" not in sd      # transformers 5.x dropped the 4.39.2 `vision_model.` prefix
+    fix = (lambda n: n[len("vision_model."):]) if strip else (lambda n: n)
+    for k, t in p.items():
+        hk = fix(clip_name(k))
+        t2 = t.reshape(sd[hk].shape)          # cls_token (1,1,D) -> (D,), position_embeddings (1,N,D) -> (N,D)
+        mapped[hk] = t2.clone()
+    extra = [k for k in sd if k not in mapped and not k.endswith("position_ids")]
+    assert not extra, extra
+    model.load_state_dict(mapped, strict=False)
+    g = torch.Generator().manual_seed(1000 + seed)
+    image = torch.randn((batch, v.channels, v.image_size, v.image_size), generator=g)
+    r = torch.randn((batch, v.hidden), generator=g)
+    out = model(pixel_values=image).pooler_output
+    (out * r).sum().backward()
+    back = {fix(clip_name(k)): k for k in p}
+    names = [back[n] for n, _ in model.named_parameters()]
+    res = {"seed": np.array(seed), "layers": np.array(layers), "batch": np.array(batch),
+           "input_checksum": np.array([float(image.double().sum()), float(image.double().abs().sum()), float(r.double().sum())]),
+           "param_checksum": checksum(p), "pooler_output": out.detach().numpy(),
+           "grad_names": np.array(names),
+           "grad_norms": np.array([float(q.grad.double().norm()) for _, q in model.named_parameters()]),
+           "grad_samples": np.stack([sample_of(q.grad) for _, q in model.named_parameters()])}
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **res)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 def gen_index_fixtures():
     """(iii) bit-exact index fixtures: patch order of a counting image, token gather rows."""
     img = torch.arange(2 * 3 * 32 * 32, dtype=torch.float32).view(2, 3, 32, 32)
@@ -178,11 +261,19 @@ def gen_index_fixtures():
 
 def main():
     torch.set_num_threads(8)
+    if "--only-clip" in sys.argv:
+        gen_clip_case()
+        return
+    if "--only-b32" in sys.argv:
+        gen_case("config3_b32", O.config3("cls"), batch=32, seq=128, seed=4, steps=1, with_grads=True, store_inputs=False)
+        return
     gen_index_fixtures()
     gen_case("tiny_cls", O.tiny_config("cls"), batch=4, seq=16, seed=1, steps=3, with_grads=True)
     gen_case("tiny_last", O.tiny_config("last"), batch=4, seq=16, seed=2, steps=3, with_grads=True)
     if "--no-full" not in sys.argv:
         gen_case("config3_b2", O.config3("cls"), batch=2, seq=128, seed=3, steps=0, with_grads=False)
+    if "--b32" in sys.argv:      # the benchmarked configuration itself (BASELINE.json configs[2]): one full step at batch 32
+        gen_case("config3_b32", O.config3("cls"), batch=32, seq=128, seed=4, steps=1, with_grads=True, store_inputs=False)
 
 
 if __name__ == "__main__":

@@ -72,6 +72,12 @@ class ImageConfig:
     heads: int = 12
     intermediate: int = 3072
     ln_eps: float = 1e-6             # timm ViT eps
+    # CLIP vision tower (transformers CLIPVisionModel; BASELINE.json configs[4], reference evidence
+    # example_scripts/mm_model_mm_example_task2C.py:49): quick-GELU, a LayerNorm on the embeddings in front
+    # of the first block (pre_layrnorm), no bias on the patch conv
+    act: str = "gelu"
+    pre_ln: bool = False
+    patch_bias: bool = True
 
     @property
     def n_patches(self) -> int:
@@ -102,6 +108,17 @@ def tiny_config(pool: str = "cls") -> OracleConfig:
         image=ImageConfig(image_size=32, patch=16, hidden=128, layers=2, heads=2,
                           intermediate=256),
         proj=128, num_classes=2, pool=pool)
+
+
+def config5(pool: str = "cls", layers: int = 24) -> OracleConfig:
+    """BASELINE.json configs[4]: CLIP ViT-L/14 @336 image tower (577 tokens, D 1024, quick-GELU, pre-LN, bias-free
+    14x14 patch conv, LayerNorm eps 1e-5) + BERT-large (V = 30522), S = 256.  ``layers`` < 24 keeps every width and
+    sequence length and only shortens the stacks (parity tests)."""
+    return OracleConfig(
+        text=TextConfig(vocab_size=30522, hidden=1024, layers=layers, heads=16, intermediate=4096, max_position=512),
+        image=ImageConfig(image_size=336, patch=14, hidden=1024, layers=layers, heads=16, intermediate=4096,
+                          ln_eps=1e-5, act="quick_gelu", pre_ln=True, patch_bias=False),
+        proj=512, num_classes=2, pool=pool)
 
 
 def config3(pool: str = "cls") -> OracleConfig:
@@ -147,8 +164,12 @@ def _image_shapes(c: ImageConfig, pfx: str = "image_model.") -> Dict[str, Tuple[
         pfx + "embeddings.cls_token": (1, 1, D),
         pfx + "embeddings.position_embeddings": (1, c.n_tokens, D),
         pfx + "embeddings.patch_embeddings.projection.weight": (D, c.channels, c.patch, c.patch),
-        pfx + "embeddings.patch_embeddings.projection.bias": (D,),
     }
+    if c.patch_bias:
+        s[pfx + "embeddings.patch_embeddings.projection.bias"] = (D,)
+    if c.pre_ln:
+        s[pfx + "pre_layernorm.weight"] = (D,)
+        s[pfx + "pre_layernorm.bias"] = (D,)
     for i in range(c.layers):
         L = f"{pfx}encoder.layer.{i}."
         s[L + "layernorm_before.weight"] = (D,)
@@ -207,7 +228,7 @@ def init_params(cfg: OracleConfig, seed: int = 0) -> Params:
             t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * b
         else:
             t = torch.randn(shape, generator=g, dtype=torch.float32) * 0.02
-            if "LayerNorm.weight" in name or "layernorm" in name and name.endswith("weight"):
+            if "LayerNorm.weight" in name or ("layernorm" in name and name.endswith("weight")):
                 t = t + 1.0
         out[name] = t
     return out
@@ -295,9 +316,12 @@ def image_tower(p: Params, image: torch.Tensor, c: ImageConfig,
     B = image.shape[0]
     D = c.hidden
     w = p[pfx + "embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
-    x = F.linear(patchify(image, c.patch), w, p[pfx + "embeddings.patch_embeddings.projection.bias"])
+    x = F.linear(patchify(image, c.patch), w, p.get(pfx + "embeddings.patch_embeddings.projection.bias"))
     x = torch.cat([p[pfx + "embeddings.cls_token"].expand(B, -1, -1), x], dim=1)
     x = x + p[pfx + "embeddings.position_embeddings"]
+    if c.pre_ln:      # CLIPVisionTransformer.pre_layrnorm
+        x = F.layer_norm(x, (D,), p[pfx + "pre_layernorm.weight"], p[pfx + "pre_layernorm.bias"], c.ln_eps)
+    act = (lambda z: z * torch.sigmoid(1.702 * z)) if c.act == "quick_gelu" else F.gelu
     for i in range(c.layers):
         L = f"{pfx}encoder.layer.{i}."
         h = F.layer_norm(x, (D,), p[L + "layernorm_before.weight"], p[L + "layernorm_before.bias"], c.ln_eps)
@@ -308,7 +332,7 @@ def image_tower(p: Params, image: torch.Tensor, c: ImageConfig,
                    c.heads, None)
         x = x + F.linear(ctx, p[L + "attention.output.dense.weight"], p[L + "attention.output.dense.bias"])
         h = F.layer_norm(x, (D,), p[L + "layernorm_after.weight"], p[L + "layernorm_after.bias"], c.ln_eps)
-        h = F.gelu(F.linear(h, p[L + "intermediate.dense.weight"], p[L + "intermediate.dense.bias"]))
+        h = act(F.linear(h, p[L + "intermediate.dense.weight"], p[L + "intermediate.dense.bias"]))
         x = x + F.linear(h, p[L + "output.dense.weight"], p[L + "output.dense.bias"])
     return F.layer_norm(x, (D,), p[pfx + "layernorm.weight"], p[pfx + "layernorm.bias"], c.ln_eps)
 

@@ -1,0 +1,146 @@
+"""BASELINE.json configs[4] on the MI355X: CLIP ViT-L/14 @336 image tower (577 tokens, 14x14 patches, quick-GELU,
+pre-LayerNorm, bias-free patch conv) + BERT-large at S = 256.  The kernels are the ones config 3 runs; these tests cover
+what is new -- the padded patch gather, the quick-GELU epilogue -- and the whole step at the true widths and sequence
+lengths against the CPU oracle (whose CLIP branch is pinned to transformers' CLIPVisionModel, test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import multimodal_propaganda_meme_classification_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def ops(pkg):
+    from multimodal_propaganda_meme_classification_amd import ops as o
+    return o
+
+
+def _oracle():
+    from oracle import meme_oracle as O
+    return O
+
+
+@pytest.mark.parametrize("T16", [BF16, F16])
+def test_patch_gather_14x14_with_padding_is_bit_exact(ops, T16):
+    O = _oracle()
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn((2, 3, 42, 28), generator=g)                       # 3 x 2 patches of 14 x 14
+    ref = O.patchify(img, 14).reshape(-1, 588).to(T16)                   # RNE cast of the exact gather
+    out = ops.patchify(img.cuda(), 14, dtype=T16, ld=640)
+    assert out.shape == (12, 640)
+    assert torch.equal(out[:, :588].cpu(), ref)
+    assert float(out[:, 588:].float().abs().max()) == 0.0
+    # the padded weight copy and the un-padding of its gradient
+    w = torch.randn((128, 588), generator=g).to(T16).cuda()
+    wp = torch.full((128, 640), 7.0, dtype=T16, device="cuda")
+    ops.copy2d_words(w, 294, wp, 320, 128, 294, 320)
+    assert torch.equal(wp[:, :588], w) and float(wp[:, 588:].float().abs().max()) == 0.0
+    gp = torch.randn((128, 640), generator=g).cuda()
+    gout = torch.zeros((128, 588), device="cuda")
+    ops.copy2d_words(gp, 640, gout, 588, 128, 588, 588)
+    assert torch.equal(gout, gp[:, :588])
+
+
+def test_quick_gelu_epilogue_and_derivative(ops):
+    g = torch.Generator().manual_seed(5)
+    T, N, K = 200, 256, 128
+    x = (torch.randn((T, K), generator=g)).to(BF16).cuda()
+    w = (torch.randn((N, K), generator=g) * 0.1).to(BF16).cuda()
+    b = torch.randn((N,), generator=g).cuda()
+    aux = torch.empty((T, N), dtype=BF16, device="cuda")
+    y = ops.linear_fwd(x, w, bias=b, aux=aux, gelu=True, quick=True)
+    pre = x.float() @ w.float().t() + b
+    ref = pre * torch.sigmoid(1.702 * pre)
+    assert float((y.float() - ref).abs().max()) < 2e-2 and float((y.float() - ref).abs().mean()) < 2e-3
+    dy = torch.randn((T, N), generator=g).to(BF16).cuda()
+    prek = torch.randn((T, K), generator=g).to(BF16).cuda()
+    dx = ops.linear_dgrad(dy, w, mul=prek, quick=True)
+    pf = prek.float().requires_grad_(True)
+    (pf * torch.sigmoid(1.702 * pf)).backward(dy.float() @ w.float())
+    err = (dx.float() - pf.grad).abs()
+    assert float(err.max()) < 6e-2 * float(pf.grad.abs().max()) + 1e-2 and float(err.mean()) < 5e-3 * float(pf.grad.abs().mean()) + 1e-3
+
+
+def _build(pkg, O, cfg, seed, dtype):
+    params = O.init_params(cfg, seed)
+    d = cfg.to_dict()
+    d["compute_dtype"] = dtype
+    model = pkg.MultimodalClassifier.from_config(pkg.ModelConfig.from_dict(d), init=False)
+    model.load_state_dict(params)
+    model.to("cuda").train()
+    return params, model
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 1e-3), ("bf16", 4e-3)])
+def test_config5_two_layers_at_the_true_shapes(pkg, dtype, tol):
+    """2 + 2 layers of config 5 at its true widths and sequence lengths (D 1024, 16 heads, I 4096, 577 image tokens from
+    14x14 patches of a 336x336 image, 256 text tokens with ragged masks): logits, loss, every gradient, and the parameters
+    after one Adam step against the CPU oracle."""
+    O = _oracle()
+    torch.set_num_threads(16)
+    cfg = O.config5("cls", layers=2)
+    params, model = _build(pkg, O, cfg, 21, dtype)
+    text, image, mask, labels = O.synthetic_batch(cfg, 3, 256, seed=77)
+    ref_logits, ref_loss, ref_grads = O.loss_and_grads(params, text, image, mask, labels, cfg)
+    opt = pkg.Adam(model.parameters(), lr=2e-5)
+    crit = pkg.CrossEntropyLoss()
+    logits = model(text.cuda(), image.cuda(), mask.cuda())
+    loss = crit(logits, labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().float().cpu() - ref_logits).abs().max())
+    print(f"[config 5, 2 layers, {dtype}] max |logit - oracle| = {err:.3e}")
+    assert err < tol and abs(float(loss.detach()) - float(ref_loss)) < tol
+    rel_tol = 2e-2 if dtype == "fp16" else 5e-2
+    for name, p in model.named_parameters():
+        ref = ref_grads[name]
+        got = p.grad.detach().float().cpu()
+        num, den = float((got - ref).norm()), float(ref.norm())
+        if ".key.bias" in name:
+            assert num < 1e-4
+            continue
+        assert num <= rel_tol * den + 2e-6, f"grad {name}: ||diff|| {num:.3e} vs ||ref|| {den:.3e}"
+    opt.step()
+    torch.cuda.synchronize()
+    st = O.AdamState()
+    p1 = O.adam_step(params, ref_grads, st, lr=2e-5)
+    sd = model.state_dict()
+    worst = max(float((sd[k].float().cpu() - p1[k]).abs().max()) for k in p1 if ".key.bias" not in k)
+    assert worst < 2.05 * 2e-5, worst
+
+
+def test_config5_full_depth_smoke(pkg):
+    """All 24 + 24 layers (639 M parameters), batch 2: logits against the CPU oracle, then three graphed steps whose loss
+    falls on a fixed batch."""
+    O = _oracle()
+    torch.set_num_threads(16)
+    cfg = O.config5("cls")
+    params, model = _build(pkg, O, cfg, 22, "fp16")
+    assert model.layout.n_total >= 639_175_170
+    text, image, mask, labels = O.synthetic_batch(cfg, 2, 256, seed=78)
+    with torch.no_grad():
+        ref = O.forward(params, text, image, mask, cfg)
+    model.eval()
+    with torch.no_grad():
+        got = model(text.cuda(), image.cuda(), mask.cuda()).float().cpu()
+    err = float((got - ref).abs().max())
+    print(f"[config 5, 24 layers, fp16] max |logit - oracle| = {err:.3e}")
+    assert err < 1.5e-3          # 1e-3 at 12 layers; twice the depth
+    model.train()
+    opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)
+    step = pkg.GraphedStep(model, opt, 2, 256)
+    step.load_batch(text.cuda(), image.cuda(), mask.cuda(), labels.cuda())
+    losses = []
+    for _ in range(4):
+        loss, _ = step.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -139,3 +139,36 @@ def test_gradient_reducer_gloo_world2():
     out = mgr.dict()
     mp.spawn(_ddp_worker, args=(world, port, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_resize_and_crop_follow_torchvision_formulas():
+    """torchvision 0.17.2: Resize(int) truncates the long side, CenterCrop rounds (half to even) the offset --
+    known answers worked by hand from transforms/functional.py (_compute_resized_output_size, center_crop)."""
+    from multimodal_propaganda_meme_classification_amd.data import center_crop_box, resized_size
+    assert resized_size(640, 427) == (383, 256)            # 256 * 640 / 427 = 383.7 -> 383 (round() would give 384)
+    assert resized_size(427, 640) == (256, 383)
+    assert resized_size(400, 300) == (341, 256)
+    assert resized_size(500, 500) == (256, 256)
+    assert center_crop_box(383, 256, 224) == (80, 16, 304, 240)     # (383-224)/2 = 79.5 -> 80 (half to even), not 79
+    assert center_crop_box(341, 256, 224) == (58, 16, 282, 240)     # 58.5 -> 58
+    assert center_crop_box(256, 256, 224) == (16, 16, 240, 240)
+
+
+def test_image_projection_name_is_configurable():
+    """state_dict() can carry the organizers' `resnet_fc.*` keys (Multimodal_example_task2C.txt:165); either name loads."""
+    cfg = _tiny_cfg()
+    cfg.image_fc_name = "resnet_fc"
+    m = pkg.MultimodalClassifier.from_config(cfg, seed=1)
+    keys = list(m.state_dict())
+    assert "resnet_fc.weight" in keys and "resnet_fc.bias" in keys and not any(k.startswith("image_fc") for k in keys)
+    assert [n for n, _ in m.named_parameters()] == keys
+    m2 = pkg.MultimodalClassifier.from_config(_tiny_cfg(), init=False)             # default name: image_fc
+    m2.load_state_dict(m.state_dict())
+    assert torch.equal(m2.flat_params, m.flat_params)
+    m3 = pkg.MultimodalClassifier.from_config(cfg, init=False)
+    m3.load_state_dict(m2.state_dict())
+    assert torch.equal(m3.flat_params, m.flat_params)
+    bad = _tiny_cfg()
+    bad.image_fc_name = "vit_fc"
+    with pytest.raises(ValueError):
+        bad.validate()

@@ -127,3 +127,30 @@ def test_clip_matches_torch():
     torch.nn.utils.clip_grad_norm_([w], 1.0)
     n = O.global_grad_norm({"w": g})
     np.testing.assert_allclose((g * min(1.0, float(1.0 / (n + 1e-6)))).numpy(), w.grad.numpy(), rtol=1e-6)
+
+
+def test_clip_branch_matches_transformers_clip_vision_model(golden_dir):
+    """The oracle's CLIP image tower (quick-GELU, pre_layrnorm, bias-free 14x14 patch conv, eps 1e-5; BASELINE config 5's
+    widths, 2 blocks) against the fixture made from transformers' CLIPVisionModel (oracle/gen_golden.py: gen_clip_case)."""
+    from oracle.gen_golden import sample_index
+    z = _load(golden_dir, "clip_l14_336_2layer")
+    seed, layers, batch = int(z["seed"]), int(z["layers"]), int(z["batch"])
+    cfg = O.config5("cls", layers=layers)
+    v = cfg.image
+    p = {k: t for k, t in O.init_params(cfg, seed).items() if k.startswith("image_model.")}
+    np.testing.assert_allclose(_checksum(p), z["param_checksum"], rtol=1e-9)
+    g = torch.Generator().manual_seed(1000 + seed)
+    image = torch.randn((batch, v.channels, v.image_size, v.image_size), generator=g)
+    r = torch.randn((batch, v.hidden), generator=g)
+    np.testing.assert_allclose([float(image.double().sum()), float(image.double().abs().sum()), float(r.double().sum())],
+                               z["input_checksum"], rtol=1e-9)
+    leaves = {k: t.clone().requires_grad_(True) for k, t in p.items()}
+    pooled = O.image_tower(leaves, image, v)[:, 0]
+    np.testing.assert_allclose(pooled.detach().numpy(), z["pooler_output"], atol=3e-5, rtol=1e-4)
+    (pooled * r).sum().backward()
+    names = [str(n) for n in z["grad_names"]]
+    norms = np.array([float(leaves[n].grad.double().norm()) for n in names])
+    np.testing.assert_allclose(norms, z["grad_norms"], rtol=5e-4, atol=1e-7)
+    for n, ref in zip(names, z["grad_samples"]):
+        f = leaves[n].grad.reshape(-1)
+        np.testing.assert_allclose(f[sample_index(f.numel())].numpy(), ref, rtol=5e-3, atol=2e-5)
