@@ -305,7 +305,7 @@ def main():
                          "step_mfma_frac": round(flop_exec_per_meme * value / world / (MFMA_PEAK_TFLOPS * 1e12), 4)},
             # the tolerance every storage type is held to on THIS configuration (config 3, batch 32) by the GPU suite
             "parity": {"fp16": {"tol_logits": 1e-3, "test": "tests/test_round2_gpu.py::test_config3_batch32_matches_the_fixture[fp16]"},
-                       "bf16": {"tol_logits": 5e-3, "test": "tests/test_round2_gpu.py::test_config3_batch32_matches_the_fixture[bf16]"}},
+                       "bf16": {"tol_logits": 8e-3, "test": "tests/test_round2_gpu.py::test_config3_batch32_matches_the_fixture[bf16]"}},
         }
         if world == 1 and not args.force_ddp and not args.no_extras and not args.tiny and args.config == 3:
             # secondary lines, same K / W, same batch: the other 16-bit storage type (fp16 meets north_star's 1e-3 on the

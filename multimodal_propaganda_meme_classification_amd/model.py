@@ -382,17 +382,23 @@ class MultimodalClassifier(nn.Module):
     def mark_weights_changed(self):
         self._shadow_stale = True
 
+    def _weights_version(self) -> int:
+        # every Parameter was created as a view of the first flat buffer and keeps sharing that buffer's autograd
+        # version counter for life (Tensor.data = ... / .to(device) swap the storage, not the counter): one counter
+        # for all parameters, bumped by any in-place torch op on any of them
+        return self._params[self._names[0]]._version
+
     def _shadow_synced(self):
         self._shadow_stale = False
-        self._shadow_version = self._P._version
+        self._shadow_version = self._weights_version()
 
     def weights_changed(self) -> bool:
         """True when the fp32 master weights were edited since the 16-bit shadow (what every tower GEMM reads) was last
-        cast from them.  The parameters are views of one flat buffer and share its autograd version counter, so ANY
-        in-place update through torch -- ``torch.optim.Adam(model.parameters()).step()``, HF Trainer's AdamW,
-        ``p.data.mul_()``, ``clip``-free SGD -- is seen here without a hook; the fused ``memehip.Adam`` rewrites the
-        shadow itself (mh_adam_step) and re-syncs the version."""
-        return self._shadow_stale or self._P._version != self._shadow_version
+        cast from them.  All parameters share one autograd version counter, so ANY in-place update through torch --
+        ``torch.optim.Adam(model.parameters()).step()``, HF Trainer's AdamW, SGD, ``with torch.no_grad(): p.mul_(..)`` --
+        is seen here without a hook; the fused ``memehip.Adam`` rewrites the shadow itself (mh_adam_step) and re-syncs.
+        Edits that bypass the counter by construction (``p.data.mul_()``, raw pointers) need ``mark_weights_changed()``."""
+        return self._shadow_stale or self._weights_version() != self._shadow_version
 
     def manual_seed(self, seed: int):
         """Seed of the dropout masks (stateless counter RNG: mask = f(seed, step, site, element))."""
