@@ -330,6 +330,62 @@ int mh_focal_fwd_bwd(const float* logits, int ld, const float* targets /*f32 [B]
                      mh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Heads on top of the towers (SURVEY section 8 f ranks 1-2), all fp32:
+ *   Kevin's `Linear + BatchNorm1d + ReLU` projections, `ConcatAttention3`, `Linear(512,1) + BatchNorm1d(1)`
+ *   (Multimodal_example_task2C.py:599-612, 476-499, 641-643) and the pooling branches of LLMWithClassificationHead
+ *   (Multimodal_example_task2C.py:362-392, DistilBERT_example_task2A.py:185-210).
+ *
+ * mh_gemm_f32: C[M][N] = act(A . B^T + bias) in EXACT f32 on v_mfma_f32_32x32x2_f32 (an fmaf chain per element: the
+ *   head adds no 16-bit rounding), any M / N / K, operand layouts as in mh_gemm_bf16_grouped (a_kmajor / b_kmajor).
+ *   flags: MH_F32_ACCUM (C += ...), MH_F32_TANH, MH_F32_RELU, MH_F32_BN.
+ *   MH_F32_BN (M <= 64, one row tile = the whole batch): nn.Linear -> nn.BatchNorm1d (-> ReLU with MH_F32_RELU) in ONE
+ *   launch: z = A B^T + bias is kept in bn_z (for the backward), training mode normalises with the batch statistics
+ *   (biased variance), saves mean / rstd and updates the running statistics (unbiased variance, momentum) exactly as
+ *   mh_bn1d_fwd does; eval mode uses the running statistics.
+ * ------------------------------------------------------------------------------------------ */
+#define MH_F32_ACCUM 1
+#define MH_F32_TANH 2
+#define MH_F32_RELU 4
+#define MH_F32_BN 8
+typedef struct MhGemmF32 {
+    const float* A; const float* B; float* C; const float* bias /*[N] or NULL*/;
+    int32_t M, N, K, lda, ldb, ldc, flags;
+    const float* bn_gamma; const float* bn_beta; float* bn_running_mean; float* bn_running_var;
+    float* bn_save_mean; float* bn_save_rstd; float* bn_z /*[M][bn_ldz] pre-BatchNorm output or NULL*/;
+    int32_t bn_ldz; float bn_eps; float bn_momentum; int32_t bn_training;
+} MhGemmF32;
+int mh_gemm_f32(const MhGemmF32* p /*host*/, int a_kmajor, int b_kmajor, mh_stream_t stream);
+/* out[d] = scale * sum_r x[r][d] (bias gradients; fixed summation order) */
+int mh_colsum_f32(const float* x, int ld, float* out, int rows, int D, float scale, mh_stream_t stream);
+/* Sequence poolings over the last hidden state h f32 [B][S][D]:
+ *   max   : out[b][d] = max_s h ; arg = the first maximising s ; bwd writes dh (all of it) from dout and arg
+ *   mean  : out = sum_s h m / clamp(sum_s m, 1e-9) with the int64 attention mask m [B][S]
+ *   attn  : u = tanh(h W1^T + b1) comes from mh_gemm_f32(MH_F32_TANH); scores = u . w2 + b2 + (1 - m) * -1e9;
+ *           p = softmax_s (saved [B][S]); out = sum_s p h.  bwd: du [B][S][A] (feed the two GEMMs for dW1 / dh),
+ *           dh = p dout (the direct path; the GEMM adds du W1 with MH_F32_ACCUM), per-sample partials dw2_part [B][A],
+ *           db2_part [B] (finish with mh_colsum_f32).  S <= 1024.
+ *   cnn   : conv1d(D -> D, `taps` taps, same padding) + ReLU + max over positions, as a GEMM over zero-padded
+ *           sequences: mh_pad_seq_f32 builds hp [B][Sp = S + taps - 1][D]; z = mh_gemm_f32(A = hp viewed with lda = D,
+ *           K = taps * D, M = B*Sp - (taps-1), B = weight permuted to [O][taps][C]); mh_relu_max_fwd reduces the S valid
+ *           rows of each sample (arg = -1 when the ReLU floor wins); bwd: mh_relu_max_bwd scatters dout into dz,
+ *           two GEMMs give dW and da = dz W, mh_conv_fold_f32 sums the taps back into dh. */
+int mh_pool_max_fwd(const float* h, float* out, int32_t* arg, int B, int S, int D, mh_stream_t stream);
+int mh_pool_max_bwd(const float* dout, const int32_t* arg, float* dh, int B, int S, int D, mh_stream_t stream);
+int mh_pool_mean_fwd(const float* h, const int64_t* mask, float* out, int B, int S, int D, mh_stream_t stream);
+int mh_pool_mean_bwd(const float* dout, const int64_t* mask, float* dh, int B, int S, int D, mh_stream_t stream);
+int mh_pool_attn_fwd(const float* h, const float* u, const float* w2, const float* b2, const int64_t* mask, float* p,
+                     float* out, int B, int S, int D, int A, mh_stream_t stream);
+int mh_pool_attn_bwd(const float* h, const float* u, const float* w2, const float* p, const float* dout, float* du, float* dh,
+                     float* dw2_part, float* db2_part, int B, int S, int D, int A, mh_stream_t stream);
+int mh_pad_seq_f32(const float* h, float* hp, int B, int S, int D, int pad, int Sp, mh_stream_t stream);
+int mh_relu_max_fwd(const float* z, float* out, int32_t* arg, int B, int S, int Sp, int D, mh_stream_t stream);
+int mh_relu_max_bwd(const float* dout, const int32_t* arg, float* dz, int rows, int Sp, int D, mh_stream_t stream);
+int mh_conv_fold_f32(const float* da, float* dh, int B, int S, int D, int taps, int pad, int Sp, int rows, mh_stream_t stream);
+/* ConcatAttention3's gate (Multimodal_example_task2C.py:495-496): y = softmax(g, dim=1) * c ; bwd: dg, dc from dy */
+int mh_softmax_gate_fwd(const float* g, const float* c, float* y, int B, int F, mh_stream_t stream);
+int mh_softmax_gate_bwd(const float* g, const float* c, const float* dy, float* dg, float* dc, int B, int F, mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam / AdamW, Multimodal_example_task2C.txt:249,217; HF Trainer
  * adamw_torch + max_grad_norm, DistilBERT_example_task2A.ipynb:3211-3213,3280):
  *   mh_sumsq_f32: out[0] = sum g^2 over n elements (two-pass deterministic; workspace >= 1024 f32)

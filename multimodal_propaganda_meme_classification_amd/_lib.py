@@ -57,6 +57,17 @@ class MhAttnProblem(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class MhGemmF32(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p)] + \
+               [(n, C.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "flags")] + \
+               [(n, c_void_p) for n in ("bn_gamma", "bn_beta", "bn_running_mean", "bn_running_var", "bn_save_mean",
+                                        "bn_save_rstd", "bn_z")] + \
+               [("bn_ldz", C.c_int32), ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("bn_training", C.c_int32)]
+
+
+MH_F32_ACCUM, MH_F32_TANH, MH_F32_RELU, MH_F32_BN = 1, 2, 4, 8
+
+
 class MhHeadParams(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("Wt", "bt", "Wi", "bi", "Wf", "bf_", "Wo", "bo")]
 
@@ -102,6 +113,20 @@ _PROTOS = {
                     c_float, c_float, c_int, c_int, c_void_p],
     "mh_bn1d_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                     c_void_p, c_int, c_int, c_int, c_void_p],
+    "mh_gemm_f32": [C.POINTER(MhGemmF32), c_int, c_int, c_void_p],
+    "mh_colsum_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p],
+    "mh_pool_max_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mh_pool_max_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mh_pool_mean_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mh_pool_mean_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mh_pool_attn_fwd": [c_void_p] * 7 + [c_int] * 4 + [c_void_p],
+    "mh_pool_attn_bwd": [c_void_p] * 9 + [c_int] * 4 + [c_void_p],
+    "mh_pad_seq_f32": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
+    "mh_relu_max_fwd": [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p],
+    "mh_relu_max_bwd": [c_void_p, c_void_p, c_void_p] + [c_int] * 3 + [c_void_p],
+    "mh_conv_fold_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "mh_softmax_gate_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "mh_softmax_gate_bwd": [c_void_p] * 5 + [c_int, c_int, c_void_p],
     "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
     "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],

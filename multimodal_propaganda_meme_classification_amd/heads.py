@@ -96,9 +96,10 @@ class TextClassifier(nn.Module):
         else:
             pooled = self.pool(self.model.hidden_states(input_ids, attention_mask), attention_mask)
         if self.head == "distilbert":
-            logits = self.classifier(torch.relu(self.pre_classifier(pooled)))
+            hid = fused.linear(pooled, self.pre_classifier.weight, self.pre_classifier.bias, act="relu")
+            logits = fused.linear(hid, self.classifier.weight, self.classifier.bias)
         else:
-            logits = self.output_layer(pooled)
+            logits = fused.linear(pooled, self.output_layer.weight, self.output_layer.bias)
         if labels is not None:
             loss = self.loss_fct(logits.view(-1, self.num_classes), labels.view(-1))
             return loss, logits
@@ -146,6 +147,18 @@ class LinearBNReLU(nn.Sequential):
         return fused.linear_bn_act(x, self[0], self[1], self.relu)
 
 
+class FineTuneMLP(nn.Sequential):
+    """``CustomDenseNet161.fine_tune`` (Multimodal_example_task2C.py:571-574): Linear -> ReLU -> Dropout(0.35) -> Linear, same
+    state_dict keys (``0.*``, ``3.*``); the two Linear layers (the first with its ReLU fused) run in mh_gemm_f32."""
+
+    def __init__(self, in_features: int, width: int):
+        super().__init__(nn.Linear(in_features, width), nn.ReLU(inplace=True), nn.Dropout(p=0.35), nn.Linear(width, width))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = fused.linear(x, self[0].weight, self[0].bias, act="relu")
+        return fused.linear(self[2](x), self[3].weight, self[3].bias)
+
+
 class ConcatAttention3(nn.Module):
     """Multimodal_example_task2C.py:476-499: softmax-gated concat of the three towers' features + reduce."""
 
@@ -184,8 +197,7 @@ class KevinMultimodalClassifier(nn.Module):
         self.text_dropout, self.caption_text_dropout = nn.Dropout(0.3), nn.Dropout(0.3)
         self.text_fc = LinearBNReLU(tc.hidden, proj)
         self.caption_text_fc = LinearBNReLU(cc.hidden, proj)
-        self.image_fine_tune = nn.Sequential(nn.Linear(ic.hidden, proj), nn.ReLU(inplace=True), nn.Dropout(p=0.35),
-                                             nn.Linear(proj, proj))
+        self.image_fine_tune = FineTuneMLP(ic.hidden, proj)
         self.fusion_layer = ConcatAttention3(3 * proj, proj)
         self.output_fc = LinearBNReLU(proj, 1, relu=False)
         self._head_flat = False
