@@ -730,7 +730,7 @@ class Adam(torch.optim.Optimizer):
         if len(self._buckets) == 1:
             return self._buckets[0]["nrm"]
         total = self._flat["nrm_total"]
-        torch.stack([f["nrm"][0] for f in self._buckets]).sum(dim=0, keepdim=True, out=total)
+        torch.sum(torch.stack([f["nrm"][0] for f in self._buckets]).view(1, -1), dim=1, out=total)
         return total
 
     def grad_norm(self) -> torch.Tensor:
