@@ -417,10 +417,13 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
 // ----------------------------------------------------------------------------------------------
 // backward, dK / dV:  one wave = 32 keys at a time, sweep query tiles (resident Q/dO when NT_RES > 0)
 // ----------------------------------------------------------------------------------------------
-template <int NW, int NT_RES, bool DROP>
+// OWN_DELTA: delta = rowsum(dO o O) of the staged query rows is computed here instead of being read from the dQ kernel's
+// output, so the dQ and dK/dV sweeps of a layer can share ONE launch (no ordering between their workgroups).
+template <int NW, int NT_RES, bool DROP, bool OWN_DELTA = false>
 MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, const int bh, char* smem) {
     const h16* __restrict__ qkv = A.qkv;
     const int64_t* __restrict__ key_mask = A.key_mask;
+    const h16* __restrict__ outp = A.out;
     const h16* __restrict__ dout = A.dout;
     const float* __restrict__ lse = A.lse;
     const float* __restrict__ delta = A.delta;
@@ -463,7 +466,27 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
             const int qq = t * TILE + i;
             // rows past S: lse = +big makes P = exp2(-big) = 0, so they add nothing
             lse_t[slot * TILE + i] = qq < Sb ? lse[((size_t)b * H + hh) * S + qq] * LOG2E : 1.0e30f;
-            dl_t[slot * TILE + i] = qq < Sb ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
+            if (!OWN_DELTA) dl_t[slot * TILE + i] = qq < Sb ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
+        }
+        if (OWN_DELTA && tid < 4 * TILE) {     // four threads per query row, 16 dims each (NT >= 256)
+            const int i = tid >> 2, part = tid & 3;
+            const int qq = t * TILE + i;
+            float dl = 0.f;
+            if (qq < Sb) {
+                const h16* dr = dob + (size_t)qq * H * HD + part * 16;
+                const h16* orow = outp + (r0 + qq) * (size_t)H * HD + hh * HD + part * 16;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    Pack8 a, o;
+                    a.v = *(const i32x4*)(dr + c2 * 8);
+                    o.v = *(const i32x4*)(orow + c2 * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dl += (float)a.e[e] * (float)o.e[e];
+                }
+            }
+            dl += __shfl_xor(dl, 1, 64);
+            dl += __shfl_xor(dl, 2, 64);
+            if (part == 0) dl_t[slot * TILE + i] = dl;
         }
     };
     if (NT_RES > 0) {
@@ -604,6 +627,27 @@ __global__ __launch_bounds__(448) void attn_bwd_dkv_dual_kernel(const AttnArgs A
     }
 }
 
+// The whole backward of a layer pair in ONE launch: workgroup roles [dQ of A | dK,dV of A | dQ of B | dK,dV of B].
+// The dK/dV workgroups compute their own delta (OWN_DELTA), so no role waits for another; the dQ and dK/dV sweeps --
+// each a latency-bound chain at 60 % idle wave-cycles when launched alone -- fill each other's holes.
+// RES_B: the text heads keep Q / dO (K / V) resident in LDS (2) or stream them (0: 33 KB per workgroup, more
+// workgroups per CU).
+template <int RES_B, bool DROP_B>
+__global__ __launch_bounds__(448) void attn_bwd_merged_dual_kernel(const AttnArgs A, const AttnArgs Bp, const int nA,
+                                                                   const int nB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int y = blockIdx.y;
+    if (y < nA) {
+        attn_bwd_dq_body<7, 0, false>(A, 0, 1, y, smem);
+    } else if (y < 2 * nA) {
+        attn_bwd_dkv_body<7, 0, false, true>(A, 0, 1, y - nA, smem);
+    } else {
+        if (threadIdx.x >= 256) return;
+        if (y < 2 * nA + nB) attn_bwd_dq_body<4, RES_B, DROP_B>(Bp, 0, 1, y - 2 * nA, smem);
+        else attn_bwd_dkv_body<4, RES_B, DROP_B, true>(Bp, 0, 1, y - 2 * nA - nB, smem);
+    }
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------
 // resident when S <= 256 (NT_RES = 2 for S <= 128, else 4); the 32-row tiles of a head are dealt to
 // `split` workgroups of 4 waves (split chosen so that every wave has work and the grid fills 256 CUs)
@@ -618,6 +662,17 @@ int bwd_resident_max() {
     if (v < 0) {
         const char* e = getenv("MEMEHIP_ATTN_BWD_RESIDENT_MAX");
         v = e ? atoi(e) : 128;   // measured: at S = 197 the 24-KB streaming kernels co-schedule better with the side-stream GEMMs
+    }
+    return v;
+}
+// MEMEHIP_ATTN_BWD_MERGED: 0 = dQ launch then dK/dV launch (round 1), 1 = one launch, text heads streaming (default),
+// 2 = one launch, text heads resident
+int bwd_merged_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MEMEHIP_ATTN_BWD_MERGED");
+        v = e ? atoi(e) : 1;
+        if (v < 0 || v > 2) v = 1;
     }
     return v;
 }
@@ -794,9 +849,37 @@ extern "C" int mh_attn_bwd_grouped(const MhAttnProblem* p, int n, mh_stream_t st
         const AttnArgs A = to_args(p[ia]), Bp = to_args(p[ib]);
         const int nA = p[ia].B * p[ia].H, nB = p[ib].B * p[ib].H;
         const bool dr = has_drop(p[ib]);
-        const dim3 grid(1, nA + nB);
-        ATTN_LAUNCH_DUAL(attn_bwd_dq_dual_kernel, cmax(lds_dq(0), lds_dq(2)), grid, A, Bp, nA);
-        ATTN_LAUNCH_DUAL(attn_bwd_dkv_dual_kernel, cmax(lds_dkv(0), lds_dkv(2)), grid, A, Bp, nA);
+        const int mode = bwd_merged_mode();
+        if (mode == 0) {
+            const dim3 grid(1, nA + nB);
+            ATTN_LAUNCH_DUAL(attn_bwd_dq_dual_kernel, cmax(lds_dq(0), lds_dq(2)), grid, A, Bp, nA);
+            ATTN_LAUNCH_DUAL(attn_bwd_dkv_dual_kernel, cmax(lds_dkv(0), lds_dkv(2)), grid, A, Bp, nA);
+        } else {
+            const dim3 grid(1, 2 * (nA + nB));
+            if (mode == 2) {
+                constexpr int L = cmax(cmax(lds_dq(0), lds_dkv(0)), cmax(lds_dq(2), lds_dkv(2)));
+                if (dr) {
+                    static bool o1 = (set_lds(attn_bwd_merged_dual_kernel<2, true>, L), true);
+                    (void)o1;
+                    hipLaunchKernelGGL((attn_bwd_merged_dual_kernel<2, true>), grid, dim3(448), L, s, A, Bp, nA, nB);
+                } else {
+                    static bool o2 = (set_lds(attn_bwd_merged_dual_kernel<2, false>, L), true);
+                    (void)o2;
+                    hipLaunchKernelGGL((attn_bwd_merged_dual_kernel<2, false>), grid, dim3(448), L, s, A, Bp, nA, nB);
+                }
+            } else {
+                constexpr int L = cmax(lds_dq(0), lds_dkv(0));
+                if (dr) {
+                    static bool o3 = (set_lds(attn_bwd_merged_dual_kernel<0, true>, L), true);
+                    (void)o3;
+                    hipLaunchKernelGGL((attn_bwd_merged_dual_kernel<0, true>), grid, dim3(448), L, s, A, Bp, nA, nB);
+                } else {
+                    static bool o4 = (set_lds(attn_bwd_merged_dual_kernel<0, false>, L), true);
+                    (void)o4;
+                    hipLaunchKernelGGL((attn_bwd_merged_dual_kernel<0, false>), grid, dim3(448), L, s, A, Bp, nA, nB);
+                }
+            }
+        }
     } else {
         for (int i = 0; i < n; ++i) launch_bwd(p[i], s);
     }

@@ -50,13 +50,37 @@ MH_DEV void store_row(h16* __restrict__ p, int D, int lane, const float (&v)[NCH
     }
 }
 
+// a row kept in its packed 16-bit form (4 registers per chunk): what a prefetch holds while the previous row computes
+template <int NCH>
+MH_DEV void load_row_raw(const h16* __restrict__ p, int D, int lane, i32x4 (&r)[NCH]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        r[i] = i32x4{0, 0, 0, 0};
+        if (c < D) r[i] = *(const i32x4*)(p + c);
+    }
+}
+template <int NCH>
+MH_DEV void unpack_row(const i32x4 (&r)[NCH], float (&v)[NCH][8]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        Pack8 u;
+        u.v = r[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = mh_bf2f(u.e[e]);
+    }
+}
+
 struct LnFwdGroup {
     int n;
     int start[MH_LN_MAX_JOBS + 1];      // first workgroup of each job
     MhLnFwdJob job[MH_LN_MAX_JOBS];
 };
 
-// grouped launch: workgroups [start[j], start[j+1]) normalise job j's rows, 4 rows (waves) per workgroup
+// grouped launch: workgroups [start[j], start[j+1]) normalise job j's rows, 8 rows per workgroup: every wave takes TWO
+// rows and has both rows' loads in flight before the first reduction (the kernel is a latency chain load -> reduce ->
+// reduce -> store; a second independent chain per wave hides half of it)
+constexpr int LN_FWD_ROWS_PER_WG = 8;
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp, int D) {
     int j = 0;
@@ -72,47 +96,58 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp, int D
     const int rows = jb.rows_dev ? min(jb.rows, *jb.rows_dev) : jb.rows;
     const float eps = jb.eps;
     const int lane = threadIdx.x & 63;
-    const int row = ((int)blockIdx.x - grp.start[j]) * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    float v[NCH][8], g[NCH][8], b[NCH][8];
-    load_row<NCH>(x + (size_t)row * D, D, lane, v);
+    const int row0 = ((int)blockIdx.x - grp.start[j]) * LN_FWD_ROWS_PER_WG + (threadIdx.x >> 6) * 2;
+    if (row0 >= rows) return;
+    const bool two = row0 + 1 < rows;
+    i32x4 raw0[NCH], raw1[NCH];
+    load_row_raw<NCH>(x + (size_t)row0 * D, D, lane, raw0);
+    load_row_raw<NCH>(x + (size_t)(two ? row0 + 1 : row0) * D, D, lane, raw1);
+    float g[NCH][8], b[NCH][8];
     load_row_f32<NCH>(gamma, D, lane, g);
     load_row_f32<NCH>(beta, D, lane, b);
-    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
+    for (int r = 0; r < 2; ++r) {
+        if (r == 1 && !two) break;
+        const int row = row0 + r;
+        float v[NCH][8];
+        if (r == 0) unpack_row<NCH>(raw0, v);
+        else unpack_row<NCH>(raw1, v);
+        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[i][e];
-    const float mu = wave_sum(s) / (float)D;
-    float ss = 0.f;
+        for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const bool ok = (lane + 64 * i) * 8 < D;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float d = ok ? v[i][e] - mu : 0.f;
-            ss += d * d;
-        }
-    }
-    const float rs = rsqrtf(wave_sum(ss) / (float)D + eps);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] - mu) * rs * g[i][e] + b[i][e];
-    store_row<NCH>(y + (size_t)row * D, D, lane, v);
-    if (y32) {
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        const float mu = wave_sum(s) / (float)D;
+        float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = (lane + 64 * i) * 8;
-            if (c < D) {
-                *(f32x4*)(y32 + (size_t)row * D + c) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
-                *(f32x4*)(y32 + (size_t)row * D + c + 4) = f32x4{v[i][4], v[i][5], v[i][6], v[i][7]};
+            const bool ok = (lane + 64 * i) * 8 < D;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = ok ? v[i][e] - mu : 0.f;
+                ss += d * d;
             }
         }
-    }
-    if (lane == 0) {
-        if (mean) mean[row] = mu;
-        if (rstd) rstd[row] = rs;
+        const float rs = rsqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] - mu) * rs * g[i][e] + b[i][e];
+        store_row<NCH>(y + (size_t)row * D, D, lane, v);
+        if (y32) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = (lane + 64 * i) * 8;
+                if (c < D) {
+                    *(f32x4*)(y32 + (size_t)row * D + c) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                    *(f32x4*)(y32 + (size_t)row * D + c + 4) = f32x4{v[i][4], v[i][5], v[i][6], v[i][7]};
+                }
+            }
+        }
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
     }
 }
 
@@ -153,11 +188,32 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LnBwdGroup grp, 
     const float invD = 1.0f / (float)D;
     const bool dropj = DROP && dx_drop != nullptr;      // per job: only some jobs of a group carry a dropout site
     const DropCtx drop = mh_drop_ctx(dropj ? jb.rng : nullptr, jb.drop_p, jb.drop_stream);
-    for (int row = blk * NWV + wave; row < rows; row += n_part * NWV) {
-        float xv[NCH][8], dv[NCH][8];
-        load_row<NCH>(x + (size_t)row * D, D, lane, xv);
-        load_row<NCH>(dy + (size_t)row * D, D, lane, dv);
-        const float mu = mean[row], rs = rstd[row];
+    // software pipeline: the next row's x / dy / dx_add (kept packed: 4 registers per chunk) and statistics are requested
+    // before the current row's two reductions, so a wave always has a row in flight
+    int row = blk * NWV + wave;
+    i32x4 nx[NCH], nd[NCH], na[NCH];
+    float nmu = 0.f, nrs = 0.f;
+    if (row < rows) {
+        load_row_raw<NCH>(x + (size_t)row * D, D, lane, nx);
+        load_row_raw<NCH>(dy + (size_t)row * D, D, lane, nd);
+        if (dx_add) load_row_raw<NCH>(dx_add + (size_t)row * D, D, lane, na);
+        nmu = mean[row];
+        nrs = rstd[row];
+    }
+    for (; row < rows; row += n_part * NWV) {
+        float xv[NCH][8], dv[NCH][8], av[NCH][8];
+        unpack_row<NCH>(nx, xv);
+        unpack_row<NCH>(nd, dv);
+        if (dx_add) unpack_row<NCH>(na, av);
+        const float mu = nmu, rs = nrs;
+        const int nrow = row + n_part * NWV;
+        if (nrow < rows) {
+            load_row_raw<NCH>(x + (size_t)nrow * D, D, lane, nx);
+            load_row_raw<NCH>(dy + (size_t)nrow * D, D, lane, nd);
+            if (dx_add) load_row_raw<NCH>(dx_add + (size_t)nrow * D, D, lane, na);
+            nmu = mean[nrow];
+            nrs = rstd[nrow];
+        }
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -176,8 +232,6 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LnBwdGroup grp, 
         c1 = wave_sum(c1) * invD;
         c2 = wave_sum(c2) * invD;
         if (dx_add) {
-            float av[NCH][8];
-            load_row<NCH>(dx_add + (size_t)row * D, D, lane, av);
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
 #pragma unroll
@@ -289,7 +343,7 @@ extern "C" int mh_layernorm_fwd_grouped(const MhLnFwdJob* jobs, int n_jobs, int 
         if (jb.rows < 1) return MH_ESHAPE;
         g.job[i] = jb;
         g.start[i] = blocks;
-        blocks += (jb.rows + 3) / 4;
+        blocks += (jb.rows + LN_FWD_ROWS_PER_WG - 1) / LN_FWD_ROWS_PER_WG;
     }
     for (int i = n_jobs; i <= MH_LN_MAX_JOBS; ++i) g.start[i] = blocks;
     hipStream_t s = (hipStream_t)stream;
