@@ -468,25 +468,24 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
             lse_t[slot * TILE + i] = qq < Sb ? lse[((size_t)b * H + hh) * S + qq] * LOG2E : 1.0e30f;
             if (!OWN_DELTA) dl_t[slot * TILE + i] = qq < Sb ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
         }
-        if (OWN_DELTA && tid < 4 * TILE) {     // four threads per query row, 16 dims each (NT >= 256)
-            const int i = tid >> 2, part = tid & 3;
+        if (OWN_DELTA && tid < 2 * TILE) {     // two threads per query row, summing in the dQ kernel's order (bit-identical
+            const int i = tid >> 1, hf = tid & 1;   // delta): dims 16 s + 8 hf + j, s-major, then the two halves added
             const int qq = t * TILE + i;
             float dl = 0.f;
             if (qq < Sb) {
-                const h16* dr = dob + (size_t)qq * H * HD + part * 16;
-                const h16* orow = outp + (r0 + qq) * (size_t)H * HD + hh * HD + part * 16;
+                const h16* dr = dob + (size_t)qq * H * HD + 8 * hf;
+                const h16* orow = outp + (r0 + qq) * (size_t)H * HD + hh * HD + 8 * hf;
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) {
+                for (int s4 = 0; s4 < 4; ++s4) {
                     Pack8 a, o;
-                    a.v = *(const i32x4*)(dr + c2 * 8);
-                    o.v = *(const i32x4*)(orow + c2 * 8);
+                    a.v = *(const i32x4*)(dr + 16 * s4);
+                    o.v = *(const i32x4*)(orow + 16 * s4);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) dl += (float)a.e[e] * (float)o.e[e];
+                    for (int j = 0; j < 8; ++j) dl += (float)a.h[j] * (float)o.h[j];
                 }
             }
             dl += __shfl_xor(dl, 1, 64);
-            dl += __shfl_xor(dl, 2, 64);
-            if (part == 0) dl_t[slot * TILE + i] = dl;
+            if (hf == 0) dl_t[slot * TILE + i] = dl;
         }
     };
     if (NT_RES > 0) {
@@ -665,14 +664,15 @@ int bwd_resident_max() {
     }
     return v;
 }
-// MEMEHIP_ATTN_BWD_MERGED: 0 = dQ launch then dK/dV launch (round 1), 1 = one launch, text heads streaming (default),
-// 2 = one launch, text heads resident
+// MEMEHIP_ATTN_BWD_MERGED: 0 = dQ launch then dK/dV launch (round 1), 1 = one launch, text heads streaming,
+// 2 = one launch, text heads resident (default).  Measured in the step (same box, 30 steps): 10.05 / 10.01 / 10.00 ms --
+// the side-stream weight-gradient GEMMs already fill the holes of the two-launch form, so the merge returns little.
 int bwd_merged_mode() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MEMEHIP_ATTN_BWD_MERGED");
-        v = e ? atoi(e) : 1;
-        if (v < 0 || v > 2) v = 1;
+        v = e ? atoi(e) : 2;
+        if (v < 0 || v > 2) v = 2;
     }
     return v;
 }
