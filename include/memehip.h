@@ -57,9 +57,10 @@ const char* mh_status_str(int status);
  *                  if mul_dgelu: v *= gelu'(mul[m,n]);  if residual: v += residual[m,n];
  *                  C[m,n] = v  (bf16, or f32 when MH_GEMM_OUT_F32; += when MH_GEMM_ACCUM with f32).
  * rowsum (wgrad only, a_kmajor==1): rowsum[m] = sum_k A(m,k)  -- the bias gradient.
- * Constraints: N % 128 == 0; K % 64 == 0 unless the contraction dim is the leading (row) index
- * of both operands (a_kmajor && b_kmajor), in which case any K; M any when a_kmajor==0, else
- * M % 128 == 0; ld* % 8 == 0; all bases 16-byte aligned; up to MH_GEMM_MAX_GROUP problems.
+ * Constraints: N % 8 == 0 (128-column tiles; a last partial tile computes and discards the columns past N);
+ * K % 64 == 0 unless the contraction dim is the leading (row) index of both operands (a_kmajor && b_kmajor), in
+ * which case any K; M any when a_kmajor==0, else M % 8 == 0; ld* % 8 == 0; all bases 16-byte aligned; up to
+ * MH_GEMM_MAX_GROUP problems.
  * ------------------------------------------------------------------------------------------ */
 #define MH_GEMM_MAX_GROUP 8
 #define MH_GEMM_GELU 1
@@ -384,6 +385,44 @@ int mh_conv_fold_f32(const float* da, float* dh, int B, int S, int D, int taps, 
 /* ConcatAttention3's gate (Multimodal_example_task2C.py:495-496): y = softmax(g, dim=1) * c ; bwd: dg, dc from dy */
 int mh_softmax_gate_fwd(const float* g, const float* c, float* y, int B, int F, mh_stream_t stream);
 int mh_softmax_gate_bwd(const float* g, const float* c, const float* dy, float* dg, float* dc, int B, int F, mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conv tower (BASELINE config 2: torchvision ResNet-50 as wired at Multimodal_example_task2C.txt:164-165,183-184).
+ * Activations are NHWC 16-bit = a row-major [B*H*W][C] matrix, so a convolution is mh_gemm_bf16_grouped:
+ *   1x1 / stride 1 : directly on the activation matrix;  k x k or strided: on the mh_im2col_nhwc matrix
+ *   (column order (kh, kw, c); weights packed to [Cout][(kh,kw,c)] by mh_conv_weight_pack);
+ *   dgrad = the GEMM in the dgrad layout followed by mh_col2im_nhwc (gather form, no atomics);
+ *   wgrad = the GEMM in the wgrad layout over the im2col matrix, un-packed by mh_conv_weight_unpack.
+ * mh_bn2d_fwd / mh_bn2d_bwd: nn.BatchNorm2d over that matrix (M = B*H*W rows), training mode = per-replica batch
+ *   statistics (biased variance for the normalisation, unbiased for the running statistics, momentum form), optional fused
+ *   residual add and ReLU: y = relu(bn(x) + residual).  workspace: f32, >= (ceil(M/128) * 2 + 2) * C elements.
+ *   bwd: dx, the residual-branch gradient dres (= dy masked by the ReLU), dgamma, dbeta (times `scale`).
+ * mh_maxpool_* (k x k / stride / pad, first maximum wins, arg = tap index), mh_avgpool_* (global), mh_nchw_to_nhwc (f32 image
+ * -> 16-bit NHWC with the channels zero-padded to Cp), mh_add_h16.
+ * ------------------------------------------------------------------------------------------ */
+int mh_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int Cp, mh_stream_t stream);
+int mh_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int ldc,
+                   mh_stream_t stream);
+int mh_col2im_nhwc(const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int ldc,
+                   mh_stream_t stream);
+int mh_conv_weight_pack(const float* w /*[Cout][Cin][KH][KW]*/, void* out /*16-bit [Cout][ldk]*/, int Cout, int Cin, int KH, int KW,
+                        int Cp, int ldk, mh_stream_t stream);
+int mh_conv_weight_unpack(const float* gk /*[Cout][ldk]*/, float* g /*[Cout][Cin][KH][KW]*/, int Cout, int Cin, int KH, int KW, int Cp,
+                          int ldk, float scale, mh_stream_t stream);
+int mh_bn2d_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, const void* residual,
+                void* y, float* save_mean, float* save_rstd, float* workspace, int M, int C, float eps, float momentum, int training,
+                int relu, mh_stream_t stream);
+int mh_bn2d_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const void* residual,
+                  void* y, int M, int C, int relu, mh_stream_t stream);
+int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean, const float* save_rstd,
+                void* dx, void* dres, float* dgamma, float* dbeta, float* workspace, int M, int C, int relu, float scale,
+                mh_stream_t stream);
+int mh_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad, mh_stream_t stream);
+int mh_maxpool_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, int K, int stride, int pad,
+                   mh_stream_t stream);
+int mh_avgpool_fwd(const void* x, float* y, int B, int HW, int C, mh_stream_t stream);
+int mh_avgpool_bwd(const float* dy, void* dx, int B, int HW, int C, float scale, mh_stream_t stream);
+int mh_add_h16(const void* a, const void* b, void* y, int64_t n, mh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam / AdamW, Multimodal_example_task2C.txt:249,217; HF Trainer

@@ -127,6 +127,19 @@ _PROTOS = {
     "mh_conv_fold_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     "mh_softmax_gate_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "mh_softmax_gate_bwd": [c_void_p] * 5 + [c_int, c_int, c_void_p],
+    "mh_nchw_to_nhwc": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
+    "mh_im2col_nhwc": [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p],
+    "mh_col2im_nhwc": [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p],
+    "mh_conv_weight_pack": [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
+    "mh_conv_weight_unpack": [c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p],
+    "mh_bn2d_fwd": [c_void_p] * 10 + [c_int, c_int, c_float, c_float, c_int, c_int, c_void_p],
+    "mh_bn2d_apply": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p],
+    "mh_bn2d_bwd": [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p],
+    "mh_maxpool_fwd": [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "mh_maxpool_bwd": [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "mh_avgpool_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mh_avgpool_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
+    "mh_add_h16": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
     "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],

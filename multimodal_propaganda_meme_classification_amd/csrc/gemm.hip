@@ -168,7 +168,7 @@ MH_DEV void epilogue_prefetch(const MhGemmProblem& P, int m0, int n0, int tid, i
     for (int it = 0; it < EpiPrefetch<TM, NTHR>::iters; ++it) {
         const int q = it * NTHR + tid;
         const int row = q >> 4, cc = q & 15;
-        const int gm = min(m0 + row, M - 1), gn = n0 + cc * 8;       // clamped: rows past M are never stored
+        const int gm = min(m0 + row, M - 1), gn = min(n0 + cc * 8, P.N - 8);   // clamped: rows past M / columns past N are never stored
         const size_t o = (size_t)gm * P.ldc + gn;
         pf.res[it] = i32x4{0, 0, 0, 0};
         pf.mul[it] = i32x4{0, 0, 0, 0};
@@ -191,7 +191,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
         const int q = it * nthreads + tid;
         const int row = q >> 4, cc = q & 15;
         const int gm = m0 + row, gn = n0 + cc * 8;
-        if (gm >= M) continue;
+        if (gm >= M || gn >= P.N) continue;      // ragged M; N need not fill the last 128-column tile (conv layers with 64 filters)
         float v[8];
         {
             const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
@@ -1173,18 +1173,18 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         const MhGemmProblem& p = problems[i];
         if (!p.A || !p.B || !p.C) return MH_EINVAL;
         if (p.M < 1 || p.N < 1 || p.K < 1) return MH_ESHAPE;
-        if (p.N % BN) return MH_ESHAPE;
-        if (a_kmajor && (p.M % BM)) return MH_ESHAPE;
+        if (p.N % 8) return MH_ESHAPE;
+        if (a_kmajor && (p.M % 8)) return MH_ESHAPE;
         if (!(a_kmajor && b_kmajor) && (p.K % BK)) return MH_ESHAPE;     // (also a multiple of variant 6's 32)
         if ((p.lda % 8) || (p.ldb % 8) || (p.ldc % 8)) return MH_ESHAPE;
         if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return MH_EINVAL;
         if (p.rowsum && !a_kmajor) return MH_EINVAL;
         if ((p.flags & MH_GEMM_ACCUM) && !(p.flags & MH_GEMM_OUT_F32)) return MH_EINVAL;
         g.d[i].p = p;
-        g.d[i].tiles_n = p.N / tile_n;
+        g.d[i].tiles_n = (p.N + tile_n - 1) / tile_n;
         g.d[i].tile_start = total;
         g.d[i].tiles_m = (p.M + tile_m - 1) / tile_m;
-        total += g.d[i].tiles_m * (p.N / tile_n);
+        total += g.d[i].tiles_m * g.d[i].tiles_n;
     }
     g.total_tiles = total;
     static int group_m = -1;

@@ -1,0 +1,324 @@
+"""ResNet-50 image tower on the HIP path (BASELINE config 2; the organizers' image encoder:
+``models.resnet50(pretrained=True)`` -> 1000 logits -> ``Linear(1000, 512)``, Multimodal_example_task2C.txt:164-165,183-184).
+
+``ResNet50`` has torchvision's module tree and state_dict keys (``conv1.weight``, ``bn1.running_mean``,
+``layer3.4.conv2.weight``, ``layer2.0.downsample.0.weight``, ``fc.bias`` ...): the ``nn.Conv2d / nn.BatchNorm2d / nn.Linear``
+submodules only HOLD the parameters and running statistics; the arithmetic runs in libmemehip:
+
+* activations NHWC 16-bit (a [B*H*W][C] matrix); every convolution is ``mh_gemm_bf16_grouped`` -- directly for 1x1/stride 1,
+  over ``mh_im2col_nhwc`` otherwise; weights are re-packed to ``[Cout][(kh,kw,c)]`` 16-bit every forward (150 MB of traffic);
+* train-mode BatchNorm2d with per-replica batch statistics (the reference uses plain BN) fused with the residual
+  add and the ReLU (``mh_bn2d_fwd / mh_bn2d_bwd``), max pool, global average pool, the 2048 -> 1000 classifier in exact f32;
+* the backward is one opaque autograd node (dgrad GEMM + ``mh_col2im_nhwc``, wgrad GEMM, BatchNorm backward);
+* the 16-bit gradient stream carries ``grad_stream_scale`` (8192 for fp16), removed where parameter gradients are produced.
+
+``ResNetClassifier`` is the Subtask-2B surface (ResNet_example_task2B.py:206-221): ``model(pixel_values=..., labels=...)``
+returns ``(loss, logits)`` for HF Trainer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, fused, ops
+from ._lib import check
+from .model import CrossEntropyLoss
+
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Conv:
+    """One convolution's geometry + launches."""
+
+    def __init__(self, mod: nn.Conv2d, cin_pad: Optional[int] = None):
+        self.mod = mod
+        self.cout, self.cin = mod.out_channels, mod.in_channels
+        self.kh, self.kw = mod.kernel_size
+        self.stride, self.pad = mod.stride[0], mod.padding[0]
+        self.cp = cin_pad or self.cin                      # channels of the NHWC input (3 -> 8 for the stem)
+        k = self.kh * self.kw * self.cp
+        self.ldk = (k + 63) // 64 * 64                     # GEMM contraction (multiple of 64)
+        self.direct = self.kh == 1 and self.kw == 1 and self.stride == 1 and self.ldk == self.cp
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
+
+    def pack_weight(self, lib, T16):
+        wk = torch.empty((self.cout, self.ldk), dtype=T16, device=self.mod.weight.device)
+        check(lib.mh_conv_weight_pack(self.mod.weight.data_ptr(), wk.data_ptr(), self.cout, self.cin, self.kh, self.kw, self.cp, self.ldk,
+                                      _stream()), "mh_conv_weight_pack")
+        return wk
+
+    def forward(self, lib, x, B, H, W, T16):
+        """x: [B*H*W, cp] 16-bit -> (y [B*Ho*Wo, cout] 16-bit, saved A matrix, wk, Ho, Wo)"""
+        Ho, Wo = self.out_hw(H, W)
+        M = B * Ho * Wo
+        if self.direct:
+            A = x
+        else:
+            A = torch.empty((M, self.ldk), dtype=T16, device=x.device)
+            check(lib.mh_im2col_nhwc(x.data_ptr(), A.data_ptr(), B, H, W, self.cp, self.kh, self.kw, self.stride, self.pad, self.ldk,
+                                     _stream()), "mh_im2col_nhwc")
+        wk = self.pack_weight(lib, T16)
+        y = torch.empty((M, self.cout), dtype=T16, device=x.device)
+        ops.gemm_grouped([ops.Gemm(A, wk, y, M, self.cout, self.ldk, self.ldk, self.ldk, self.cout)], False, False)
+        return y, A, wk, Ho, Wo
+
+    def backward(self, lib, dy, A, wk, B, H, W, Ho, Wo, gscale, grads, need_dx=True):
+        """dy [M, cout] 16-bit -> dx [B*H*W, cp] 16-bit (or None); the weight gradient goes to grads[id(weight)]"""
+        M = B * Ho * Wo
+        dev = dy.device
+        gk = torch.empty((self.cout, self.ldk), dtype=F32, device=dev)
+        ops.gemm_grouped([ops.Gemm(dy, A, gk, self.cout, self.ldk, M, self.cout, self.ldk, self.ldk, alpha=1.0 / gscale)], True, True)
+        g = torch.empty_like(self.mod.weight)
+        check(lib.mh_conv_weight_unpack(gk.data_ptr(), g.data_ptr(), self.cout, self.cin, self.kh, self.kw, self.cp, self.ldk, 1.0,
+                                        _stream()), "mh_conv_weight_unpack")
+        grads[id(self.mod.weight)] = g
+        if not need_dx:
+            return None
+        dA = torch.empty((M, self.ldk), dtype=dy.dtype, device=dev)
+        ops.gemm_grouped([ops.Gemm(dy, wk, dA, M, self.ldk, self.cout, self.cout, self.ldk, self.ldk)], False, True)
+        if self.direct:
+            return dA
+        dx = torch.empty((B * H * W, self.cp), dtype=dy.dtype, device=dev)
+        check(lib.mh_col2im_nhwc(dA.data_ptr(), dx.data_ptr(), B, H, W, self.cp, self.kh, self.kw, self.stride, self.pad, self.ldk,
+                                 _stream()), "mh_col2im_nhwc")
+        return dx
+
+
+class _BN:
+    def __init__(self, mod: nn.BatchNorm2d):
+        self.mod = mod
+        self.C = mod.num_features
+
+    def _ws(self, M, dev):
+        return torch.empty(((M + 127) // 128 * 2 + 2) * self.C, dtype=F32, device=dev)
+
+    def forward(self, lib, x, M, residual, relu, training):
+        m = self.mod
+        y = torch.empty_like(x)
+        sm, sr = torch.empty(self.C, dtype=F32, device=x.device), torch.empty(self.C, dtype=F32, device=x.device)
+        check(lib.mh_bn2d_fwd(x.data_ptr(), m.weight.data_ptr(), m.bias.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr(),
+                              None if residual is None else residual.data_ptr(), y.data_ptr(), sm.data_ptr(), sr.data_ptr(),
+                              self._ws(M, x.device).data_ptr(), M, self.C, float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+                              int(training), int(relu), _stream()), "mh_bn2d_fwd")
+        if training:
+            m.num_batches_tracked += 1
+        return y, sm, sr
+
+    def backward(self, lib, dy, x, y, sm, sr, M, relu, want_dres, gscale, grads):
+        m = self.mod
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if want_dres else None
+        dg, db = torch.empty_like(m.weight), torch.empty_like(m.bias)
+        check(lib.mh_bn2d_bwd(dy.data_ptr(), x.data_ptr(), None if y is None else y.data_ptr(), m.weight.data_ptr(), sm.data_ptr(),
+                              sr.data_ptr(), dx.data_ptr(), None if dres is None else dres.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                              self._ws(M, x.device).data_ptr(), M, self.C, int(relu), 1.0 / gscale, _stream()), "mh_bn2d_bwd")
+        grads[id(m.weight)], grads[id(m.bias)] = dg, db
+        return dx, dres
+
+
+class Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (v1.5: the stride sits on the 3x3 convolution): parameter holder."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: bool = False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        self.stride = stride
+
+
+class _TowerFn(torch.autograd.Function):
+    """Opaque autograd node: the whole conv tower forward; backward walks the saved tape."""
+
+    @staticmethod
+    def forward(ctx, image, net, *params):
+        ctx.net = net
+        ctx.tape = net._forward_tape(image, training=net.training)
+        return ctx.tape["pooled"].clone()
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        grads = ctx.net._backward_tape(ctx.tape, d_pooled)
+        ctx.tape = None
+        return (None, None) + tuple(grads[id(p)] for p in ctx.net._tower_params)
+
+
+class ResNet50(nn.Module):
+    """torchvision ``resnet50`` topology and state_dict on the HIP kernels.  ``forward(image f32 [B,3,H,W]) -> logits [B,1000]``
+    (``num_classes`` outputs); ``features(image)`` returns the pooled 2048-d features."""
+
+    def __init__(self, num_classes: int = 1000, compute_dtype: str = "fp16", layers=(3, 4, 6, 3), width: int = 64,
+                 grad_stream_scale: float = 0.0, seed: int = 0):
+        super().__init__()
+        if compute_dtype not in ("bf16", "fp16"):
+            raise ValueError(f"compute_dtype must be 'bf16' or 'fp16', got {compute_dtype!r}")
+        torch.manual_seed(seed)
+        self.compute_dtype = compute_dtype
+        self.gscale = float(grad_stream_scale) if grad_stream_scale else (8192.0 if compute_dtype == "fp16" else 1.0)
+        self.conv1 = nn.Conv2d(3, width, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        inplanes = width
+        for li, (n, planes, stride) in enumerate(zip(layers, (width, width * 2, width * 4, width * 8), (1, 2, 2, 2)), 1):
+            blocks = []
+            for bi in range(n):
+                s = stride if bi == 0 else 1
+                blocks.append(Bottleneck(inplanes, planes, s, downsample=(bi == 0 and (s != 1 or inplanes != planes * 4))))
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self.feature_dim = inplanes
+        self.fc = nn.Linear(inplanes, num_classes)
+        for m in self.modules():          # torchvision's initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._tower_params: List[nn.Parameter] = [p for n, p in self.named_parameters() if not n.startswith("fc.")]
+
+    # ---- launches ----------------------------------------------------------------------------------------------
+    def _lib(self):
+        return _lib.load(self.compute_dtype)
+
+    def _blocks(self):
+        for li in range(1, 5):
+            for blk in getattr(self, f"layer{li}"):
+                yield blk
+
+    def _forward_tape(self, image: torch.Tensor, training: bool):
+        if not image.is_cuda:
+            raise _lib.MemehipError("ResNet50 runs on the HIP device only (no CPU fallback): move the batch with .to(device)")
+        lib = self._lib()
+        T16 = torch.float16 if self.compute_dtype == "fp16" else torch.bfloat16
+        B, Cc, H, W = image.shape
+        if Cc != 3:
+            raise ValueError("ResNet50 expects 3-channel images")
+        tape = {"B": B, "ops": []}
+        x = torch.empty((B * H * W, 8), dtype=T16, device=image.device)
+        check(lib.mh_nchw_to_nhwc(image.to(F32).contiguous().data_ptr(), x.data_ptr(), B, 3, H, W, 8, _stream()), "mh_nchw_to_nhwc")
+
+        def conv_bn(conv_mod, bn_mod, xin, h, w, residual=None, relu=True, cin_pad=None):
+            cv, bn = _Conv(conv_mod, cin_pad), _BN(bn_mod)
+            z, A, wk, ho, wo = cv.forward(lib, xin, B, h, w, T16)
+            M = B * ho * wo
+            y, sm, sr = bn.forward(lib, z, M, residual, relu, training)
+            tape["ops"].append(("conv_bn", cv, bn, A, wk, z, y, sm, sr, h, w, ho, wo, relu, residual is not None))
+            return y, ho, wo
+
+        y, h, w = conv_bn(self.conv1, self.bn1, x, H, W, cin_pad=8)
+        C1 = self.conv1.out_channels
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        p = torch.empty((B * ho * wo, C1), dtype=T16, device=image.device)
+        arg = torch.empty((B * ho * wo, C1), dtype=torch.uint8, device=image.device)
+        check(lib.mh_maxpool_fwd(y.data_ptr(), p.data_ptr(), arg.data_ptr(), B, h, w, C1, 3, 2, 1, _stream()), "mh_maxpool_fwd")
+        tape["ops"].append(("maxpool", arg, h, w, C1))
+        x, h, w = p, ho, wo
+        for blk in self._blocks():
+            tape["ops"].append(("block_begin",))
+            identity, ih, iw = x, h, w
+            o, h1, w1 = conv_bn(blk.conv1, blk.bn1, x, h, w)
+            o, h2, w2 = conv_bn(blk.conv2, blk.bn2, o, h1, w1)
+            if blk.downsample is not None:
+                identity, _, _ = conv_bn(blk.downsample[0], blk.downsample[1], x, ih, iw, relu=False)
+                tape["ops"].append(("branch_end",))
+            x, h, w = conv_bn(blk.conv3, blk.bn3, o, h2, w2, residual=identity, relu=True)
+            tape["ops"].append(("block_end", blk.downsample is not None))
+        Cf = self.feature_dim
+        pooled = torch.empty((B, Cf), dtype=F32, device=image.device)
+        check(lib.mh_avgpool_fwd(x.data_ptr(), pooled.data_ptr(), B, h * w, Cf, _stream()), "mh_avgpool_fwd")
+        tape.update(pooled=pooled, last_hw=(h, w), T16=T16)
+        return tape
+
+    def _backward_tape(self, tape, d_pooled: torch.Tensor):
+        lib = self._lib()
+        B, T16 = tape["B"], tape["T16"]
+        h, w = tape["last_hw"]
+        Cf = self.feature_dim
+        dev = d_pooled.device
+        dx = torch.empty((B * h * w, Cf), dtype=T16, device=dev)
+        check(lib.mh_avgpool_bwd(d_pooled.to(F32).contiguous().data_ptr(), dx.data_ptr(), B, h * w, Cf, self.gscale, _stream()), "mh_avgpool_bwd")
+        ops_ = tape["ops"]
+        i = len(ops_) - 1
+        grads = {}      # id(parameter) -> gradient tensor (returned to autograd, which accumulates into .grad)
+
+        def conv_bn_bwd(op, dy, want_dres, need_dx=True):
+            _, cv, bn, A, wk, z, y, sm, sr, hh, ww, ho, wo, relu, has_res = op
+            M = B * ho * wo
+            dz, dres = bn.backward(lib, dy, z, y if relu else None, sm, sr, M, relu, want_dres, self.gscale, grads)
+            dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, grads, need_dx)
+            return dxin, dres
+
+        while i >= 0:
+            op = ops_[i]
+            kind = op[0]
+            if kind == "block_end":
+                has_ds = op[1]
+                # conv3 + bn3 (+ residual + relu): dres is the gradient of the identity branch
+                d_o, dres = conv_bn_bwd(ops_[i - 1], dx, want_dres=True)
+                j = i - 2
+                d_ident = dres
+                if has_ds:
+                    assert ops_[j][0] == "branch_end"
+                    d_branch_in, _ = conv_bn_bwd(ops_[j - 1], dres, want_dres=False)      # downsample conv + bn (no relu)
+                    d_ident = d_branch_in
+                    j -= 2
+                d_o, _ = conv_bn_bwd(ops_[j], d_o, want_dres=False)        # conv2
+                d_o, _ = conv_bn_bwd(ops_[j - 1], d_o, want_dres=False)    # conv1
+                assert ops_[j - 2][0] == "block_begin"
+                merged = torch.empty_like(d_o)
+                check(lib.mh_add_h16(d_o.data_ptr(), d_ident.data_ptr(), merged.data_ptr(), d_o.numel(), _stream()), "mh_add_h16")
+                dx = merged
+                i = j - 3
+                continue
+            if kind == "maxpool":
+                _, arg, hh, ww, C1 = op
+                dxp = torch.empty((B * hh * ww, C1), dtype=T16, device=dev)
+                check(lib.mh_maxpool_bwd(dx.data_ptr(), arg.data_ptr(), dxp.data_ptr(), B, hh, ww, C1, 3, 2, 1, _stream()), "mh_maxpool_bwd")
+                dx = dxp
+                i -= 1
+                continue
+            if kind == "conv_bn":      # the stem
+                conv_bn_bwd(op, dx, want_dres=False, need_dx=False)
+                i -= 1
+                continue
+            raise AssertionError(kind)
+        return grads
+
+    # ---- nn.Module surface ------------------------------------------------------------------------------------------
+    def features(self, image: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and self.training:
+            return _TowerFn.apply(image, self, *self._tower_params)
+        return self._forward_tape(image, training=self.training)["pooled"]
+
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        return fused.linear(self.features(image), self.fc.weight, self.fc.bias)
+
+
+class ResNetClassifier(nn.Module):
+    """Subtask-2B surface over ``ResNet50`` (ResNet_example_task2B.py:206-221): ``model(pixel_values=..., labels=...)`` ->
+    ``(loss, logits)``; without labels ``logits``."""
+
+    def __init__(self, num_labels: int = 2, compute_dtype: str = "fp16", **kw):
+        super().__init__()
+        self.resnet = ResNet50(num_classes=num_labels, compute_dtype=compute_dtype, **kw)
+        self.loss_fct = CrossEntropyLoss()
+
+    def forward(self, pixel_values=None, labels=None, **unused):
+        if pixel_values is None:
+            raise ValueError("ResNetClassifier.forward needs pixel_values")
+        logits = self.resnet(pixel_values)
+        if labels is not None:
+            return self.loss_fct(logits, labels.view(-1)), logits
+        return logits

@@ -241,6 +241,58 @@ def gen_clip_case(name: str = "clip_l14_336_2layer", layers: int = 2, batch: int
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+def gen_resnet_case(name: str = "resnet_1111_w64", layers=(1, 1, 1, 1), width: int = 64, batch: int = 2, size: int = 64, seed: int = 13):
+    """Pins oracle/resnet_oracle.py against transformers' ResNetModel (bottleneck, stride on the 3x3 conv = torchvision
+    v1.5): pooled features, the gradient of sum(pooled * r) w.r.t. every parameter, running statistics after the step."""
+    from transformers import ResNetConfig, ResNetModel
+    from . import resnet_oracle as R
+    p = {k: v for k, v in R.resnet_init(layers, width, 10, seed).items() if not k.startswith("fc.")}
+    cfg = ResNetConfig(num_channels=3, embedding_size=width, hidden_sizes=[width * 4, width * 8, width * 16, width * 32],
+                       depths=list(layers), layer_type="bottleneck", hidden_act="relu", downsample_in_bottleneck=False)
+    model = ResNetModel(cfg)
+    sd = model.state_dict()
+
+    def hf(k):
+        if k.startswith("conv1."):
+            return "embedder.embedder.convolution." + k[6:]
+        if k.startswith("bn1."):
+            return "embedder.embedder.normalization." + k[4:]
+        m_ = re.match(r"layer(\d)\.(\d+)\.(conv|bn)(\d)\.(.*)", k)
+        if m_:
+            li, bi, kind, idx, rest = m_.groups()
+            return f"encoder.stages.{int(li) - 1}.layers.{bi}.layer.{int(idx) - 1}.{'convolution' if kind == 'conv' else 'normalization'}.{rest}"
+        m_ = re.match(r"layer(\d)\.(\d+)\.downsample\.(\d)\.(.*)", k)
+        li, bi, idx, rest = m_.groups()
+        return f"encoder.stages.{int(li) - 1}.layers.{bi}.shortcut.{'convolution' if idx == '0' else 'normalization'}.{rest}"
+
+    mapped = {hf(k): v.clone() for k, v in p.items()}
+    missing = [k for k in mapped if k not in sd]
+    assert not missing, missing[:4]
+    extra = [k for k in sd if k not in mapped and "running" not in k and "num_batches" not in k]
+    assert not extra, extra[:4]
+    model.load_state_dict(mapped, strict=False)
+    model.train()
+    g = torch.Generator().manual_seed(2000 + seed)
+    image = torch.randn((batch, 3, size, size), generator=g)
+    r = torch.randn((batch, width * 32), generator=g)
+    out = model(pixel_values=image).pooler_output.flatten(1)
+    (out * r).sum().backward()
+    back = {hf(k): k for k in p}
+    names = [back[n] for n, _ in model.named_parameters()]
+    after = model.state_dict()
+    res = {"seed": np.array(seed), "layers": np.array(layers), "width": np.array(width), "batch": np.array(batch), "size": np.array(size),
+           "input_checksum": np.array([float(image.double().sum()), float(image.double().abs().sum()), float(r.double().sum())]),
+           "param_checksum": checksum(p), "pooled": out.detach().numpy(), "grad_names": np.array(names),
+           "grad_norms": np.array([float(q.grad.double().norm()) for _, q in model.named_parameters()]),
+           "grad_samples": np.stack([sample_of(q.grad) for _, q in model.named_parameters()]),
+           "bn1_running_mean": after["embedder.embedder.normalization.running_mean"].numpy(),
+           "bn1_running_var": after["embedder.embedder.normalization.running_var"].numpy(),
+           "last_running_var": after[hf(f"layer4.{layers[3] - 1}.bn3.weight").replace("weight", "running_var")].numpy()}
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **res)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 def gen_index_fixtures():
     """(iii) bit-exact index fixtures: patch order of a counting image, token gather rows."""
     img = torch.arange(2 * 3 * 32 * 32, dtype=torch.float32).view(2, 3, 32, 32)
@@ -261,6 +313,9 @@ def gen_index_fixtures():
 
 def main():
     torch.set_num_threads(8)
+    if "--only-resnet" in sys.argv:
+        gen_resnet_case()
+        return
     if "--only-clip" in sys.argv:
         gen_clip_case()
         return

@@ -154,3 +154,33 @@ def test_clip_branch_matches_transformers_clip_vision_model(golden_dir):
     for n, ref in zip(names, z["grad_samples"]):
         f = leaves[n].grad.reshape(-1)
         np.testing.assert_allclose(f[sample_index(f.numel())].numpy(), ref, rtol=5e-3, atol=2e-5)
+
+
+def test_resnet_oracle_matches_transformers_resnet_model(golden_dir):
+    """oracle/resnet_oracle.py (torchvision ResNet-50 v1.5 restated) against the fixture made from transformers'
+    ResNetModel with the same weights (gen_golden.py: gen_resnet_case): pooled features, every gradient, running statistics."""
+    from oracle import resnet_oracle as R
+    from oracle.gen_golden import sample_index
+    z = _load(golden_dir, "resnet_1111_w64")
+    layers, width, batch, size, seed = tuple(int(x) for x in z["layers"]), int(z["width"]), int(z["batch"]), int(z["size"]), int(z["seed"])
+    p = {k: v for k, v in R.resnet_init(layers, width, 10, seed).items() if not k.startswith("fc.")}
+    np.testing.assert_allclose(_checksum(p), z["param_checksum"], rtol=1e-9)
+    g = torch.Generator().manual_seed(2000 + seed)
+    image = torch.randn((batch, 3, size, size), generator=g)
+    r = torch.randn((batch, width * 32), generator=g)
+    np.testing.assert_allclose([float(image.double().sum()), float(image.double().abs().sum()), float(r.double().sum())],
+                               z["input_checksum"], rtol=1e-9)
+    leaves = {k: t.clone().requires_grad_(True) for k, t in p.items()}
+    st = R.new_bn_state(p)
+    pooled = R.resnet_features(leaves, st, image, layers, training=True)
+    np.testing.assert_allclose(pooled.detach().numpy(), z["pooled"], atol=2e-5, rtol=1e-4)
+    (pooled * r).sum().backward()
+    names = [str(n) for n in z["grad_names"]]
+    norms = np.array([float(leaves[n].grad.double().norm()) for n in names])
+    np.testing.assert_allclose(norms, z["grad_norms"], rtol=2e-3, atol=1e-6)
+    for n, ref in zip(names, z["grad_samples"]):
+        f = leaves[n].grad.reshape(-1)
+        np.testing.assert_allclose(f[sample_index(f.numel())].numpy(), ref, rtol=2e-2, atol=2e-4 * float(np.abs(ref).max() + 1e-6) + 1e-6)
+    np.testing.assert_allclose(st["bn1.running_mean"].numpy(), z["bn1_running_mean"], atol=1e-6)
+    np.testing.assert_allclose(st["bn1.running_var"].numpy(), z["bn1_running_var"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(st[f"layer4.{layers[3] - 1}.bn3.running_var"].numpy(), z["last_running_var"], atol=1e-6, rtol=1e-4)

@@ -1,0 +1,183 @@
+"""BASELINE config 2 on the MI355X: the ResNet-50 image tower (torchvision topology, Multimodal_example_task2C.txt:164,183)
+through the C ABI -- the NHWC kernels one by one, a bottleneck block and a four-stage tower forward + backward against the
+CPU oracle (oracle/resnet_oracle.py, pinned to transformers' ResNetModel in test_oracle_golden.py), and the Subtask-2B
+Trainer surface."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+F16, BF16, F32 = torch.float16, torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import multimodal_propaganda_meme_classification_amd as m
+    return m
+
+
+def _nhwc(x, T16):      # [B,C,H,W] f32 -> [B*H*W, C] 16-bit on the device
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).to(T16).cuda().contiguous()
+
+
+def _nchw(m, B, H, W):  # [B*H*W, C] -> [B,C,H,W] f32 cpu
+    return m.float().cpu().view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("T16", [F16, BF16])
+def test_im2col_col2im_pool_kernels_are_exact(pkg, T16):
+    lib = pkg._lib.load("fp16" if T16 == F16 else "bf16")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(1)
+    B, C, H, W = 2, 16, 9, 7
+    x = torch.randint(-4, 5, (B, C, H, W), generator=g).float()
+    xd = _nhwc(x, T16)
+    for (k, s, p) in ((3, 1, 1), (3, 2, 1), (1, 2, 0), (7, 2, 3)):
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        ld = (k * k * C + 63) // 64 * 64
+        col = torch.full((B * Ho * Wo, ld), 9.0, dtype=T16, device="cuda")
+        pkg._lib.check(lib.mh_im2col_nhwc(xd.data_ptr(), col.data_ptr(), B, H, W, C, k, k, s, p, ld, st), "im2col")
+        ref = F.unfold(x, k, padding=p, stride=s)                       # [B, C*k*k, L] with (c, kh, kw) order
+        ref = ref.view(B, C, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, k * k * C)     # -> (kh, kw, c)
+        assert torch.equal(col[:, :k * k * C].float().cpu(), ref) and float(col[:, k * k * C:].float().abs().max() if ld > k * k * C else 0) == 0
+        # col2im is the adjoint: <im2col(x), d> == <x, col2im(d)> exactly on small integers
+        d = torch.randint(-3, 4, (B * Ho * Wo, ld), generator=g).float()
+        d[:, k * k * C:] = 0
+        dx = torch.empty((B * H * W, C), dtype=T16, device="cuda")
+        pkg._lib.check(lib.mh_col2im_nhwc(d.to(T16).cuda().data_ptr(), dx.data_ptr(), B, H, W, C, k, k, s, p, ld, st), "col2im")
+        dref = F.fold(d[:, :k * k * C].view(B, Ho * Wo, k * k, C).permute(0, 3, 2, 1).reshape(B, C * k * k, Ho * Wo), (H, W), k, padding=p, stride=s)
+        assert torch.equal(_nchw(dx, B, H, W), dref)
+    # max pool 3x3 / 2 / pad 1 and its backward
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    xr = torch.randn((B, C, H, W), generator=g).to(T16).float().requires_grad_(True)
+    y = torch.empty((B * Ho * Wo, C), dtype=T16, device="cuda")
+    arg = torch.empty((B * Ho * Wo, C), dtype=torch.uint8, device="cuda")
+    pkg._lib.check(lib.mh_maxpool_fwd(_nhwc(xr.detach(), T16).data_ptr(), y.data_ptr(), arg.data_ptr(), B, H, W, C, 3, 2, 1, st), "maxpool")
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(_nchw(y, B, Ho, Wo), yr.detach())
+    dy = torch.randint(-3, 4, (B, C, Ho, Wo), generator=g).float()
+    yr.backward(dy)
+    dx = torch.empty((B * H * W, C), dtype=T16, device="cuda")
+    pkg._lib.check(lib.mh_maxpool_bwd(_nhwc(dy, T16).data_ptr(), arg.data_ptr(), dx.data_ptr(), B, H, W, C, 3, 2, 1, st), "maxpool_bwd")
+    assert torch.equal(_nchw(dx, B, H, W), xr.grad)
+
+
+def test_batchnorm2d_train_fwd_bwd_matches_torch(pkg):
+    lib = pkg._lib.load("fp16")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(2)
+    for (B, C, H, W, relu, res) in ((4, 64, 14, 14, True, False), (3, 256, 7, 7, True, True), (2, 24, 5, 5, False, False)):
+        M = B * H * W
+        x = (torch.randn((B, C, H, W), generator=g) * 1.5 + 0.3).to(F16).float()
+        r = torch.randn((B, C, H, W), generator=g).to(F16).float()
+        gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+        rm, rv = torch.zeros(C), torch.ones(C)
+        xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        y = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+        if res:
+            y = y + rr
+        if relu:
+            y = F.relu(y)
+        dy = torch.randn((B, C, H, W), generator=g).to(F16).float()
+        y.backward(dy)
+        xd, rd = _nhwc(x, F16), _nhwc(r, F16)
+        yd = torch.empty_like(xd)
+        sm, sr = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        ws = torch.empty(((M + 127) // 128 * 2 + 2) * C, device="cuda")
+        pkg._lib.check(lib.mh_bn2d_fwd(xd.data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(), rmd.data_ptr(), rvd.data_ptr(),
+                                       rd.data_ptr() if res else None, yd.data_ptr(), sm.data_ptr(), sr.data_ptr(), ws.data_ptr(), M, C, 1e-5,
+                                       0.1, 1, int(relu), st), "bn2d_fwd")
+        assert float((_nchw(yd, B, H, W) - y.detach()).abs().max()) < 4e-3
+        assert float((rmd.cpu() - rm).abs().max()) < 1e-5 and float((rvd.cpu() - rv).abs().max()) < 2e-5
+        dxd, dresd = torch.empty_like(xd), torch.empty_like(xd)
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        pkg._lib.check(lib.mh_bn2d_bwd(_nhwc(dy, F16).data_ptr(), xd.data_ptr(), yd.data_ptr(), gamma.cuda().data_ptr(), sm.data_ptr(),
+                                       sr.data_ptr(), dxd.data_ptr(), dresd.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), M, C,
+                                       int(relu), 1.0, st), "bn2d_bwd")
+        scale = float(xr.grad.abs().max())
+        assert float((_nchw(dxd, B, H, W) - xr.grad).abs().max()) < 6e-3 * scale + 1e-3
+        assert float((dg.cpu() - gr.grad).abs().max()) < 5e-3 * float(gr.grad.abs().max()) + 1e-2
+        assert float((db.cpu() - br.grad).abs().max()) < 5e-3 * float(br.grad.abs().max()) + 1e-2
+        if res:
+            assert float((_nchw(dresd, B, H, W) - rr.grad).abs().max()) < 2e-3
+
+
+def _load_oracle_params(net, p):
+    sd = net.state_dict()
+    for k, v in p.items():
+        sd[k].copy_(v)
+
+
+@pytest.mark.parametrize("dtype,ftol,gtol", [("fp16", 4e-3, 3e-2), ("bf16", 3e-2, 1.2e-1)])
+def test_resnet_tower_forward_backward_matches_the_oracle(pkg, dtype, ftol, gtol):
+    """A four-stage bottleneck tower at the true widths (64..2048 channels, every kernel shape of ResNet-50: 7x7/2 stem, max
+    pool, 1x1, 3x3 stride 1 and 2, strided 1x1 downsample, train-mode BatchNorm + residual + ReLU), one block per stage plus
+    a second block in stage 1 (the identity shortcut): pooled features and every parameter gradient against the CPU oracle."""
+    from oracle import resnet_oracle as R
+    layers = (2, 1, 1, 1)
+    p = R.resnet_init(layers, 64, 10, seed=5)
+    net = pkg.ResNet50(num_classes=10, compute_dtype=dtype, layers=layers)
+    _load_oracle_params(net, p)
+    net.cuda().train()
+    g = torch.Generator().manual_seed(6)
+    image = torch.randn((4, 3, 64, 64), generator=g)
+    labels = torch.tensor([1, 7, 3, 3])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    st = R.new_bn_state(p)
+    ref_logits = R.resnet_forward(leaves, st, image, layers, training=True)
+    ref_loss = F.cross_entropy(ref_logits, labels)
+    ref_loss.backward()
+    logits = net(image.cuda())
+    loss = pkg.CrossEntropyLoss()(logits, labels.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    err = float((logits.detach().float().cpu() - ref_logits.detach()).abs().max())
+    print(f"[resnet {dtype}] max |logit - oracle| = {err:.3e}, loss {float(loss):.5f} vs {float(ref_loss):.5f}")
+    assert err < ftol * max(1.0, float(ref_logits.abs().max()))
+    worst = ("", 0.0)
+    for name, prm in net.named_parameters():
+        ref = leaves[name].grad
+        got = prm.grad.float().cpu()
+        rel = float((got - ref).norm()) / (float(ref.norm()) + 1e-12)
+        if rel > worst[1]:
+            worst = (name, rel)
+        assert rel < gtol, f"{name}: relative gradient error {rel:.3e}"
+    print(f"[resnet {dtype}] worst relative gradient error {worst[1]:.3e} ({worst[0]})")
+    sd = net.state_dict()
+    assert float((sd["bn1.running_mean"].cpu() - st["bn1.running_mean"]).abs().max()) < 2e-3
+    assert float((sd["layer4.0.bn3.running_var"].cpu() - st["layer4.0.bn3.running_var"]).abs().max()) < 2e-2
+    assert int(sd["bn1.num_batches_tracked"]) == 1
+
+
+def test_resnet50_state_dict_is_torchvisions(pkg):
+    net = pkg.ResNet50()
+    sd = net.state_dict()
+    assert sum(p.numel() for p in net.parameters()) == 25_557_032          # torchvision resnet50
+    assert len(sd) == 320 and "layer3.5.conv3.weight" in sd and "layer2.0.downsample.1.running_var" in sd and "fc.bias" in sd
+    assert tuple(sd["layer4.0.conv2.weight"].shape) == (512, 512, 3, 3) and net.layer4[0].conv2.stride == (2, 2)
+
+
+def test_resnet_classifier_trainer_protocol_and_fused_adam(pkg):
+    """Subtask-2B surface: model(pixel_values=..., labels=...) -> (loss, logits); a few steps with the fused Adam over the
+    flattened parameters lower the loss on a fixed batch."""
+    torch.manual_seed(0)
+    model = pkg.ResNetClassifier(num_labels=2, compute_dtype="fp16", layers=(1, 1, 1, 1)).cuda()
+    pkg.flatten_parameters(model)
+    model.train()
+    g = torch.Generator().manual_seed(3)
+    batch = {"pixel_values": torch.randn((8, 3, 64, 64), generator=g).cuda(), "labels": torch.tensor([0, 1, 1, 0, 1, 0, 0, 1]).cuda()}
+    opt = pkg.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss, logits = model(**batch)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert logits.shape == (8, 2) and model(pixel_values=batch["pixel_values"]).shape == (8, 2)
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
