@@ -105,9 +105,10 @@ class _BN:
         m = self.mod
         y = torch.empty_like(x)
         sm, sr = torch.empty(self.C, dtype=F32, device=x.device), torch.empty(self.C, dtype=F32, device=x.device)
+        ws = self._ws(M, x.device)
         check(lib.mh_bn2d_fwd(x.data_ptr(), m.weight.data_ptr(), m.bias.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr(),
                               None if residual is None else residual.data_ptr(), y.data_ptr(), sm.data_ptr(), sr.data_ptr(),
-                              self._ws(M, x.device).data_ptr(), M, self.C, float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+                              ws.data_ptr(), M, self.C, float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
                               int(training), int(relu), _stream()), "mh_bn2d_fwd")
         if training:
             m.num_batches_tracked += 1
@@ -118,9 +119,10 @@ class _BN:
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_dres else None
         dg, db = torch.empty_like(m.weight), torch.empty_like(m.bias)
+        ws = self._ws(M, x.device)
         check(lib.mh_bn2d_bwd(dy.data_ptr(), x.data_ptr(), None if y is None else y.data_ptr(), m.weight.data_ptr(), sm.data_ptr(),
                               sr.data_ptr(), dx.data_ptr(), None if dres is None else dres.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                              self._ws(M, x.device).data_ptr(), M, self.C, int(relu), 1.0 / gscale, _stream()), "mh_bn2d_bwd")
+                              ws.data_ptr(), M, self.C, int(relu), 1.0 / gscale, _stream()), "mh_bn2d_bwd")
         grads[id(m.weight)], grads[id(m.bias)] = dg, db
         return dx, dres
 
@@ -207,7 +209,8 @@ class ResNet50(nn.Module):
             raise ValueError("ResNet50 expects 3-channel images")
         tape = {"B": B, "ops": []}
         x = torch.empty((B * H * W, 8), dtype=T16, device=image.device)
-        check(lib.mh_nchw_to_nhwc(image.to(F32).contiguous().data_ptr(), x.data_ptr(), B, 3, H, W, 8, _stream()), "mh_nchw_to_nhwc")
+        img32 = image.to(F32).contiguous()      # named: a temporary would be freed (and its block re-used) before the launch
+        check(lib.mh_nchw_to_nhwc(img32.data_ptr(), x.data_ptr(), B, 3, H, W, 8, _stream()), "mh_nchw_to_nhwc")
 
         def conv_bn(conv_mod, bn_mod, xin, h, w, residual=None, relu=True, cin_pad=None):
             cv, bn = _Conv(conv_mod, cin_pad), _BN(bn_mod)
@@ -248,7 +251,8 @@ class ResNet50(nn.Module):
         Cf = self.feature_dim
         dev = d_pooled.device
         dx = torch.empty((B * h * w, Cf), dtype=T16, device=dev)
-        check(lib.mh_avgpool_bwd(d_pooled.to(F32).contiguous().data_ptr(), dx.data_ptr(), B, h * w, Cf, self.gscale, _stream()), "mh_avgpool_bwd")
+        dp32 = d_pooled.to(F32).contiguous()
+        check(lib.mh_avgpool_bwd(dp32.data_ptr(), dx.data_ptr(), B, h * w, Cf, self.gscale, _stream()), "mh_avgpool_bwd")
         ops_ = tape["ops"]
         i = len(ops_) - 1
         grads = {}      # id(parameter) -> gradient tensor (returned to autograd, which accumulates into .grad)

@@ -74,27 +74,49 @@ def new_bn_state(p: Params) -> Params:
     return st
 
 
+class _RoundSTE(torch.autograd.Function):
+    """x -> x rounded to a 16-bit storage type and back (straight-through gradient): the storage points of the HIP tower."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return x.to(dtype).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 def _bn(x, p, st, pfx, training):
     return F.batch_norm(x, st[pfx + ".running_mean"], st[pfx + ".running_var"], p[pfx + ".weight"], p[pfx + ".bias"], training, 0.1, 1e-5)
 
 
-def resnet_features(p: Params, st: Params, image: torch.Tensor, layers=(3, 4, 6, 3), training: bool = True) -> torch.Tensor:
-    """-> pooled features [B, 8 * 4 * width]; ``st`` (running statistics) is updated in place in training mode."""
-    x = F.relu(_bn(F.conv2d(image, p["conv1.weight"], stride=2, padding=3), p, st, "bn1", training))
+def resnet_features(p: Params, st: Params, image: torch.Tensor, layers=(3, 4, 6, 3), training: bool = True,
+                    storage=None) -> torch.Tensor:
+    """-> pooled features [B, 8 * 4 * width]; ``st`` (running statistics) is updated in place in training mode.
+    ``storage`` = torch.float16 / torch.bfloat16 inserts the 16-bit STORAGE rounding of the HIP tower (weights, conv inputs and
+    outputs, BatchNorm(+residual)(+ReLU) outputs; all arithmetic stays fp32): a random-init ResNet's gradients move by 10-50 %
+    under that rounding alone (train-mode BatchNorm + ReLU masks), so gradient parity of the 16-bit tower is checked against
+    this variant, forward parity against the plain fp32 one."""
+    q = (lambda t: _RoundSTE.apply(t, storage)) if storage is not None else (lambda t: t)
+
+    def conv(x, w, **kw):
+        return q(F.conv2d(q(x), q(w), **kw))
+
+    x = q(F.relu(_bn(conv(image, p["conv1.weight"], stride=2, padding=3), p, st, "bn1", training)))
     x = F.max_pool2d(x, 3, 2, 1)
     for li, (n, stride) in enumerate(zip(layers, (1, 2, 2, 2)), 1):
         for bi in range(n):
             L = f"layer{li}.{bi}."
             s = stride if bi == 0 else 1
-            o = F.relu(_bn(F.conv2d(x, p[L + "conv1.weight"]), p, st, L + "bn1", training))
-            o = F.relu(_bn(F.conv2d(o, p[L + "conv2.weight"], stride=s, padding=1), p, st, L + "bn2", training))
-            o = _bn(F.conv2d(o, p[L + "conv3.weight"]), p, st, L + "bn3", training)
+            o = q(F.relu(_bn(conv(x, p[L + "conv1.weight"]), p, st, L + "bn1", training)))
+            o = q(F.relu(_bn(conv(o, p[L + "conv2.weight"], stride=s, padding=1), p, st, L + "bn2", training)))
+            o = _bn(conv(o, p[L + "conv3.weight"]), p, st, L + "bn3", training)
             idn = x
             if (L + "downsample.0.weight") in p:
-                idn = _bn(F.conv2d(x, p[L + "downsample.0.weight"], stride=s), p, st, L + "downsample.1", training)
-            x = F.relu(o + idn)
+                idn = q(_bn(conv(x, p[L + "downsample.0.weight"], stride=s), p, st, L + "downsample.1", training))
+            x = q(F.relu(o + idn))
     return x.mean(dim=(2, 3))
 
 
-def resnet_forward(p: Params, st: Params, image: torch.Tensor, layers=(3, 4, 6, 3), training: bool = True) -> torch.Tensor:
-    return F.linear(resnet_features(p, st, image, layers, training), p["fc.weight"], p["fc.bias"])
+def resnet_forward(p: Params, st: Params, image: torch.Tensor, layers=(3, 4, 6, 3), training: bool = True, storage=None) -> torch.Tensor:
+    return F.linear(resnet_features(p, st, image, layers, training, storage), p["fc.weight"], p["fc.bias"])
