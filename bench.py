@@ -40,9 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="memes per GPU")
     ap.add_argument("--seq", type=int, default=0, help="text tokens (default: 128 for config 3, 256 for config 5)")
-    ap.add_argument("--config", type=int, choices=(3, 5), default=3,
+    ap.add_argument("--config", type=int, choices=(2, 3, 5), default=3,
                     help="BASELINE.json configuration: 3 = ViT-B/16 + BERT-base (the headline metric), "
-                         "5 = CLIP ViT-L/14@336 + BERT-large, seq 256")
+                         "5 = CLIP ViT-L/14@336 + BERT-large, seq 256, 2 = Subtask-2B ResNet-50 image-only (single GPU)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -154,8 +154,70 @@ def timed_variant(pkg, args, device, dtype=None, full_masks=None, dense_text=Non
     return args.batch * args.steps / dt, dt / args.steps * 1e3
 
 
+def bench_config2(args):
+    """BASELINE.json configs[1]: Subtask 2B, ResNet-50 image-only, 224x224 synthetic, batch 32, one MI355X: images/s of one
+    fine-tune step (forward + cross-entropy + backward + fused Adam) through the Trainer-protocol module, replayed as a hipGraph."""
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    import multimodal_propaganda_meme_classification_amd as pkg
+    model = pkg.ResNetClassifier(num_labels=2, compute_dtype=args.dtype).to(device)
+    pkg.flatten_parameters(model)
+    model.train()
+    opt = pkg.Adam(model.parameters(), lr=2e-5)
+    g = torch.Generator().manual_seed(1234)
+    image = torch.randn((args.batch, 3, 224, 224), generator=g).to(device)
+    labels = (torch.rand((args.batch,), generator=g) < 0.28).long().to(device)
+    loss_buf = torch.zeros((), device=device)
+
+    def one_step():
+        opt.zero_grad()
+        loss, _ = model(pixel_values=image, labels=labels)
+        loss.backward()
+        opt.step()
+        loss_buf.copy_(loss.detach())
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            one_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one_step()
+    run = graph.replay if graph is not None else one_step
+    for _ in range(max(args.warmup, 1)):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    value = args.batch * args.steps / dt
+    flop_per_image = 24.5e9          # fwd + bwd, BASELINE.md section 2
+    out = {"metric": "images/sec (fine-tune step) ResNet-50 224x224 bs=32 (BASELINE configs[1], Subtask 2B)", "value": round(value, 2),
+           "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"Subtask-2B fine-tune step: torchvision-topology ResNet-50 (25.6 M parameters), 3x224x224, batch {args.batch}, "
+                                  "fwd+CE+bwd+Adam, train-mode BatchNorm, random-init weights; convolutions = MFMA GEMM over explicit NHWC im2col",
+                      "global_batch": args.batch, "image": "3x224x224", "parallelism": "dp1",
+                      "launch": "eager" if args.no_graph else "hipGraph", "final_loss": round(float(loss_buf), 5)},
+           "roofline": {"bound": "mfma", "kernel": "whole step (conv GEMMs + im2col / BatchNorm passes)",
+                        "achieved": round(flop_per_image * value / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(flop_per_image * value / (MFMA_PEAK_TFLOPS * 1e12), 4), "traffic": None}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.config == 2:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+        return bench_config2(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

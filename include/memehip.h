@@ -87,10 +87,18 @@ typedef struct MhGemmProblem {
     const int32_t* rows_dev;  /* device int32 or NULL: live token rows of a PACKED (padding-free) operand, read at launch
                                  time.  Clamps M (a_kmajor==0: tiles past it exit) or the contraction K (a_kmajor==1). */
     const int32_t* drop_rows; /* device int32 [M] or NULL: row m's index in the unpacked tensor (dropout mask index) */
+    int32_t ksplit;           /* > 1: split-K for few-tile / long-contraction problems (conv weight gradients: K = B*H*W).  The
+                                 contraction is cut into exactly `ksplit` chunks of ceil(K / ksplit) rounded up to 64 (the call
+                                 returns MH_ESHAPE when that leaves a chunk empty: use mh_gemm_ksplit_for); chunk s writes
+                                 alpha * partial to the f32 slab C + s*M*ldc; no epilogue operands; sum the slabs with
+                                 mh_colsum_partials_f32(n_part = ksplit, D = M*ldc).  0 / 1 = off. */
+    int32_t reserved_;
 } MhGemmProblem;
 
 int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems, int a_kmajor,
                          int b_kmajor, mh_stream_t stream);
+/* a split count <= want for which every chunk of ceil(K/ksplit) rounded up to 64 is non-empty (1 when K is short) */
+int mh_gemm_ksplit_for(int K, int want);
 /* kernel variant for A/B measurements in one process (all 128x128x64 tiles unless noted):
  * 0 = 4 waves, tiles staged global->VGPR->LDS; 1 = 4 waves, LDS-DMA (buffer_load ... lds);
  * 2 = 256x128 tile, 8 waves, 3-stage LDS-DMA ring with counted vmcnt; 3 = that ring with the two wave

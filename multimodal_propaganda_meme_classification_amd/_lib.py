@@ -33,7 +33,7 @@ class MhGemmProblem(C.Structure):
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
                 ("flags", C.c_int32), ("alpha", C.c_float),
                 ("drop_rng", c_void_p), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
-                ("rows_dev", c_void_p), ("drop_rows", c_void_p)]
+                ("rows_dev", c_void_p), ("drop_rows", c_void_p), ("ksplit", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class MhColsumJob(C.Structure):
@@ -48,7 +48,7 @@ class MhLnFwdJob(C.Structure):
 class MhLnBwdJob(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("dy", "x", "gamma", "mean", "rstd", "dx_add", "dx", "part", "dx_drop", "rng")] + \
                [("n_part", C.c_int32), ("rows", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
-                ("rows_dev", c_void_p), ("drop_rows", c_void_p)]
+                ("rows_dev", c_void_p), ("drop_rows", c_void_p), ("ksplit", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class MhAttnProblem(C.Structure):
@@ -80,6 +80,7 @@ class MhHeadGrads(C.Structure):
 _PROTOS = {
     "mh_gemm_bf16_grouped": [C.POINTER(MhGemmProblem), c_int, c_int, c_int, c_void_p],
     "mh_gemm_set_variant": [c_int],
+    "mh_gemm_ksplit_for": [c_int, c_int],
     "mh_layernorm_fwd": [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p],
     "mh_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_layernorm_fwd_grouped": [C.POINTER(MhLnFwdJob), c_int, c_int, c_void_p],

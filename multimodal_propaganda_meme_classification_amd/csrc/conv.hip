@@ -141,17 +141,26 @@ __global__ __launch_bounds__(256) void bn2d_stats_kernel(const h16* __restrict__
     }
     bn_block_reduce(s, q, part, blk, C, t < c8 ? t : C, ty, nty, c8w);
 }
-// finish: mean / rstd (biased variance), running statistics (unbiased), one thread per channel
+MH_DEV double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// finish: mean / rstd (biased variance), running statistics (unbiased); one WAVE per channel (the lanes split the row
+// blocks: a thread per channel walking ~800 partials was 7 % of the ResNet step)
 __global__ __launch_bounds__(256) void bn2d_finish_kernel(const float* __restrict__ part, int nblk, int M, int C, float eps,
                                                           float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s += (double)part[((size_t)b * 2) * C + c];
         q += (double)part[((size_t)b * 2 + 1) * C + c];
     }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane != 0) return;
     const double mu = s / M;
     double var = q / M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -224,13 +233,16 @@ __global__ __launch_bounds__(256) void bn2d_bwd_stats_kernel(const h16* __restri
 __global__ __launch_bounds__(256) void bn2d_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, float scale,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ sums /*[2][C]: sum dy', sum dy' xhat*/) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s += (double)part[((size_t)b * 2) * C + c];
         q += (double)part[((size_t)b * 2 + 1) * C + c];
     }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (lane != 0) return;
     sums[c] = (float)s;
     sums[C + c] = (float)q;
     if (dbeta) dbeta[c] = (float)s * scale;
@@ -417,7 +429,7 @@ extern "C" int mh_bn2d_fwd(const void* x, const float* gamma, const float* beta,
         if (!workspace) return MH_EINVAL;
         const int nblk = (M + BN_RPB - 1) / BN_RPB;
         hipLaunchKernelGGL(bn2d_stats_kernel, dim3((C / 8 + 255) / 256, nblk), dim3(256), 0, s, (const h16*)x, workspace, M, C);
-        hipLaunchKernelGGL(bn2d_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, M, C, eps, momentum, save_mean,
+        hipLaunchKernelGGL(bn2d_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, M, C, eps, momentum, save_mean,
                            save_rstd, running_mean, running_var);
     } else {
         if (!running_mean || !running_var) return MH_EINVAL;
@@ -447,7 +459,7 @@ extern "C" int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const f
     float* sums = workspace + (size_t)nblk * 2 * C;
     hipLaunchKernelGGL(bn2d_bwd_stats_kernel, dim3((C / 8 + 255) / 256, nblk), dim3(256), 0, s, (const h16*)dy, (const h16*)x,
                        (const h16*)y, save_mean, save_rstd, workspace, M, C, relu);
-    hipLaunchKernelGGL(bn2d_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, nblk, C, scale, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn2d_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, scale, dgamma, dbeta, sums);
     hipLaunchKernelGGL(bn2d_bwd_apply_kernel, dim3(grid1((size_t)M * (C / 8))), dim3(256), 0, s, (const h16*)dy, (const h16*)x,
                        (const h16*)y, save_mean, save_rstd, gamma, sums, (h16*)dx, (h16*)dres, (size_t)M, C, relu);
     return mh_launch_status();

@@ -27,7 +27,7 @@ struct DevProblem {
     int tiles_n;
     int tile_start;
     int tiles_m;
-    int pad_;
+    int kchunk;       // split-K (MhGemmProblem.ksplit > 1): contraction elements per split, a multiple of BK; 0 = no split
 };
 struct GemmGroup {
     int n;
@@ -293,7 +293,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
         if (i < g.n && t >= g.d[i].tile_start) pi = i;
     const MhGemmProblem& P = g.d[pi].p;
-    const int lt = t - g.d[pi].tile_start;
+    int lt = t - g.d[pi].tile_start;
+    // split-K: the problem's tiles are replicated ksplit times; split s contracts over [s * kchunk, (s+1) * kchunk) and
+    // writes its own f32 partial output at C + s * split_stride (summed by the caller: mh_colsum_partials_f32)
+    const int kchunk = g.d[pi].kchunk;
+    int ksplit_idx = 0;
+    if (kchunk > 0) {
+        const int per = g.d[pi].tiles_m * g.d[pi].tiles_n;
+        ksplit_idx = lt / per;
+        lt -= ksplit_idx * per;
+    }
     int tm, tn;
     tile_coords(g.d[pi], g.group_m, lt, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -309,6 +318,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
             K = min(K, live);
         }
     }
+    const int kbeg = ksplit_idx * kchunk;                       // 0 without split-K
+    const int kend = kchunk > 0 ? min(K, kbeg + kchunk) : K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / NWN) * (NI * 16), wn0 = (wave % NWN) * (NJ * 16);
 
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (h16)1.0f;
 
-    const int nk = (K + BK - 1) / BK;
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
     auto compute = [&](const char* cur) {
         const char* la = cur;
         const char* lb = cur + BM * BK * 2;
@@ -356,15 +367,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
         }
     };
     if (DMA) {
-        dma_tile<LA, 16 / NW>(ra, P.lda, m0, 0, wave, lane, smem);
-        dma_tile<LB, 16 / NW>(rb, P.ldb, n0, 0, wave, lane, smem + BM * BK * 2);
+        dma_tile<LA, 16 / NW>(ra, P.lda, m0, kbeg, wave, lane, smem);
+        dma_tile<LB, 16 / NW>(rb, P.ldb, n0, kbeg, wave, lane, smem + BM * BK * 2);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             char* cur = smem + (kt & 1) * STAGE_BYTES;
             char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
             if (kt + 1 < nk) {
-                dma_tile<LA, 16 / NW>(ra, P.lda, m0, (kt + 1) * BK, wave, lane, nxt);
-                dma_tile<LB, 16 / NW>(rb, P.ldb, n0, (kt + 1) * BK, wave, lane, nxt + BM * BK * 2);
+                dma_tile<LA, 16 / NW>(ra, P.lda, m0, kbeg + (kt + 1) * BK, wave, lane, nxt);
+                dma_tile<LB, 16 / NW>(rb, P.ldb, n0, kbeg + (kt + 1) * BK, wave, lane, nxt + BM * BK * 2);
             }
             compute(cur);
             __syncthreads();
@@ -405,6 +416,31 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     }
     // (issuing these under the last K tile's MFMAs instead was measured 20 % slower: the extra live registers
     //  across the main loop cost more than the remaining exposed latency)
+    if (kchunk > 0) {       // split-K partial: plain f32 store of alpha * acc into this split's slab, no epilogue operands
+        __syncthreads();
+        float* cs = (float*)smem;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cs[cs_index(wm0 + i * 16 + (lane >> 4) * 4 + r, wn0 + j * 16 + (lane & 15))] = acc[i][j][r];
+        __syncthreads();
+        float* slab = (float*)P.C + (size_t)ksplit_idx * (size_t)P.M * (size_t)P.ldc;
+        const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
+        for (int q = tid; q < BM * 16; q += NW * 64) {
+            const int row = q >> 4, cc = q & 15;
+            const int gm = m0 + row, gn = n0 + cc * 8;
+            if (gm >= M || gn >= N) continue;
+            const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
+            const f32x4 x1 = *(const f32x4*)(cs + cs_index(row, cc * 8 + 4));
+            float* c = slab + (size_t)gm * P.ldc + gn;
+            *(f32x4*)c = x0 * alpha;
+            *(f32x4*)(c + 4) = x1 * alpha;
+        }
+        return;
+    }
     EpiPrefetch<BM, NW * 64> pf;
     if (PREF) epilogue_prefetch<BM, NW * 64>(P, m0, n0, tid, M, pf);
     float* cs = (float*)smem;  // [128][128] f32
@@ -1184,7 +1220,18 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         g.d[i].tiles_n = (p.N + tile_n - 1) / tile_n;
         g.d[i].tile_start = total;
         g.d[i].tiles_m = (p.M + tile_m - 1) / tile_m;
-        total += g.d[i].tiles_m * g.d[i].tiles_n;
+        g.d[i].kchunk = 0;
+        int splits = 1;
+        if (p.ksplit > 1) {       // split-K: f32 output slabs [ksplit][M][ldc], default kernel variant only, no fused epilogue
+            if (g_variant != 4 || wide || !(p.flags & MH_GEMM_OUT_F32) || (p.flags & (MH_GEMM_ACCUM | MH_GEMM_GELU)) || p.bias ||
+                p.residual || p.aux || p.mul || p.rowsum || p.rows_dev || p.drop_rng)
+                return MH_EINVAL;
+            const int kc = ((p.K + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
+            g.d[i].kchunk = kc;
+            splits = (p.K + kc - 1) / kc;          // splits that actually hold rows (<= ksplit); the caller zero-fills the rest
+            if (splits != p.ksplit) return MH_ESHAPE;
+        }
+        total += g.d[i].tiles_m * g.d[i].tiles_n * splits;
     }
     g.total_tiles = total;
     static int group_m = -1;
@@ -1200,6 +1247,14 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     if (!a_kmajor && b_kmajor) return launch<0, 1>(g, s);
     if (a_kmajor && b_kmajor) return launch<1, 1>(g, s);
     return MH_EINVAL;  // (1,0) is not needed by the path
+}
+
+extern "C" int mh_gemm_ksplit_for(int K, int want) {
+    for (int sp = want; sp > 1; --sp) {
+        const int kc = ((K + sp - 1) / sp + BK - 1) / BK * BK;
+        if ((K + kc - 1) / kc == sp) return sp;
+    }
+    return 1;
 }
 
 // experiment knob (A/B in one process): 0 = register-staged tiles, 1 = LDS-DMA staged tiles

@@ -58,11 +58,12 @@ class Gemm:
     """One problem of a grouped launch (see MhGemmProblem in include/memehip.h)."""
 
     __slots__ = ("A", "B", "C", "bias", "residual", "aux", "mul", "rowsum", "M", "N", "K", "lda", "ldb", "ldc",
-                 "flags", "alpha", "drop", "rows_dev", "drop_rows")
+                 "flags", "alpha", "drop", "rows_dev", "drop_rows", "ksplit")
 
     def __init__(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, residual=None, aux=None, mul=None,
-                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None, rows_dev=None, drop_rows=None, quick=False):
+                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None, rows_dev=None, drop_rows=None, quick=False, ksplit=0):
         self.alpha = alpha
+        self.ksplit = int(ksplit)      # > 1: split-K, C holds [ksplit][M][ldc] f32 slabs (see MhGemmProblem.ksplit)
         self.rows_dev, self.drop_rows = rows_dev, drop_rows     # packed token rows: device int32 [1] / int32 [M]
         self.drop = drop            # (rng u32[4] device tensor, p, site id) or None
         self.A, self.B, self.C = A, B, C
@@ -117,6 +118,10 @@ def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
         a_need = _min_elems(g.K, g.lda, g.M) if a_kmajor else _min_elems(g.M, g.lda, g.K)
         b_need = _min_elems(g.K, g.ldb, g.N) if b_kmajor else _min_elems(g.N, g.ldb, g.K)
         c_need = _min_elems(g.M, g.ldc, g.N)
+        if g.ksplit > 1:
+            c_need = (g.ksplit - 1) * g.M * g.ldc + c_need        # [ksplit][M][ldc] f32 slabs
+            if g.C.dtype != F32:
+                raise TypeError("split-K needs an f32 output")
         if g.A.numel() < a_need or g.B.numel() < b_need or g.C.numel() < c_need:
             raise ValueError(f"gemm problem {i}: operand smaller than M/N/K/ld imply")
         for nm, t, dt, need in (("bias", g.bias, F32, g.N), ("residual", g.residual, BF16, c_need),
@@ -137,7 +142,27 @@ def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
             if not (g.rows_dev.is_cuda and g.rows_dev.dtype == torch.int32):
                 raise TypeError("rows_dev must be a device int32 tensor")
             a.rows_dev = _p(g.rows_dev)
+        a.ksplit = g.ksplit
     check(_L(problems[0].A).mh_gemm_bf16_grouped(arr, n, int(a_kmajor), int(b_kmajor), _stream()), "mh_gemm_bf16_grouped")
+
+
+def wgrad_splitk(dy, x, M, N, K, lda, ldb, alpha=1.0, target_tiles: int = 1024, max_split: int = 64):
+    """dW[M][N] (f32) = alpha * dy^T x over a long contraction K with few output tiles (conv weight gradients: K = B*H*W,
+    M = Cout, N = kh*kw*Cin): split-K inside the grouped GEMM + a fixed-order sum of the slabs (reproducible, no atomics)."""
+    lib = _L(dy)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    want = max(1, min(max_split, -(-target_tiles // tiles), K // 256))
+    sp = lib.mh_gemm_ksplit_for(int(K), int(want))
+    out = torch.empty((M, N), dtype=F32, device=dy.device)
+    if sp <= 1:
+        gemm_grouped([Gemm(dy, x, out, M, N, K, lda, ldb, N, alpha=alpha)], True, True)
+        return out
+    slabs = torch.empty((sp, M, N), dtype=F32, device=dy.device)
+    gemm_grouped([Gemm(dy, x, slabs, M, N, K, lda, ldb, N, alpha=alpha, ksplit=sp)], True, True)
+    jobs = (MhColsumJob * 1)()
+    jobs[0].part, jobs[0].out0, jobs[0].out1 = _p(slabs), _p(out), None
+    check(_lib.load().mh_colsum_partials_f32(jobs, 1, sp, M * N, 1.0, _stream()), "mh_colsum_partials_f32")
+    return out
 
 
 def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False, drop=None, quick=False):

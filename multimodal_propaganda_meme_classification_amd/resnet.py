@@ -75,8 +75,7 @@ class _Conv:
         """dy [M, cout] 16-bit -> dx [B*H*W, cp] 16-bit (or None); the weight gradient goes to grads[id(weight)]"""
         M = B * Ho * Wo
         dev = dy.device
-        gk = torch.empty((self.cout, self.ldk), dtype=F32, device=dev)
-        ops.gemm_grouped([ops.Gemm(dy, A, gk, self.cout, self.ldk, M, self.cout, self.ldk, self.ldk, alpha=1.0 / gscale)], True, True)
+        gk = ops.wgrad_splitk(dy, A, self.cout, self.ldk, M, self.cout, self.ldk, alpha=1.0 / gscale)
         g = torch.empty_like(self.mod.weight)
         check(lib.mh_conv_weight_unpack(gk.data_ptr(), g.data_ptr(), self.cout, self.cin, self.kh, self.kw, self.cp, self.ldk, 1.0,
                                         _stream()), "mh_conv_weight_unpack")

@@ -402,3 +402,15 @@ def test_adam_sumsq_cast(ops):
     hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01, 1 / (1 - 0.9), 1 / math.sqrt(1 - 0.999), 1.0]).to(dev())
     ops.adam_step(p, m, v, gd, None, 0, hyper, decoupled=True, gnorm_sq=nrm, max_norm=1.0)
     close(p, ref2.detach(), 1e-6, 1e-7, "adamw + clip")
+
+
+def test_gemm_split_k_weight_gradient(ops):
+    """Split-K inside the grouped GEMM (conv weight gradients: few output tiles, contraction = B*H*W): exact on small integers,
+    equal to the unsplit launch, ragged contraction lengths."""
+    for (M, N, K) in ((64, 64, 5000), (64, 576, 12544), (256, 64, 777)):
+        dy, x = ints(K, M, seed=K), ints(K, N, seed=K + 1)
+        want = dy.float().t() @ x.float()
+        got = ops.wgrad_splitk(dy, x, M, N, K, M, N)
+        assert torch.equal(got, want), (M, N, K)
+        got2 = ops.wgrad_splitk(dy, x, M, N, K, M, N, alpha=0.5, target_tiles=8)
+        assert torch.equal(got2, 0.5 * want)
