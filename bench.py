@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-overlap-opt", action="store_true", help="A/B: whole Adam update after the backward")
     ap.add_argument("--force-ddp", action="store_true",
                     help="debug: run the data-parallel code path (segmented graphs, RCCL all-reduce) on a 1-rank group")
+    ap.add_argument("--ddp-compress", choices=("none", "bf16"), default="none",
+                    help="N > 1: wire format of the gradient exchange: fp32 all-reduce (default) or bf16 with fp32 accumulation on "
+                         "receipt (all-to-all + all-gather, half the bytes)")
     ap.add_argument("--dense-text", action="store_true",
                     help="A/B: compute every padded text position like the reference does (default: padding-free text tower)")
     ap.add_argument("--full-masks", action="store_true", help="all-ones attention masks (SURVEY 8d's second input variant)")
@@ -256,7 +259,7 @@ def main():
     if world > 1 or args.force_ddp:
         ddp.broadcast_parameters(model.flat_params)
         model.mark_weights_changed()
-        reducer = ddp.GradientReducer(model.flat_grads)
+        reducer = ddp.GradientReducer(model.flat_grads, compress=None if args.ddp_compress == "none" else args.ddp_compress)
     opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)
     step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer,
                            overlap_wgrad=not args.no_overlap_wgrad, overlap_optimizer=not args.no_overlap_opt)

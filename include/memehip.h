@@ -463,6 +463,9 @@ int mh_adam_step_rows(float* p, float* m, float* v, const float* g,
                       const float* gnorm_sq, float max_norm, mh_stream_t stream);
 int mh_cast_f32_bf16(const float* src, void* dst, int64_t n, mh_stream_t stream);
 int mh_cast_bf16_f32(const void* src, float* dst, int64_t n, mh_stream_t stream);
+/* Data-parallel gradient exchange with 16-bit wire format (ddp.GradientReducer(compress="bf16")): out[i] = 16-bit(sum_w
+ * in[w][i]) with the sum in fp32 and a fixed order -- the shards received by the all-to-all, accumulated on receipt. */
+int mh_sum_shards_16(const void* in /*[W][shard]*/, void* out /*[shard]*/, int W, int64_t shard, mh_stream_t stream);
 
 #ifdef __cplusplus
 }

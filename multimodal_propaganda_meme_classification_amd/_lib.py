@@ -148,6 +148,7 @@ _PROTOS = {
     "mh_adam_step_rows": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p],
     "mh_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "mh_cast_bf16_f32": [c_void_p, c_void_p, c_int64, c_void_p],
+    "mh_sum_shards_16": [c_void_p, c_void_p, c_int, c_int64, c_void_p],
     "mh_version": [],
     "mh_status_str": [c_int],
 }

@@ -204,6 +204,34 @@ extern "C" int mh_cast_f32_bf16(const float* src, void* dst, int64_t n, mh_strea
                        (h16*)dst, n);
     return mh_launch_status();
 }
+namespace {
+// out[i] = 16-bit( sum_w in[w][i] ) with the sum in fp32, fixed order w = 0 .. W-1
+__global__ __launch_bounds__(256) void sum_shards_kernel(const h16* __restrict__ in, h16* __restrict__ out, int W, size_t shard8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= shard8) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < W; ++w) {
+        Pack8 u;
+        u.v = *(const i32x4*)(in + ((size_t)w * shard8 + i) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += mh_bf2f(u.e[e]);
+    }
+    Pack8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = mh_f2bf(acc[e]);
+    *(i32x4*)(out + i * 8) = o.v;
+}
+}  // namespace
+
+extern "C" int mh_sum_shards_16(const void* in, void* out, int W, int64_t shard, mh_stream_t stream) {
+    if (!in || !out) return MH_EINVAL;
+    if (W < 1 || shard < 8 || (shard % 8)) return MH_ESHAPE;
+    const size_t s8 = (size_t)shard / 8;
+    hipLaunchKernelGGL(sum_shards_kernel, dim3((unsigned)((s8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const h16*)in, (h16*)out,
+                       W, s8);
+    return mh_launch_status();
+}
+
 extern "C" int mh_cast_bf16_f32(const void* src, float* dst, int64_t n, mh_stream_t stream) {
     if (!src || !dst) return MH_EINVAL;
     if (n < 1 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MH_ESHAPE;

@@ -16,14 +16,78 @@ import torch
 import torch.distributed as dist
 
 
+class _EventWork:
+    """Work handle of a compressed bucket on a HIP device: wait() makes the current stream wait for the comm stream."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+
+
 class GradientReducer:
-    def __init__(self, flat_grads: torch.Tensor, group=None, bucket_cap_elems: int = 64 << 20):
+    """``compress="bf16"``: the gradient slice crosses xGMI as bfloat16 -- half the bytes of the fp32 all-reduce (443 MB
+    instead of 887 MB per step for config 3) -- WITHOUT summing in bf16: every rank sends shard r of its
+    bf16-rounded slice to rank r (all-to-all), rank r adds the `world` shards in fp32, rounds the sum to bf16 once and
+    all-gathers it.  Per element: one bf16 rounding of each rank's contribution + one of the sum (relative 2^-9 each); the
+    fp32 buffer receives the exact bf16 value, identical on every rank."""
+
+    def __init__(self, flat_grads: torch.Tensor, group=None, bucket_cap_elems: int = 64 << 20, compress: Optional[str] = None):
+        if compress not in (None, "bf16"):
+            raise ValueError(f"compress must be None or 'bf16', got {compress!r}")
         self.G = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cap = bucket_cap_elems
+        self.compress = compress
         self.pending: List = []
         self.reduced_elems = 0
+        self.wire_bytes = 0                  # bytes this rank put on the wire per element-pass (accounting for tests / logs)
+        self._cstream = torch.cuda.Stream() if (compress and flat_grads.is_cuda) else None
+        self._bufs = {}
+
+    def _reduce_compressed(self, a: int, e: int):
+        """all-to-all (bf16) -> fp32 sum of the received shards -> bf16 -> all-gather -> fp32 gradient slice."""
+        W, n = self.world, e - a
+        shard = -(-n // (W * 8)) * 8
+        key = shard
+        if key not in self._bufs:
+            dev = self.G.device
+            self._bufs[key] = (torch.zeros(W * shard, dtype=torch.bfloat16, device=dev), torch.empty(W * shard, dtype=torch.bfloat16, device=dev),
+                               torch.empty(shard, dtype=torch.bfloat16, device=dev), torch.empty(W * shard, dtype=torch.bfloat16, device=dev))
+        send, recv, mine, full = self._bufs[key]
+        g = self.G[a:e]
+
+        def body():
+            if g.is_cuda:
+                from . import ops
+                ops.cast_f32_bf16(g, send[:n] if n % 4 == 0 else send)      # HIP cast kernel (n is 4-aligned for layout slices)
+            else:
+                send[:n].copy_(g)
+            dist.all_to_all_single(recv, send, group=self.group)
+            if g.is_cuda:
+                ops.sum_shards_16(recv, mine, W)                            # fp32 accumulation on receipt, one rounding
+            else:
+                mine.copy_(recv.view(W, shard).float().sum(dim=0))
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+            if g.is_cuda:
+                from . import ops
+                ops.cast_bf16_f32(full[:n], g)
+            else:
+                g.copy_(full[:n])
+
+        self.wire_bytes += 2 * 2 * (W - 1) * shard
+        if self._cstream is None:
+            body()
+            return _EventWork(None)
+        self._cstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._cstream):
+            body()
+            ev = torch.cuda.Event()
+            ev.record(self._cstream)
+        return _EventWork(ev)
 
     def reduce_range(self, rng: Optional[Tuple[int, int]]):
         """Start the all-reduce (SUM) of G[start:end]; returns immediately with the list of work handles started."""
@@ -31,6 +95,14 @@ class GradientReducer:
         if rng is None or not dist.is_initialized():
             return started
         a, b = rng
+        if self.compress:      # (also on a 1-rank group: the same collectives and kernels, so one GPU can rehearse the path)
+            while a < b:
+                e = min(b, a + self.cap)
+                started.append(self._reduce_compressed(a, e))
+                self.reduced_elems += e - a
+                a = e
+            self.pending += started
+            return started
         while a < b:
             e = min(b, a + self.cap)
             started.append(dist.all_reduce(self.G[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -549,3 +549,18 @@ def cast_f32_bf16(src, dst):
     _chk(src, F32, "src"), _chk(dst, BF16, "dst")
     assert dst.numel() >= src.numel()
     check(_L(dst).mh_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "mh_cast_f32_bf16")
+
+
+def cast_bf16_f32(src, dst):
+    """dst f32 [n] = src 16-bit [n]  (mh_cast_bf16_f32)"""
+    _chk(src, BF16, "src"), _chk(dst, F32, "dst")
+    assert dst.numel() >= src.numel()
+    check(_L(src).mh_cast_bf16_f32(_p(src), _p(dst), src.numel(), _stream()), "mh_cast_bf16_f32")
+
+
+def sum_shards_16(shards, out, W: int):
+    """out[i] = 16-bit(sum_w shards[w][i]), fp32 accumulation (mh_sum_shards_16)"""
+    _chk(shards, BF16, "shards"), _chk(out, BF16, "out")
+    shard = out.numel()
+    assert shards.numel() >= W * shard and shards.dtype == out.dtype
+    check(_L(out).mh_sum_shards_16(_p(shards), _p(out), int(W), shard, _stream()), "mh_sum_shards_16")

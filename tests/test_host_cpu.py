@@ -131,6 +131,50 @@ def _ddp_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _ddp_bf16_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 5000
+        gen = torch.Generator().manual_seed(100 + rank)
+        mine = torch.randn(n, generator=gen)
+        g32, g16 = mine.clone(), mine.clone()
+        ddp.GradientReducer(g32, bucket_cap_elems=2048).hook("a", (0, n))
+        red = ddp.GradientReducer(g16, bucket_cap_elems=2048, compress="bf16")
+        for rng in ((0, 1000), (1000, 1008), (1008, n)):
+            for w in red.reduce_range(rng):
+                w.wait()
+        red.wait()
+        # exact model of the compressed path: bf16(sum_r bf16(g_r)) with the sum in fp32
+        parts = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)).to(torch.bfloat16).float() for r in range(world)]
+        want = torch.stack(parts).sum(0).to(torch.bfloat16).float()
+        ok = torch.equal(g16, want)
+        ok = ok and float((g16 - g32).abs().max()) <= 2.0 ** -7 * float(g32.abs().max())     # within bf16 rounding of the fp32 sum
+        ok = ok and red.reduced_elems == n and red.wire_bytes < 0.6 * 4 * 2 * (world - 1) / world * n + 4096   # about half the fp32 bytes
+        gathered = [torch.empty_like(g16) for _ in range(world)]
+        dist.all_gather(gathered, g16)
+        ok = ok and all(torch.equal(gathered[0], t) for t in gathered)                        # identical on every rank
+        out[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_reducer_bf16_compression_gloo_world2():
+    """bf16 on the wire, fp32 accumulation on receipt (all-to-all + all-gather): against the fp32 all-reduce and an exact
+    model of the compressed arithmetic."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_bf16_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+    with pytest.raises(ValueError):
+        ddp.GradientReducer(torch.zeros(8), compress="int8")
+
+
 def test_gradient_reducer_gloo_world2():
     import torch.multiprocessing as mp
     world = 2

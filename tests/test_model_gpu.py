@@ -285,6 +285,44 @@ def test_ddp_segmented_graph_path_world1(pkg, clip):
         dist.destroy_process_group()
 
 
+def test_ddp_bf16_compressed_exchange_world1(pkg):
+    """ddp.GradientReducer(compress="bf16") on a real RCCL communicator (1 rank): all-to-all + fp32 shard sum + all-gather
+    between the backward segments' graphs.  The gradients arrive bf16-rounded, so the step is not bit-identical to the fp32
+    exchange: after 3 steps every parameter is within one Adam step size of it and the mean difference is ~1 % of lr."""
+    import torch.distributed as dist
+    from multimodal_propaganda_meme_classification_amd import ddp
+    O = _oracle()
+    cfg = O.tiny_config("cls")
+    text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=12)
+    dev = [t.cuda() for t in (text, image, mask, labels)]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29950 + os.getpid() % 40)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        m1, _ = _make(pkg, O, cfg, 14)
+        m2, _ = _make(pkg, O, cfg, 14)
+        o1, o2 = pkg.Adam(m1.parameters(), lr=LR), pkg.Adam(m2.parameters(), lr=LR)
+        r1 = ddp.GradientReducer(m1.flat_grads, bucket_cap_elems=1 << 16)
+        r2 = ddp.GradientReducer(m2.flat_grads, bucket_cap_elems=1 << 16, compress="bf16")
+        g1 = pkg.GraphedStep(m1, o1, 4, 16, reducer=r1)
+        g2 = pkg.GraphedStep(m2, o2, 4, 16, reducer=r2)
+        for k in range(3):
+            g1.load_batch(*dev)
+            g2.load_batch(*dev)
+            l1, _ = g1.step()
+            l2, _ = g2.step()
+            torch.cuda.synchronize()
+            assert abs(float(l1) - float(l2)) < 1e-4
+            d = (m1.flat_params - m2.flat_params).abs()
+            assert float(d.max()) <= 2.05 * LR * (k + 1) and float(d.mean()) < 0.05 * LR, (float(d.max()), float(d.mean()))
+        assert r2.reduced_elems == r1.reduced_elems and r2.wire_bytes == 0          # one rank: nothing crosses a link
+        # the exchanged gradients are exactly bf16 values
+        gsl = m2.flat_grads[:4096]
+        assert torch.equal(gsl, gsl.to(torch.bfloat16).float())
+    finally:
+        dist.destroy_process_group()
+
+
 def test_ddp_two_ranks_on_one_gpu_match_the_global_batch():
     """N = 2 for real: two processes (gloo backend, both on device 0) run the data-parallel step -- parameter broadcast,
     per-segment all-reduce, the gathered embedding-table gradient, 1/world in Adam, Adam slices behind each bucket --
