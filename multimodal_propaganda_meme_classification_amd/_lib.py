@@ -48,7 +48,7 @@ class MhLnFwdJob(C.Structure):
 class MhLnBwdJob(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("dy", "x", "gamma", "mean", "rstd", "dx_add", "dx", "part", "dx_drop", "rng")] + \
                [("n_part", C.c_int32), ("rows", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32),
-                ("rows_dev", c_void_p), ("drop_rows", c_void_p), ("ksplit", C.c_int32), ("reserved_", C.c_int32)]
+                ("rows_dev", c_void_p), ("drop_rows", c_void_p)]
 
 
 class MhAttnProblem(C.Structure):

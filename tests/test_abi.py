@@ -44,7 +44,7 @@ def test_binding_covers_header(lib):
 
 def test_struct_layout_matches_header(lib):
     # 8 pointers + 7 int32 + float + pointer + float + uint32 + 2 pointers = 128 bytes; a drift here would corrupt every grouped launch
-    assert ctypes.sizeof(lib.MhGemmProblem) == 128
+    assert ctypes.sizeof(lib.MhGemmProblem) == 136
     assert ctypes.sizeof(lib.MhColsumJob) == 24
     assert ctypes.sizeof(lib.MhAttnProblem) == 104
     assert ctypes.sizeof(lib.MhLnFwdJob) == 72 and ctypes.sizeof(lib.MhLnBwdJob) == 112
@@ -69,3 +69,22 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "from .. import oracle" not in src and "import oracle" not in src, f
+
+
+def test_ctypes_structs_match_the_c_compiler(tmp_path):
+    """Every struct of include/memehip.h, sized by gcc, against its ctypes mirror: a field added on one side only shifts the
+    second element of a job array and fails far from its cause."""
+    import ctypes
+    import subprocess
+    from multimodal_propaganda_meme_classification_amd import _lib as lib
+    names = ["MhGemmProblem", "MhColsumJob", "MhLnFwdJob", "MhLnBwdJob", "MhAttnProblem", "MhHeadParams", "MhHeadGrads", "MhGemmF32"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "memehip.h"\nint main(void){' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for n in names:
+        assert ctypes.sizeof(getattr(lib, n)) == int(sizes[n]), (n, ctypes.sizeof(getattr(lib, n)), sizes[n])
