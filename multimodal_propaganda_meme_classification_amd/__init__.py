@@ -14,3 +14,4 @@ from .heads import (ConcatAttention3, FineTuneMLP, KevinMultimodalClassifier, Li
 from .data import HashTokenizer, MultimodalDataset, id2l, l2id, normalize_images, read_data  # noqa: F401
 from .train import evaluate, test, train  # noqa: F401
 from .resnet import Bottleneck, ResNet50, ResNetClassifier  # noqa: F401
+from .features import dump_features, get_features  # noqa: F401

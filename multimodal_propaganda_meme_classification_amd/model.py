@@ -502,9 +502,10 @@ class MultimodalClassifier(nn.Module):
         finally:
             self.train(was)
         out = {"text": t_.clone(), "image": i_.clone()}
-        if pooler is not None:
-            w, b = (x.to(t_.device, F32) for x in pooler)
-            out["pooler_output"] = torch.tanh(torch.addmm(b, out["text"], w.t()))
+        if pooler is not None:      # BertPooler: tanh(dense(h_cls)), one exact-f32 HIP GEMM with the tanh in its epilogue
+            from . import fused
+            w, b = (x.to(t_.device, F32).contiguous() for x in pooler)
+            out["pooler_output"] = fused.linear(out["text"], w, b, act="tanh")
         return out
 
     def forward_backward(self, text, image, mask, labels, grad_hook=None):
