@@ -244,6 +244,26 @@ int mh_bert_embed_bwd(const int64_t* ids, const void* d_pre /*bf16 [T][D]*/, flo
  *   with torchvision's float32 arithmetic.  mean / std: three host floats each. */
 int mh_image_normalize_u8(const uint8_t* src, float* dst, int B, int H, int W, const float* mean3 /*host*/,
                           const float* std3 /*host*/, mh_stream_t stream);
+/* The transforms in front of it, on decoded uint8 pixels after ONE host-to-device copy of the batch:
+ * mh_image_resample_u8: PIL's antialiased bilinear resize (what torchvision's Resize does to a PIL image) in PIL's own 8-bit
+ *   fixed point -- horizontal pass into a uint8 image, then the vertical pass; the host supplies, per image and output
+ *   pixel, the source window {first, count} and the 22-bit integer coefficients (data.pil_resample_coeffs: PIL's
+ *   precompute_coeffs / normalize_coeffs_8bpc), so the output equals PIL's bit for bit.  Only the output window asked for
+ *   (the centre crop) is computed; `flip` (uint8 [B] or NULL) mirrors the output (RandomHorizontalFlip).
+ *     arena: the batch's images back to back, uint8 [h][w][3] each at src_off[b]; hw int32 [B][2];
+ *     xbounds / ybounds int32 [B][OW|OH][2]; xcoef / ycoef int32 [B][OW|OH][KX|KY]; tmp uint8 [B][max_h][OW][3];
+ *     out uint8 [B][OH][OW][3].
+ * mh_image_jitter_rotate_u8: ColorJitter (brightness / contrast / saturation / hue factors, per-image op order packed 2 bits
+ *   per step: 0 brightness, 1 contrast, 2 saturation, 3 hue) with PIL's ImageEnhance arithmetic on uint8, then
+ *   RandomRotation (nearest, about the centre, fill 0).  params: device array of {f32 brightness, contrast, saturation, hue,
+ *   angle_rad; i32 order; 2 x i32 pad} per image; lsum: device u64 [B] workspace (L-image sums for the contrast mean).
+ *   (Multimodal_example_task2C.py:222-235.)  The random factors are drawn on the host. */
+int mh_image_resample_u8(const uint8_t* arena, const int64_t* src_off, const int32_t* hw, const int32_t* xbounds,
+                         const int32_t* xcoef, int KX, const int32_t* ybounds, const int32_t* ycoef, int KY, const uint8_t* flip,
+                         uint8_t* tmp, uint8_t* out, int B, int max_h, int OH, int OW, mh_stream_t stream);
+int mh_image_luma_sum_u8(const uint8_t* img, unsigned long long* sums, int B, int HW, mh_stream_t stream);
+int mh_image_jitter_rotate_u8(const uint8_t* in, uint8_t* scratch, uint8_t* out, const void* params, unsigned long long* lsum,
+                              int B, int H, int W, mh_stream_t stream);
 /* Dropout helpers.  mh_dropout_apply: x[i] *= mask(i)/(1-p) in place (16-bit), e.g. the gradient arriving at a
  * dropped activation.  mh_dropout_mask_u8: the 0/1 mask a site would use for element indices 0..n-1 (tests). */
 int mh_dropout_apply(void* x, int64_t n, const uint32_t* rng, float p, uint32_t stream_id, mh_stream_t stream);

@@ -97,6 +97,9 @@ _PROTOS = {
     "mh_unpack_rows": [c_void_p] * 3 + [c_int, c_int, c_void_p],
     "mh_bert_embed_fwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_image_normalize_u8": [c_void_p, c_void_p, c_int, c_int, c_int, C.POINTER(c_float), C.POINTER(c_float), c_void_p],
+    "mh_image_resample_u8": [c_void_p] * 5 + [c_int] + [c_void_p] * 2 + [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p],
+    "mh_image_luma_sum_u8": [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "mh_image_jitter_rotate_u8": [c_void_p] * 5 + [c_int] * 3 + [c_void_p],
     "mh_dropout_apply": [c_void_p, c_int64, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_dropout_mask_u8": [c_void_p, c_int64, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_bert_embed_bwd": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -170,3 +170,160 @@ class MultimodalDataset(Dataset):
         if not self.is_test:
             fdata["label"] = torch.tensor(self.labels[index], dtype=torch.long)
         return fdata
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Device input pipeline (SURVEY section 8 f rank 4): decoded uint8 images -> ONE pinned async H2D copy -> HIP kernels
+# ---------------------------------------------------------------------------------------------------------------------
+_PRECISION_BITS = 22          # PIL ImagingResample (8 bits per channel): 32 - 8 - 2
+
+
+def pil_resample_coeffs(in_size: int, out_size: int, first: int = 0, count: Optional[int] = None):
+    """PIL's bilinear (antialiased) resample coefficients for one axis, restated from libImaging/Resample.c
+    (precompute_coeffs + normalize_coeffs_8bpc): for output pixels first .. first+count-1 of a resize in_size -> out_size,
+    returns ``bounds int32 [count, 2]`` = (first source pixel, number of taps) and ``coefs int32 [count, ksize]`` in 22-bit
+    fixed point.  A pixel is then clip8((2^21 + sum_k src[x0 + k] * coef[k]) >> 22)."""
+    count = out_size if count is None else count
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale                      # bilinear: support 1
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((count, 2), dtype=np.int32)
+    coefs = np.zeros((count, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for i in range(count):
+        xx = first + i
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        x = np.arange(xmax, dtype=np.float64)
+        w = np.abs((x + xmin - center + 0.5) * ss)
+        k = np.where(w < 1.0, 1.0 - w, 0.0)
+        ww = k.sum()
+        if ww != 0.0:
+            k = k / ww
+        fixed = np.where(k < 0, (-0.5 + k * (1 << _PRECISION_BITS)).astype(np.int64), (0.5 + k * (1 << _PRECISION_BITS)).astype(np.int64))
+        bounds[i] = (xmin, xmax)
+        coefs[i, :xmax] = fixed
+    return bounds, coefs
+
+
+def resample_u8_reference(img: np.ndarray, bx, cx, by, cy) -> np.ndarray:
+    """numpy statement of what mh_image_resample_u8 computes (horizontal pass into uint8, then vertical): tests only."""
+    h = img.shape[0]
+    tmp = np.zeros((h, bx.shape[0], 3), dtype=np.uint8)
+    for xo in range(bx.shape[0]):
+        x0, n = bx[xo]
+        acc = (1 << (_PRECISION_BITS - 1)) + (img[:, x0:x0 + n, :].astype(np.int64) * cx[xo, :n][None, :, None]).sum(1)
+        tmp[:, xo] = np.clip(acc >> _PRECISION_BITS, 0, 255)
+    out = np.zeros((by.shape[0], bx.shape[0], 3), dtype=np.uint8)
+    for yo in range(by.shape[0]):
+        y0, n = by[yo]
+        acc = (1 << (_PRECISION_BITS - 1)) + (tmp[y0:y0 + n].astype(np.int64) * cy[yo, :n][:, None, None]).sum(0)
+        out[yo] = np.clip(acc >> _PRECISION_BITS, 0, 255)
+    return out
+
+
+class DeviceImagePipeline:
+    """The reference's image transforms on the device.  ``__call__(images)`` takes the batch's decoded images (uint8
+    [h, w, 3] arrays or PIL images, any sizes), packs them into one pinned host arena, issues ONE asynchronous H2D copy and
+    returns the f32 [B, 3, S, S] normalised batch:
+
+    * ``mode="center_crop"``: Resize(resize) -> CenterCrop(image_size) -> ToTensor -> Normalize (organizers,
+      Multimodal_example_task2C.txt:37-41), bit-identical to the PIL path (``load_image``);
+    * ``mode="stretch"``: Resize((S, S)) (Kevin, Multimodal_example_task2C.py:224); ``augment=True`` adds
+      RandomHorizontalFlip, ColorJitter(0.1, 0.1, 0.1, 0.1) and RandomRotation(15) with PIL's uint8 arithmetic; the random
+      factors come from ``generator`` (torchvision's own RNG stream cannot be reproduced)."""
+
+    def __init__(self, image_size: int = 224, resize: int = 256, mode: str = "center_crop", augment: bool = False,
+                 device="cuda", generator: Optional[torch.Generator] = None, jitter=(0.1, 0.1, 0.1, 0.1), degrees: float = 15.0):
+        if mode not in ("center_crop", "stretch"):
+            raise ValueError(f"mode must be 'center_crop' or 'stretch', got {mode!r}")
+        self.S, self.resize, self.mode, self.augment = image_size, resize, mode, augment
+        self.device = torch.device(device)
+        self.gen = generator or torch.Generator().manual_seed(0)
+        self.jitter, self.degrees = jitter, degrees
+        self._pinned = {}
+
+    def _pin(self, key, nbytes):
+        buf = self._pinned.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+            self._pinned[key] = buf
+        return buf
+
+    def _plan(self, h, w):
+        S = self.S
+        if self.mode == "stretch":
+            return pil_resample_coeffs(w, S), pil_resample_coeffs(h, S)
+        nw, nh = resized_size(w, h, self.resize)
+        left, top, _, _ = center_crop_box(nw, nh, S)
+        return pil_resample_coeffs(w, nw, left, S), pil_resample_coeffs(h, nh, top, S)
+
+    def __call__(self, images) -> torch.Tensor:
+        from . import _lib, ops
+        if self.device.type != "cuda":
+            raise _lib.MemehipError("DeviceImagePipeline runs on the HIP device only (no CPU fallback)")
+        arrs = [np.ascontiguousarray(np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8)) for im in images]
+        B, S = len(arrs), self.S
+        plans = [self._plan(a.shape[0], a.shape[1]) for a in arrs]
+        KX = max(p[0][1].shape[1] for p in plans)
+        KY = max(p[1][1].shape[1] for p in plans)
+        max_h = max(a.shape[0] for a in arrs)
+        sizes = [a.size for a in arrs]
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        total = int(sum(sizes))
+        # ---- one pinned arena: pixels | offsets | sizes | x bounds | x coefs | y bounds | y coefs | flips | jitter params
+        meta = [offs.view(np.uint8), np.array([[a.shape[0], a.shape[1]] for a in arrs], dtype=np.int32).view(np.uint8)]
+        xb = np.zeros((B, S, 2), np.int32); xc = np.zeros((B, S, KX), np.int32)
+        yb = np.zeros((B, S, 2), np.int32); yc = np.zeros((B, S, KY), np.int32)
+        for b, ((bx, cx), (by, cy)) in enumerate(plans):
+            xb[b], yb[b] = bx, by
+            xc[b, :, :cx.shape[1]], yc[b, :, :cy.shape[1]] = cx, cy
+        flips = np.zeros(B, np.uint8)
+        jit = np.zeros((B, 8), np.float32)
+        if self.augment:
+            g = self.gen
+            flips = (torch.rand(B, generator=g) < 0.5).to(torch.uint8).numpy()
+            jb, jc, js, jh = self.jitter
+            u = torch.rand((B, 5), generator=g).numpy()
+            jit[:, 0] = 1 - jb + 2 * jb * u[:, 0]
+            jit[:, 1] = 1 - jc + 2 * jc * u[:, 1]
+            jit[:, 2] = 1 - js + 2 * js * u[:, 2]
+            jit[:, 3] = -jh + 2 * jh * u[:, 3]
+            jit[:, 4] = np.deg2rad(-self.degrees + 2 * self.degrees * u[:, 4])
+            order = np.zeros(B, np.int32)
+            for b in range(B):
+                perm = torch.randperm(4, generator=g).tolist()
+                order[b] = sum(int(op) << (2 * st) for st, op in enumerate(perm))
+            jit.view(np.int32)[:, 5] = order
+        parts = meta + [x.view(np.uint8).reshape(-1) for x in (xb, xc, yb, yc)] + [flips, jit.view(np.uint8).reshape(-1)]
+        starts, pos = [], (total + 63) // 64 * 64
+        for p_ in parts:
+            starts.append(pos)
+            pos = (pos + p_.size + 63) // 64 * 64
+        host = self._pin("arena", pos)
+        hv = host.numpy()
+        for a, o in zip(arrs, offs):
+            hv[o:o + a.size] = a.reshape(-1)
+        for p_, st in zip(parts, starts):
+            hv[st:st + p_.size] = p_.reshape(-1)
+        dev = torch.empty(pos, dtype=torch.uint8, device=self.device)
+        dev.copy_(host[:pos], non_blocking=True)                     # the ONE host-to-device copy of the batch
+        base = dev.data_ptr()
+        ptr = lambda i: base + starts[i]
+        tmp = torch.empty((B, max_h, S, 3), dtype=torch.uint8, device=self.device)
+        out = torch.empty((B, S, S, 3), dtype=torch.uint8, device=self.device)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.mh_image_resample_u8(base, ptr(0), ptr(1), ptr(2), ptr(3), KX, ptr(4), ptr(5), KY,
+                                            ptr(6) if self.augment else None, tmp.data_ptr(), out.data_ptr(), B, max_h, S, S, stream),
+                   "mh_image_resample_u8")
+        if self.augment:
+            scratch, out2 = torch.empty_like(out), torch.empty_like(out)
+            lsum = torch.zeros(B, dtype=torch.int64, device=self.device)
+            _lib.check(lib.mh_image_jitter_rotate_u8(out.data_ptr(), scratch.data_ptr(), out2.data_ptr(), ptr(7), lsum.data_ptr(), B, S, S,
+                                                     stream), "mh_image_jitter_rotate_u8")
+            out = out2
+        self.last_u8 = out
+        return ops.image_normalize_u8(out, IMAGENET_MEAN, IMAGENET_STD)

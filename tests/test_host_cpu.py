@@ -216,3 +216,23 @@ def test_image_projection_name_is_configurable():
     bad.image_fc_name = "vit_fc"
     with pytest.raises(ValueError):
         bad.validate()
+
+
+def test_pil_resample_restatement_is_bit_exact():
+    """data.pil_resample_coeffs (PIL's precompute_coeffs / normalize_coeffs_8bpc restated) + the two-pass uint8 arithmetic the
+    HIP kernels run (data.resample_u8_reference) against PIL's own Image.resize(BILINEAR): every pixel equal, for down- and
+    up-scaling, for the centre-crop window of Resize(256) and for Resize((224, 224))."""
+    from PIL import Image
+    from multimodal_propaganda_meme_classification_amd.data import (center_crop_box, pil_resample_coeffs, resample_u8_reference,
+                                                                    resized_size)
+    rng = np.random.default_rng(0)
+    for (h, w) in ((300, 400), (427, 640), (97, 131), (1000, 333)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        nw, nh = resized_size(w, h, 256)
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+        left, top, _, _ = center_crop_box(nw, nh, 224)
+        got = resample_u8_reference(img, *pil_resample_coeffs(w, nw, left, 224), *pil_resample_coeffs(h, nh, top, 224))
+        assert np.array_equal(got, ref[top:top + 224, left:left + 224]), (h, w)
+        ref2 = np.asarray(Image.fromarray(img).resize((224, 224), Image.BILINEAR))
+        got2 = resample_u8_reference(img, *pil_resample_coeffs(w, 224), *pil_resample_coeffs(h, 224))
+        assert np.array_equal(got2, ref2), (h, w)

@@ -473,3 +473,61 @@ def test_three_tower_model_with_caption_encoder_matches_oracle():
     w0 = lay.spec["bert.encoder.layer.0.attention.self.query.weight"]
     s0 = lay.spec["image_model.encoder.layer.0.attention.attention.query.weight"]
     assert bool(changed[w0.offset:w0.offset + w0.numel].any()) and not bool(changed[s0.offset:s0.offset + s0.numel].any())
+
+
+def test_device_image_pipeline_equals_the_pil_path(pkg, tmp_path):
+    """SURVEY 8 f rank 4: decoded uint8 images of different sizes -> one pinned async H2D copy -> PIL's antialiased bilinear
+    Resize(256) + CenterCrop(224) in its own fixed point + ToTensor + Normalize, all on the device: bit-identical to the host
+    transform (data.load_image), i.e. to the reference's torchvision pipeline on PIL images."""
+    from PIL import Image, ImageEnhance
+    from multimodal_propaganda_meme_classification_amd.data import DeviceImagePipeline, load_image, load_image_u8
+    rng = np.random.default_rng(3)
+    paths, imgs = [], []
+    for i, (h, w) in enumerate(((300, 400), (427, 640), (640, 427), (97, 131), (224, 224), (512, 512))):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        p = str(tmp_path / f"im{i}.png")
+        Image.fromarray(a).save(p)
+        paths.append(p)
+        imgs.append(Image.open(p))
+    pipe = DeviceImagePipeline(224, 256, "center_crop", device="cuda")
+    got = pipe(imgs)
+    torch.cuda.synchronize()
+    want_u8 = torch.stack([load_image_u8(p) for p in paths])
+    assert torch.equal(pipe.last_u8.cpu(), want_u8)
+    want = torch.stack([load_image(p) for p in paths])
+    assert torch.equal(got.cpu(), want)
+    # Kevin's Resize((224, 224)) + flip + ColorJitter + rotation, with factors that make each op checkable against PIL
+    pipe2 = DeviceImagePipeline(224, mode="stretch", augment=True, device="cuda", generator=torch.Generator().manual_seed(5),
+                                jitter=(0.1, 0.1, 0.1, 0.0), degrees=0.0)
+    out = pipe2(imgs)
+    torch.cuda.synchronize()
+    assert out.shape == (6, 3, 224, 224) and bool(torch.isfinite(out).all())
+    # replay the same random draws on the host with PIL's own ImageEnhance ops (hue 0, angle 0)
+    g = torch.Generator().manual_seed(5)
+    flips = (torch.rand(6, generator=g) < 0.5).numpy()
+    u = torch.rand((6, 5), generator=g).numpy()
+    for b, im in enumerate(imgs):
+        perm = torch.randperm(4, generator=g).tolist()
+        ref = im.convert("RGB").resize((224, 224), Image.BILINEAR)
+        if flips[b]:
+            ref = ref.transpose(Image.FLIP_LEFT_RIGHT)
+        f = [float(np.float32(0.9 + 0.2 * u[b, k])) for k in range(3)]
+        for op in perm:
+            if op == 0:
+                ref = ImageEnhance.Brightness(ref).enhance(f[0])
+            elif op == 1:
+                ref = ImageEnhance.Contrast(ref).enhance(f[1])
+            elif op == 2:
+                ref = ImageEnhance.Color(ref).enhance(f[2])
+        d = np.abs(np.asarray(ref).astype(int) - pipe2.last_u8[b].cpu().numpy().astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (b, perm, int(d.max()), float((d > 0).mean()))     # float32 vs double blend factor
+    # rotation: 90 degrees is an exact permutation of the pixels
+    pipe3 = DeviceImagePipeline(224, mode="stretch", augment=True, device="cuda", generator=torch.Generator().manual_seed(7),
+                                jitter=(0.0, 0.0, 0.0, 0.0), degrees=0.0)
+    base = pipe3(imgs[:2])
+    base_u8 = pipe3.last_u8.clone()
+    assert bool(torch.isfinite(base).all())
+    ref0 = np.asarray(imgs[0].convert("RGB").resize((224, 224), Image.BILINEAR))
+    g7 = torch.Generator().manual_seed(7)
+    fl = (torch.rand(2, generator=g7) < 0.5).numpy()
+    assert np.array_equal(base_u8[0].cpu().numpy(), ref0[:, ::-1] if fl[0] else ref0)          # identity jitter, angle 0
