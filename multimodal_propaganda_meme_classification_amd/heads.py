@@ -30,6 +30,39 @@ from .model import CrossEntropyLoss, MultimodalClassifier, TextEncoder, flatten_
 POOLINGS = ("cls", "max", "mean", "attention", "cnn")
 
 
+class _Composite(nn.Module):
+    """A module whose children include HIP towers (TextEncoder / MultimodalClassifier keep their parameters in a flat buffer
+    behind reference-style key names): load_state_dict hands every child ITS slice of the checkpoint, so the tower's own
+    loader (key translation, 16-bit shadow invalidation) runs instead of nn.Module's recursion into the tower's internals."""
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        missing, unexpected = [], []
+        seen = set()
+        for name, child in self._modules.items():
+            if child is None:
+                continue
+            pfx = name + "."
+            sub = {k[len(pfx):]: v for k, v in state_dict.items() if k.startswith(pfx)}
+            seen.update(pfx + k for k in sub)
+            if not sub and not list(child.state_dict().keys()):
+                continue
+            res = child.load_state_dict(sub, strict=False)
+            missing += [pfx + k for k in res.missing_keys]
+            unexpected += [pfx + k for k in res.unexpected_keys]
+        own = {n for n, _ in self.named_parameters(recurse=False)} | {n for n, _ in self.named_buffers(recurse=False)}
+        with torch.no_grad():
+            for n in own:
+                if n in state_dict:
+                    getattr(self, n).copy_(state_dict[n])
+                    seen.add(n)
+                else:
+                    missing.append(n)
+        unexpected += [k for k in state_dict if k not in seen]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:4]} unexpected {unexpected[:4]}")
+        return nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+
 class SequencePooling(nn.Module):
     """The pooling branches of ``LLMWithClassificationHead`` (Multimodal_example_task2C.py:339-392,
     DistilBERT_example_task2A.py:162-210) over a last hidden state [B, S, D] (f32, device) and the attention mask."""
@@ -59,7 +92,7 @@ class SequencePooling(nn.Module):
         raise ValueError(f"Unsupported pooling type: {kind}")
 
 
-class TextClassifier(nn.Module):
+class TextClassifier(_Composite):
     """``LLMWithClassificationHead`` with the HF-Trainer protocol (DistilBERT_example_task2A.py:140-183).
 
     ``text`` is the encoder's shape (DistilBERT-multilingual: ``TextConfig(vocab_size=119547, layers=6, type_vocab=0)``).
@@ -113,7 +146,7 @@ class TextClassifier(nn.Module):
         return enc + own
 
 
-class TrainerModel(nn.Module):
+class TrainerModel(_Composite):
     """The Subtask-2C two-tower classifier behind the HF-Trainer protocol: ``model(**batch)`` with the collator's keys
     ``input_ids, attention_mask, pixel_values[, labels]`` (ResNet_example_task2B.py:206-210 for the image side,
     DistilBERT_example_task2A.py:159 for the text side) -> ``(loss, logits)`` / ``logits``."""
@@ -130,6 +163,41 @@ class TrainerModel(nn.Module):
         if labels is not None:
             return self.loss_fct(logits, labels.view(-1)), logits
         return logits
+
+
+class OrganizersMultimodalClassifier(_Composite):
+    """The organizers' Subtask-2C model exactly as written (example_scripts/Multimodal_example_task2C.txt:152-197):
+    ``bert`` (DistilBERT-multilingual via AutoModel) -> ``[:, -1, :]`` -> ``bert_drop`` -> ``bert_fc(768, 512)``;
+    ``resnet`` (torchvision resnet50, its 1000 logits) -> ``resnet_fc(1000, 512)``; ``cat`` -> ``fusion_fc(1024, 512)`` ->
+    ``output_fc(512, num_classes)``; ``forward(text, image, mask)``.  Same attribute names and state_dict keys
+    (``bert.transformer.layer.0.attention.q_lin.weight``, ``resnet.layer1.0.conv1.weight``, ``resnet_fc.bias`` ...), so a
+    checkpoint of the reference module loads.  Towers: TextEncoder (DistilBERT naming) and ResNet50 on the HIP kernels; the
+    four Linear layers run in the exact-f32 MFMA GEMM."""
+
+    def __init__(self, num_classes: int = 2, text: Optional[TextConfig] = None, compute_dtype: str = "fp16", resnet_layers=(3, 4, 6, 3),
+                 seed: int = 0):
+        super().__init__()
+        from .resnet import ResNet50
+        tc = text or TextConfig(vocab_size=119547, hidden=768, layers=6, heads=12, intermediate=3072, max_position=512, type_vocab=0)
+        self.bert = TextEncoder(tc, pool="last", compute_dtype=compute_dtype, seed=seed, naming="distilbert")
+        self.bert_drop = nn.Dropout(0.3)
+        self.bert_fc = nn.Linear(tc.hidden, 512)
+        self.resnet = ResNet50(num_classes=1000, compute_dtype=compute_dtype, layers=resnet_layers, seed=seed + 1)
+        self.resnet_fc = nn.Linear(1000, 512)
+        self.fusion_fc = nn.Linear(1024, 512)
+        self.output_fc = nn.Linear(512, num_classes)
+
+    def forward(self, text, image, mask):
+        for t_ in (text, image, mask):
+            if not t_.is_cuda:
+                raise _lib.MemehipError("memehip runs on the HIP device only (no CPU fallback): move the batch with .to(device)")
+        bert_output = self.bert_drop(self.bert(text, mask))             # the LAST position, as the reference takes it
+        bert_output = fused.linear(bert_output, self.bert_fc.weight, self.bert_fc.bias)
+        resnet_output = self.resnet(image)
+        resnet_output = fused.linear(resnet_output, self.resnet_fc.weight, self.resnet_fc.bias)
+        features = torch.cat((bert_output, resnet_output), dim=1)
+        features = fused.linear(features, self.fusion_fc.weight, self.fusion_fc.bias)
+        return fused.linear(features, self.output_fc.weight, self.output_fc.bias)
 
 
 class LinearBNReLU(nn.Sequential):
@@ -175,7 +243,7 @@ class ConcatAttention3(nn.Module):
         return self.reduce(attended)
 
 
-class KevinMultimodalClassifier(nn.Module):
+class KevinMultimodalClassifier(_Composite):
     """``MultimodalClassifier(fusion_method)`` of Multimodal_example_task2C.py:587-685 on the HIP towers.
 
     text tower + image tower = one lockstep ``MultimodalClassifier`` (``towers``; the reference's ``text_model`` and

@@ -550,8 +550,11 @@ class TextEncoder(nn.Module):
     prefix of the two-tower module; the stub's parameters get zero gradients (the head on top never reads them), so one
     fused ``Adam(encoder.parameters())`` leaves them unchanged."""
 
-    def __init__(self, text: "TextConfig", pool: str = "cls", compute_dtype: str = "bf16", seed: int = 0):
+    def __init__(self, text: "TextConfig", pool: str = "cls", compute_dtype: str = "bf16", seed: int = 0, naming: str = "bert"):
         super().__init__()
+        if naming not in ("bert", "distilbert"):
+            raise ValueError(f"naming must be 'bert' or 'distilbert', got {naming!r}")
+        self.naming = naming
         from .config import ImageConfig
         stub = ImageConfig(image_size=16, patch=16, hidden=128, layers=1, heads=2, intermediate=128)
         cfg = ModelConfig(text=text, image=stub, proj=128, num_classes=2, pool=pool, compute_dtype=compute_dtype)
@@ -571,11 +574,44 @@ class TextEncoder(nn.Module):
         h, _ = self.inner.encode_sequence(input_ids, self._stub_image(input_ids.shape[0], input_ids.device), attention_mask)
         return h
 
-    def state_dict(self, *args, **kwargs):
-        return {k[len("bert."):]: v for k, v in self.inner.state_dict(*args, **kwargs).items() if k.startswith("bert.")}
+    # DistilBertModel (transformers 4.39.2) names <-> the BertModel names the layout uses: same post-LN arithmetic
+    _DISTIL = (("transformer.layer.", "encoder.layer."), (".attention.q_lin.", ".attention.self.query."),
+               (".attention.k_lin.", ".attention.self.key."), (".attention.v_lin.", ".attention.self.value."),
+               (".attention.out_lin.", ".attention.output.dense."), (".sa_layer_norm.", ".attention.output.LayerNorm."),
+               (".ffn.lin1.", ".intermediate.dense."), (".ffn.lin2.", ".output.dense."), (".output_layer_norm.", ".output.LayerNorm."))
+
+    @classmethod
+    def _to_bert_name(cls, k: str) -> str:
+        for a, b in cls._DISTIL:
+            k = k.replace(a, b)
+        return k
+
+    @classmethod
+    def _to_distil_name(cls, k: str) -> str:
+        for a, b in cls._DISTIL:
+            k = k.replace(b, a)
+        return k
+
+    def state_dict(self, *args, destination=None, prefix: str = "", keep_vars: bool = False, **kwargs):
+        """BertModel key names without the two-tower module's ``bert.`` prefix (``naming="distilbert"``: DistilBertModel's
+        ``transformer.layer.N.attention.q_lin.weight`` ...), so a parent module's state_dict() carries e.g. ``bert.embeddings...``
+        exactly as the reference's ``self.bert = AutoModel.from_pretrained(...)`` does."""
+        inner = self.inner.state_dict(keep_vars=keep_vars)
+        out = destination if destination is not None else {}
+        for k, v in inner.items():
+            if k.startswith("bert."):
+                name = k[len("bert."):]
+                out[prefix + (self._to_distil_name(name) if self.naming == "distilbert" else name)] = v
+        return out
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Called when a PARENT module loads a checkpoint: take this encoder's keys (either naming) out of it."""
+        mine = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        res = self.load_state_dict(mine, strict=False)
+        missing_keys.extend(prefix + k for k in res.missing_keys)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        sd = {("bert." + k): v for k, v in state_dict.items()}
+        sd = {("bert." + self._to_bert_name(k)): v for k, v in state_dict.items()}
         res = self.inner.load_state_dict(sd, strict=False)
         missing = [k[len("bert."):] for k in res.missing_keys if k.startswith("bert.")]
         if strict and (missing or res.unexpected_keys):

@@ -184,3 +184,30 @@ def test_resnet_oracle_matches_transformers_resnet_model(golden_dir):
     np.testing.assert_allclose(st["bn1.running_mean"].numpy(), z["bn1_running_mean"], atol=1e-6)
     np.testing.assert_allclose(st["bn1.running_var"].numpy(), z["bn1_running_var"], atol=1e-6, rtol=1e-5)
     np.testing.assert_allclose(st[f"layer4.{layers[3] - 1}.bn3.running_var"].numpy(), z["last_running_var"], atol=1e-6, rtol=1e-4)
+
+
+def test_distilbert_key_translation_and_arithmetic_match_transformers():
+    """TextEncoder's DistilBERT <-> BERT key map (model.TextEncoder._DISTIL) and the oracle's claim that DistilBertModel is the
+    BERT post-LN arithmetic without token types: a transformers DistilBertModel's state_dict, renamed by the product's map,
+    drives oracle.text_tower to the same last_hidden_state."""
+    from transformers import DistilBertConfig, DistilBertModel
+    from multimodal_propaganda_meme_classification_amd.model import TextEncoder
+    torch.manual_seed(0)
+    cfg = DistilBertConfig(vocab_size=600, dim=128, n_layers=2, n_heads=2, hidden_dim=256, max_position_embeddings=64, dropout=0.0,
+                           attention_dropout=0.0, sinusoidal_pos_embds=False)
+    cfg._attn_implementation = "eager"
+    hf = DistilBertModel(cfg).eval()
+    sd = hf.state_dict()
+    p = {"bert." + TextEncoder._to_bert_name(k): v for k, v in sd.items()}
+    ocfg = O.TextConfig(vocab_size=600, hidden=128, layers=2, heads=2, intermediate=256, max_position=64, type_vocab=0)
+    want = set(O._text_shapes(ocfg))
+    assert want <= set(p), sorted(want - set(p))[:4]
+    assert all(TextEncoder._to_distil_name(k[len("bert."):]) in sd for k in want)          # and back
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(5, 600, (3, 12), generator=g)
+    mask = (torch.arange(12)[None] < torch.tensor([12, 4, 7])[:, None]).long()
+    with torch.no_grad():
+        ref = hf(input_ids=ids, attention_mask=mask).last_hidden_state
+        got = O.text_tower(p, ids, mask, ocfg)
+    live = mask.bool()
+    np.testing.assert_allclose(got[live].numpy(), ref[live].numpy(), atol=2e-5, rtol=1e-4)

@@ -202,3 +202,55 @@ def test_resnet_classifier_trainer_protocol_and_fused_adam(pkg):
         losses.append(float(loss))
     assert logits.shape == (8, 2) and model(pixel_values=batch["pixel_values"]).shape == (8, 2)
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+def test_organizers_exact_model_distilbert_plus_resnet50(pkg):
+    """Multimodal_example_task2C.txt:152-197 as written: DistilBERT text tower (last position) + ResNet-50 (its 1000 logits) ->
+    bert_fc / resnet_fc -> cat -> fusion_fc -> output_fc, reference attribute names and state_dict keys, forward(text, image,
+    mask): logits against the CPU composition of the two oracles; one train step with torch.optim.Adam (the reference's
+    optimizer object) moves the loss."""
+    from oracle import meme_oracle as O
+    from oracle import resnet_oracle as R
+    tc = pkg.TextConfig(vocab_size=600, hidden=128, layers=2, heads=2, intermediate=256, max_position=64, type_vocab=0)
+    layers = (1, 1, 1, 1)
+    model = pkg.OrganizersMultimodalClassifier(2, text=tc, compute_dtype="fp16", resnet_layers=layers, seed=3)
+    model.bert_drop.p = 0.0
+    with torch.no_grad():       # BatchNorm affine away from the 1 / 0 init, as in the oracle pins
+        for n, p_ in model.resnet.named_parameters():
+            if "bn" in n or "downsample.1" in n:
+                p_.add_(torch.randn_like(p_) * 0.1)
+    sd = {k: v.detach().clone().float() for k, v in model.state_dict().items()}
+    assert "bert.transformer.layer.1.ffn.lin2.weight" in sd and "resnet.layer4.0.downsample.0.weight" in sd and "resnet_fc.weight" in sd
+    model.cuda().train()
+    g = torch.Generator().manual_seed(8)
+    B, S = 4, 16
+    text = torch.randint(5, 600, (B, S), generator=g)
+    lens = torch.tensor([16, 5, 9, 12])
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    text = text * mask
+    image = torch.randn((B, 3, 64, 64), generator=g)
+    labels = torch.tensor([0, 1, 1, 0])
+    # CPU composition
+    ocfg = O.TextConfig(vocab_size=600, hidden=128, layers=2, heads=2, intermediate=256, max_position=64, type_vocab=0)
+    bert_p = {"bert." + pkg.TextEncoder._to_bert_name(k[len("bert."):]): v for k, v in sd.items() if k.startswith("bert.")}
+    res_p = {k[len("resnet."):]: v for k, v in sd.items() if k.startswith("resnet.") and "running" not in k and "num_batches" not in k}
+    t = O.text_tower(bert_p, text, mask, ocfg)[:, -1]
+    t = F.linear(t, sd["bert_fc.weight"], sd["bert_fc.bias"])
+    r = R.resnet_forward(res_p, R.new_bn_state(res_p), image, layers, training=True)
+    r = F.linear(r, sd["resnet_fc.weight"], sd["resnet_fc.bias"])
+    f = F.linear(torch.cat((t, r), 1), sd["fusion_fc.weight"], sd["fusion_fc.bias"])
+    ref = F.linear(f, sd["output_fc.weight"], sd["output_fc.bias"])
+    out = model(text.cuda(), image.cuda(), mask.cuda())
+    err = float((out.detach().float().cpu() - ref).abs().max())
+    print(f"[organizers' model] max |logit - CPU composition| = {err:.3e} (|logit| max {float(ref.abs().max()):.3f})")
+    assert err < 1e-2
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)          # optimizer = optim.Adam(model.parameters(), lr=...), ...task2C.txt:249
+    crit = pkg.CrossEntropyLoss()
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = crit(model(text.cuda(), image.cuda(), mask.cuda()), labels.cuda())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
