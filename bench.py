@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-overlap-opt", action="store_true", help="A/B: whole Adam update after the backward")
     ap.add_argument("--force-ddp", action="store_true",
                     help="debug: run the data-parallel code path (segmented graphs, RCCL all-reduce) on a 1-rank group")
+    ap.add_argument("--ddp-mode", choices=("stream", "segments"), default=None,
+                    help="data-parallel schedule (default: MEMEHIP_DDP_MODE or 'stream'): forward graph + stream-ordered eager "
+                         "backward with the all-reduces behind a fence stream, or one hipGraph per backward segment")
     ap.add_argument("--ddp-compress", choices=("none", "bf16"), default="none",
                     help="N > 1: wire format of the gradient exchange: fp32 all-reduce (default) or bf16 with fp32 accumulation on "
                          "receipt (all-to-all + all-gather, half the bytes)")
@@ -262,7 +265,7 @@ def main():
         reducer = ddp.GradientReducer(model.flat_grads, compress=None if args.ddp_compress == "none" else args.ddp_compress)
     opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)
     step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer,
-                           overlap_wgrad=not args.no_overlap_wgrad, overlap_optimizer=not args.no_overlap_opt)
+                           overlap_wgrad=not args.no_overlap_wgrad, overlap_optimizer=not args.no_overlap_opt, ddp_mode=args.ddp_mode)
     if reducer is not None:
         end = ddp.check_bucket_cover(step.plan.bucket_after, model.layout.n_total)
         assert end == model.layout.spec["bert.embeddings.token_type_embeddings.weight"].offset, end
@@ -347,7 +350,9 @@ def main():
                        "global_batch": args.batch * world, "seq_len": args.seq,
                        "image": f"3x{cfg.image.image_size}x{cfg.image.image_size}",
                        "params": model.layout.n_total, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else ("hipGraph" if reducer is None else "hipGraph per backward segment + RCCL all-reduce"),
+                       "launch": "eager" if args.no_graph else ("hipGraph" if reducer is None else
+                                                                ("forward hipGraph + stream-ordered backward launches, RCCL all-reduce per completed gradient slice"
+                                                                 if step.ddp_stream else "hipGraph per backward segment + RCCL all-reduce")),
                        "kernel_launches_per_step": plan.n_launches, "final_loss": round(final_loss, 5),
                        "masks": "all ones" if args.full_masks else "ragged, valid length ~ U{8..seq} (SURVEY 8d)",
                        "optimizer": f"Adam lr 2e-5, dense semantics over all {model.layout.n_total / 1e6:.1f} M parameters every step (word-embedding rows "

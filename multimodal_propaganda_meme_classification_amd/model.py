@@ -909,13 +909,20 @@ class GraphedStep:
     """Whole fine-tune step (forward, loss, backward, clip, Adam) captured into hipGraphs and
     replayed per batch, so the ~600 kernel launches of a step cost a handful of host calls.
 
-    Single GPU: ONE graph.  Data parallel (``reducer`` given): one graph for forward+loss, one per
-    backward segment, one for the optimizer; after each backward segment's graph is launched the
-    gradient slice it completed is handed to the RCCL all-reduce, which overlaps the next segment.
+    Single GPU: ONE graph.  Data parallel (``reducer`` given), ``ddp_mode``:
+
+    * ``"stream"`` (default): the forward + loss is one graph; the backward is launched eagerly with exactly the
+      single-GPU two-stream schedule (weight-gradient GEMMs on a side stream, no joins between layers), and as soon as a
+      bucket's gradient slice is complete -- its segment's main-stream work and its weight-gradient event -- the RCCL
+      all-reduce of that slice is issued behind a fence stream and, behind the all-reduce, that slice's Adam update.  The
+      ~140 prepared launches of a backward cost the host < 1 ms, well under the GPU time of the forward graph that
+      precedes them, so the launch stream stays ahead of the GPU.
+    * ``"segments"``: one graph per backward segment (pairs of layers), the all-reduce issued between graph launches.
+      Every graph boundary joins all streams, which costs 6-9 % at one rank.
     """
 
     def __init__(self, model: MultimodalClassifier, optimizer: Adam, batch: int, seq_len: int, use_graph: bool = True,
-                 reducer=None, overlap_wgrad: bool = True, overlap_optimizer: bool = True):
+                 reducer=None, overlap_wgrad: bool = True, overlap_optimizer: bool = True, ddp_mode: Optional[str] = None):
         self.model, self.opt = model, optimizer
         optimizer._model = model
         eng = model._get_engine()
@@ -927,20 +934,26 @@ class GraphedStep:
         if reducer is not None:
             optimizer.grad_scale = reducer.grad_scale
         self.graphs = None
-        # single GPU: weight-gradient GEMMs run on a second stream beside the LayerNorm / attention / dgrad chain
-        self.side = torch.cuda.Stream() if ((overlap_wgrad or overlap_optimizer) and reducer is None) else None
+        import os
+        ddp_mode = ddp_mode or os.environ.get("MEMEHIP_DDP_MODE", "stream")
+        if ddp_mode not in ("stream", "segments"):
+            raise ValueError(f"ddp_mode must be 'stream' or 'segments', got {ddp_mode!r}")
+        self.ddp_stream = reducer is not None and ddp_mode == "stream"
+        # weight-gradient GEMMs run on a second stream beside the LayerNorm / attention / dgrad chain
+        self.side = torch.cuda.Stream() if ((overlap_wgrad or overlap_optimizer) and (reducer is None or self.ddp_stream)) else None
+        self.ddp_fence = torch.cuda.Stream() if self.ddp_stream else None
         self.wgrad_side = bool(overlap_wgrad)
         # optimizer-in-backward: the (HBM-bound) Adam update of a layer pair's matrices follows their weight-gradient
         # GEMMs on the side stream, under the (MFMA-bound) backward chain of the layers below; only the tail
         # (embeddings, biases, head) is updated after the backward.  Needs no global clip and a single GPU.
-        self.opt_in_bwd = bool(overlap_optimizer and self.side is not None and optimizer.max_grad_norm is None
+        self.opt_in_bwd = bool(overlap_optimizer and self.side is not None and reducer is None and optimizer.max_grad_norm is None
                                and not optimizer.skip_nonfinite)
         # data parallel: the same idea behind the all-reduce -- as soon as a layer pair's gradient slice has been summed
         # over the ranks, its Adam update runs on a side stream under the backward of the layers below
         self.ddp_opt_in_bwd = bool(overlap_optimizer and reducer is not None and optimizer.max_grad_norm is None
                                    and not optimizer.skip_nonfinite)
         self.ddp_side = torch.cuda.Stream() if self.ddp_opt_in_bwd else None
-        self.ddp_wside = torch.cuda.Stream() if (reducer is not None and overlap_wgrad) else None
+        self.ddp_wside = torch.cuda.Stream() if (reducer is not None and overlap_wgrad and not self.ddp_stream) else None
 
     # ---- pieces ------------------------------------------------------------------------------------------
     def _pieces(self):
@@ -952,7 +965,7 @@ class GraphedStep:
                 p.fwd.run2(torch.cuda.current_stream(), None, {})
             p.loss.run(stream)
         pieces = [("fwd", fwd, None)]
-        if self.side is None:
+        if self.side is None and not self.ddp_stream:
             # data parallel: `ddp_group` consecutive layer segments share one hipGraph and one all-reduce bucket (their
             # gradient ranges are adjacent in the flat buffer): fewer graph boundaries, larger RCCL messages
             import os
@@ -1004,10 +1017,55 @@ class GraphedStep:
                 main = torch.cuda.current_stream()
                 events = {}
                 done = []
+                red = self.reducer if self.ddp_stream else None
+                import os
+                group = max(1, int(os.environ.get("MEMEHIP_DDP_GROUP", "2")))
+                n_layer_segs = sum(1 for sg in p.bwd if sg.name.startswith("bwd_layer_"))
+                pend, pend_ev, seen = [], [], 0
+
+                def flush():
+                    """all-reduce the union of the pending (adjacent) gradient ranges once everything that writes them has
+                    been issued: the fence stream waits for the main stream's position and the segments' weight-gradient
+                    events, the collective is enqueued behind the fence, the slice's Adam update behind the collective."""
+                    if not pend:
+                        return
+                    rng = (min(r[0] for r in pend), max(r[1] for r in pend))
+                    layer_rngs = list(pend)
+                    self.ddp_fence.wait_stream(main)
+                    for ev in pend_ev:
+                        self.ddp_fence.wait_event(ev)
+                    with torch.cuda.stream(self.ddp_fence):
+                        works = red.reduce_range(rng)
+                    if self.ddp_opt_in_bwd and pend_layer[0]:
+                        with torch.cuda.stream(self.ddp_side):
+                            for w in works:
+                                w.wait()
+                            for r in layer_rngs:
+                                self.opt.launch(only=r)
+                        done.extend(layer_rngs)
+                    pend.clear(); pend_ev.clear(); pend_layer[0] = True
+
+                pend_layer = [True]       # every pending range belongs to a layer segment (its Adam slice may run early)
                 for seg in p.bwd:
+                    if red is not None and seg.name == "bwd_embed_tables":      # needs every rank's ids + gradient rows first
+                        red.gather(p.gather)
                     seg.run2(main, self.side if self.wgrad_side else None, events)
                     rng = p.bucket_after.get(seg.name)
-                    if self.opt_in_bwd and seg.name.startswith("bwd_layer_") and rng is not None:
+                    is_layer = seg.name.startswith("bwd_layer_")
+                    if red is not None:
+                        if rng is not None:
+                            if is_layer:
+                                seen += 1
+                            pend.append(rng)
+                            pend_layer[0] = pend_layer[0] and is_layer
+                            if seg.name in events:
+                                pend_ev.append(events[seg.name])
+                            # the last two layers (and everything that is not a layer) go out on their own, so the
+                            # all-reduce left exposed after the backward stays small
+                            if (not is_layer) or len(pend) >= group or seen > n_layer_segs - 2:
+                                flush()
+                        continue
+                    if self.opt_in_bwd and is_layer and rng is not None:
                         if seg.name not in events:      # weight gradients ran on the main stream: fork behind them
                             e = torch.cuda.Event()
                             e.record(main)
@@ -1018,11 +1076,13 @@ class GraphedStep:
                         ev.record(self.side)
                         events[seg.name] = ev
                         done.append(rng)
+                if red is not None:
+                    flush()
                 for ev in events.values():      # join before the optimizer reads the remaining gradients
                     main.wait_event(ev)
                 self._opt_done = done
             pieces.append(("bwd", bwd, None))
-        if self.ddp_opt_in_bwd:
+        if self.ddp_opt_in_bwd and not self.ddp_stream:
             self._opt_done = [p.bucket_after[seg.name] for seg in p.bwd
                               if seg.name.startswith("bwd_layer_") and p.bucket_after.get(seg.name) is not None]
         pieces.append(("opt", lambda stream: self.opt.launch(skip=getattr(self, "_opt_done", None)), None))
@@ -1048,7 +1108,7 @@ class GraphedStep:
             if name == "opt" and self.reducer is not None:
                 self.reducer.wait()
             fn(stream)
-            if self.reducer is not None:
+            if self.reducer is not None and not self.ddp_stream:
                 self._after_segment(name, rng)
         if self.ddp_side is not None:
             torch.cuda.current_stream().wait_stream(self.ddp_side)
@@ -1077,6 +1137,16 @@ class GraphedStep:
         else:
             if self.graphs is None:
                 self._capture()
+            if self.ddp_stream:       # forward graph, then the backward + optimizer as stream-ordered eager launches
+                self.graphs[0][0].replay()
+                stream = torch.cuda.current_stream().cuda_stream
+                for name, fn, rng in self._tail:
+                    if name == "opt":
+                        self.reducer.wait()
+                    fn(stream)
+                if self.ddp_side is not None:
+                    torch.cuda.current_stream().wait_stream(self.ddp_side)
+                return self.plan.buf["loss"], self.plan.buf["ncorrect"]
             for g, name, rng in self.graphs:
                 if name == "gather":
                     self.reducer.gather(self.plan.gather)
@@ -1095,6 +1165,7 @@ class GraphedStep:
         # it does not count as a training step; then capture the same launches
         f = self.opt._flat
         snap = (f["P"].clone(), f["M"].clone(), f["V"].clone())
+        counters = (self.reducer.reduced_elems, self.reducer.wire_bytes) if self.reducer is not None else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -1103,16 +1174,28 @@ class GraphedStep:
                 if name == "gather":
                     self.reducer.gather(self.plan.gather)
                 else:
+                    if name == "opt" and self.ddp_stream:
+                        self.reducer.wait()
                     fn(stream)
+            if self.ddp_side is not None and self.ddp_stream:
+                s.wait_stream(self.ddp_side)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         f["P"].copy_(snap[0]); f["M"].copy_(snap[1]); f["V"].copy_(snap[2])
+        if counters is not None:      # (the stream schedule's warm-up ran the collectives for real)
+            self.reducer.reduced_elems, self.reducer.wire_bytes = counters
         self.model.refresh_shadow()
         # (the warm-up left prev_ids == ids, so the first real step re-zeroes exactly the embedding-gradient
         #  rows the warm-up wrote)
         pieces = self._pieces()
         graphs = []
-        if self.reducer is None:
+        if self.ddp_stream:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                pieces[0][1](torch.cuda.current_stream().cuda_stream)
+            graphs.append((g, "fwd", None))
+            self._tail = pieces[1:]
+        elif self.reducer is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 stream = torch.cuda.current_stream().cuda_stream

@@ -247,10 +247,12 @@ def test_config3_logits_match_golden_and_oracle(pkg, golden_dir):
 
 
 @pytest.mark.parametrize("clip", [1.0, None])
-def test_ddp_segmented_graph_path_world1(pkg, clip):
-    """The N > 1 code path (one hipGraph per backward segment, bucketed async all-reduce between them, 1/world
-    folded into Adam; without clipping: each slice's Adam update on a side stream behind its all-reduce) on a
-    1-rank RCCL group: must reproduce the single-graph step bit for bit."""
+@pytest.mark.parametrize("ddp_mode", ["stream", "segments"])
+def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode):
+    """The N > 1 code path on a 1-rank RCCL group, both schedules -- "stream": forward graph + eagerly launched two-stream
+    backward with the all-reduce of every completed gradient slice behind a fence stream; "segments": one hipGraph per
+    backward segment, the all-reduce between graph launches -- with 1/world folded into Adam and, without clipping, each
+    slice's Adam update on a side stream behind its all-reduce: must reproduce the single-graph step bit for bit."""
     import torch.distributed as dist
     from multimodal_propaganda_meme_classification_amd import ddp
     O = _oracle()
@@ -258,7 +260,7 @@ def test_ddp_segmented_graph_path_world1(pkg, clip):
     text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=11)
     dev = [t.cuda() for t in (text, image, mask, labels)]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(29600 + (os.getpid() + (0 if clip else 151)) % 300)      # a fresh port per group
+    os.environ["MASTER_PORT"] = str(29600 + (os.getpid() + (0 if clip else 151) + (0 if ddp_mode == "stream" else 77)) % 300)      # a fresh port per group
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         m1, _ = _make(pkg, O, cfg, 13)
@@ -268,7 +270,7 @@ def test_ddp_segmented_graph_path_world1(pkg, clip):
         ddp.broadcast_parameters(m2.flat_params)
         red = ddp.GradientReducer(m2.flat_grads, bucket_cap_elems=1 << 16)
         g1 = pkg.GraphedStep(m1, o1, 4, 16)
-        g2 = pkg.GraphedStep(m2, o2, 4, 16, reducer=red)
+        g2 = pkg.GraphedStep(m2, o2, 4, 16, reducer=red, ddp_mode=ddp_mode)
         assert g2.ddp_opt_in_bwd == (clip is None)
         end = ddp.check_bucket_cover(g2.plan.bucket_after, m2.layout.n_total)
         assert end == m2.layout.spec["bert.embeddings.token_type_embeddings.weight"].offset   # tables go by gather
@@ -280,7 +282,11 @@ def test_ddp_segmented_graph_path_world1(pkg, clip):
             torch.cuda.synchronize()
             assert float(l1) == float(l2)
             assert torch.equal(m1.flat_params, m2.flat_params)
-        assert red.reduced_elems == 3 * end and 4 <= len(g2.graphs) <= len(g2.plan.bwd) + 3   # fwd, opt, gather marker + segments (paired)
+        assert red.reduced_elems == 3 * end
+        if ddp_mode == "stream":
+            assert len(g2.graphs) == 1       # the forward; the backward is stream-ordered eager launches
+        else:
+            assert 4 <= len(g2.graphs) <= len(g2.plan.bwd) + 3   # fwd, opt, gather marker + segments (paired)
     finally:
         dist.destroy_process_group()
 
