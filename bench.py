@@ -54,8 +54,8 @@ def parse():
     ap.add_argument("--force-ddp", action="store_true",
                     help="debug: run the data-parallel code path (segmented graphs, RCCL all-reduce) on a 1-rank group")
     ap.add_argument("--ddp-mode", choices=("stream", "segments"), default=None,
-                    help="data-parallel schedule (default: MEMEHIP_DDP_MODE or 'stream'): forward graph + stream-ordered eager "
-                         "backward with the all-reduces behind a fence stream, or one hipGraph per backward segment")
+                    help="data-parallel schedule (default: MEMEHIP_DDP_MODE or 'segments'): one hipGraph per backward segment, or forward "
+                         "graph + stream-ordered eager backward with the all-reduces behind a fence stream")
     ap.add_argument("--ddp-compress", choices=("none", "bf16"), default="none",
                     help="N > 1: wire format of the gradient exchange: fp32 all-reduce (default) or bf16 with fp32 accumulation on "
                          "receipt (all-to-all + all-gather, half the bytes)")

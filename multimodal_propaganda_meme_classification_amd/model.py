@@ -911,14 +911,14 @@ class GraphedStep:
 
     Single GPU: ONE graph.  Data parallel (``reducer`` given), ``ddp_mode``:
 
-    * ``"stream"`` (default): the forward + loss is one graph; the backward is launched eagerly with exactly the
-      single-GPU two-stream schedule (weight-gradient GEMMs on a side stream, no joins between layers), and as soon as a
-      bucket's gradient slice is complete -- its segment's main-stream work and its weight-gradient event -- the RCCL
-      all-reduce of that slice is issued behind a fence stream and, behind the all-reduce, that slice's Adam update.  The
-      ~140 prepared launches of a backward cost the host < 1 ms, well under the GPU time of the forward graph that
-      precedes them, so the launch stream stays ahead of the GPU.
-    * ``"segments"``: one graph per backward segment (pairs of layers), the all-reduce issued between graph launches.
-      Every graph boundary joins all streams, which costs 6-9 % at one rank.
+    * ``"segments"`` (default): one graph per backward segment (pairs of layers), the all-reduce issued between graph
+      launches.  Every graph boundary joins all streams; measured 10.55 ms against 9.91 for the single graph at one rank.
+    * ``"stream"``: the forward + loss is one graph; the backward is launched eagerly with exactly the single-GPU two-stream
+      schedule (weight-gradient GEMMs on a side stream, no joins between layers), and as soon as a bucket's gradient slice
+      is complete -- its segment's main-stream work and its weight-gradient event -- the all-reduce of that slice is issued
+      behind a fence stream and, behind the all-reduce, that slice's Adam update.  The host issues a step in 5.1 ms, so it
+      stays ahead of the GPU, but eagerly launched cross-stream edges resolve more slowly than a graph's (10-35 us gaps in
+      the kernel trace): 10.82 ms at one rank.  Kept for multi-rank A/B.
     """
 
     def __init__(self, model: MultimodalClassifier, optimizer: Adam, batch: int, seq_len: int, use_graph: bool = True,
@@ -935,7 +935,7 @@ class GraphedStep:
             optimizer.grad_scale = reducer.grad_scale
         self.graphs = None
         import os
-        ddp_mode = ddp_mode or os.environ.get("MEMEHIP_DDP_MODE", "stream")
+        ddp_mode = ddp_mode or os.environ.get("MEMEHIP_DDP_MODE", "segments")
         if ddp_mode not in ("stream", "segments"):
             raise ValueError(f"ddp_mode must be 'stream' or 'segments', got {ddp_mode!r}")
         self.ddp_stream = reducer is not None and ddp_mode == "stream"
