@@ -201,6 +201,7 @@ def bench_config2(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
+    t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     value = args.batch * args.steps / dt
@@ -211,7 +212,8 @@ def bench_config2(args):
            "config": {"workload": f"Subtask-2B fine-tune step: torchvision-topology ResNet-50 (25.6 M parameters), 3x224x224, batch {args.batch}, "
                                   "fwd+CE+bwd+Adam, train-mode BatchNorm, random-init weights; convolutions = MFMA GEMM over explicit NHWC im2col",
                       "global_batch": args.batch, "image": "3x224x224", "parallelism": "dp1",
-                      "launch": "eager" if args.no_graph else "hipGraph", "final_loss": round(float(loss_buf), 5)},
+                      "launch": "eager" if args.no_graph else "hipGraph", "final_loss": round(float(loss_buf), 5),
+                      "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
            "roofline": {"bound": "mfma", "kernel": "whole step (conv GEMMs + im2col / BatchNorm passes)",
                         "achieved": round(flop_per_image * value / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flop_per_image * value / (MFMA_PEAK_TFLOPS * 1e12), 4), "traffic": None}}

@@ -423,7 +423,8 @@ int mh_softmax_gate_bwd(const float* g, const float* c, const float* dy, float* 
  *   wgrad = the GEMM in the wgrad layout over the im2col matrix, un-packed by mh_conv_weight_unpack.
  * mh_bn2d_fwd / mh_bn2d_bwd: nn.BatchNorm2d over that matrix (M = B*H*W rows), training mode = per-replica batch
  *   statistics (biased variance for the normalisation, unbiased for the running statistics, momentum form), optional fused
- *   residual add and ReLU: y = relu(bn(x) + residual).  workspace: f32, >= (ceil(M/128) * 2 + 2) * C elements.
+ *   residual add and ReLU: y = relu(bn(x) + residual).  workspace: f32, >= mh_bn2d_workspace_elems(M, C) elements (the
+ *   statistics are per-block partial sums; the rows per block shrink with M so that deep, narrow-M layers still fill the chip).
  *   bwd: dx, the residual-branch gradient dres (= dy masked by the ReLU), dgamma, dbeta (times `scale`).
  * mh_maxpool_* (k x k / stride / pad, first maximum wins, arg = tap index), mh_avgpool_* (global), mh_nchw_to_nhwc (f32 image
  * -> 16-bit NHWC with the channels zero-padded to Cp), mh_add_h16.
@@ -437,14 +438,40 @@ int mh_conv_weight_pack(const float* w /*[Cout][Cin][KH][KW]*/, void* out /*16-b
                         int Cp, int ldk, mh_stream_t stream);
 int mh_conv_weight_unpack(const float* gk /*[Cout][ldk]*/, float* g /*[Cout][Cin][KH][KW]*/, int Cout, int Cin, int KH, int KW, int Cp,
                           int ldk, float scale, mh_stream_t stream);
+/* Every convolution of a tower in one launch (a ResNet-50 step has 53 weight packs and 53 weight-gradient finishes; at 5 us
+ * of work each the launch latency is what they cost).  block_start is filled in by the library.
+ * mh_conv_wgrad_finish_batched: g[Cout][Cin][KH][KW] (+)= scale * sum_s slabs[s][Cout][ldk] -- the fixed-order sum of the
+ * split-K slabs of the weight-gradient GEMM (nsplit = 1: its plain f32 output) un-packed to the torch layout, optionally
+ * accumulated into an existing .grad (autograd's accumulate semantics without a separate add launch per parameter). */
+#define MH_CONV_MAX_JOBS 64
+typedef struct MhConvPackJob {
+    const float* w;   /* [Cout][Cin][KH][KW] f32 */
+    void* out;        /* 16-bit [Cout][ldk] */
+    int32_t Cout, Cin, KH, KW, Cp, ldk;
+    int32_t block_start, reserved_;
+} MhConvPackJob;
+typedef struct MhConvWgradJob {
+    const float* slabs;   /* [nsplit][Cout][ldk] f32 */
+    float* g;             /* [Cout][Cin][KH][KW] f32 */
+    int32_t Cout, Cin, KH, KW, Cp, ldk;
+    int32_t nsplit, accumulate;
+    float scale;
+    int32_t block_start;
+} MhConvWgradJob;
+int mh_conv_weight_pack_batched(const MhConvPackJob* jobs, int n, mh_stream_t stream);
+int mh_conv_wgrad_finish_batched(const MhConvWgradJob* jobs, int n, mh_stream_t stream);
+int64_t mh_bn2d_workspace_elems(int M, int C);
+/* mh_bn2d_bwd flags */
+#define MH_BN_RELU 1
+#define MH_BN_ACCUM_PARAM_GRADS 2   /* dgamma / dbeta are added to, not overwritten */
 int mh_bn2d_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, const void* residual,
                 void* y, float* save_mean, float* save_rstd, float* workspace, int M, int C, float eps, float momentum, int training,
                 int relu, mh_stream_t stream);
 int mh_bn2d_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const void* residual,
                   void* y, int M, int C, int relu, mh_stream_t stream);
 int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean, const float* save_rstd,
-                void* dx, void* dres, float* dgamma, float* dbeta, float* workspace, int M, int C, int relu, float scale,
-                mh_stream_t stream);
+                void* dx, void* dres, float* dgamma, float* dbeta, float* workspace, int M, int C, int flags /* MH_BN_* */,
+                float scale, mh_stream_t stream);
 int mh_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad, mh_stream_t stream);
 int mh_maxpool_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, int K, int stride, int pad,
                    mh_stream_t stream);

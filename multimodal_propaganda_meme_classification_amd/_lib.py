@@ -40,6 +40,19 @@ class MhColsumJob(C.Structure):
     _fields_ = [("part", c_void_p), ("out0", c_void_p), ("out1", c_void_p)]
 
 
+class MhConvPackJob(C.Structure):
+    _fields_ = [("w", c_void_p), ("out", c_void_p)] + [(n, C.c_int32) for n in ("Cout", "Cin", "KH", "KW", "Cp", "ldk", "block_start", "reserved_")]
+
+
+class MhConvWgradJob(C.Structure):
+    _fields_ = [("slabs", c_void_p), ("g", c_void_p)] + [(n, C.c_int32) for n in ("Cout", "Cin", "KH", "KW", "Cp", "ldk", "nsplit", "accumulate")] + \
+               [("scale", C.c_float), ("block_start", C.c_int32)]
+
+
+MH_CONV_MAX_JOBS = 64
+MH_BN_RELU, MH_BN_ACCUM_PARAM_GRADS = 1, 2
+
+
 class MhLnFwdJob(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "gamma", "beta", "y", "y_f32", "mean", "rstd")] + \
                [("rows", C.c_int32), ("eps", C.c_float), ("rows_dev", c_void_p)]
@@ -136,6 +149,9 @@ _PROTOS = {
     "mh_col2im_nhwc": [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p],
     "mh_conv_weight_pack": [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
     "mh_conv_weight_unpack": [c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p],
+    "mh_conv_weight_pack_batched": [C.POINTER(MhConvPackJob), c_int, c_void_p],
+    "mh_conv_wgrad_finish_batched": [C.POINTER(MhConvWgradJob), c_int, c_void_p],
+    "mh_bn2d_workspace_elems": [c_int, c_int],
     "mh_bn2d_fwd": [c_void_p] * 10 + [c_int, c_int, c_float, c_float, c_int, c_int, c_void_p],
     "mh_bn2d_apply": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p],
     "mh_bn2d_bwd": [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p],
@@ -155,7 +171,7 @@ _PROTOS = {
     "mh_version": [],
     "mh_status_str": [c_int],
 }
-_RESTYPES = {"mh_version": C.c_char_p, "mh_status_str": C.c_char_p}
+_RESTYPES = {"mh_version": C.c_char_p, "mh_status_str": C.c_char_p, "mh_bn2d_workspace_elems": c_int64}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

@@ -97,13 +97,76 @@ __global__ __launch_bounds__(256) void weight_unpack_kernel(const float* __restr
     g[idx] = scale * gk[(size_t)co * ldk + (size_t)(kh * KW + kw) * Cp + ci];
 }
 
+// ---- the same for every convolution of a tower in ONE launch (a ResNet-50 step has 53 of each: launch latency, not bytes,
+// is what they cost).  Jobs ride in the kernel argument; block b belongs to the last job whose block_start <= b.
+struct PackJobs {
+    int n;
+    int pad_;
+    MhConvPackJob j[MH_CONV_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void weight_pack_batched_kernel(const PackJobs J) {
+    int ji = 0;
+    for (int i = 1; i < J.n; ++i)
+        if ((int)blockIdx.x >= J.j[i].block_start) ji = i;
+    const MhConvPackJob& q = J.j[ji];
+    const uint32_t idx = (uint32_t)(blockIdx.x - q.block_start) * 256u + threadIdx.x;      // (a job has < 2^31 elements: checked on the host)
+    if (idx >= (uint32_t)q.Cout * (uint32_t)q.ldk) return;
+    const uint32_t co = idx / (uint32_t)q.ldk, k = idx - co * (uint32_t)q.ldk;
+    float v = 0.f;
+    if (k < (uint32_t)(q.KH * q.KW * q.Cp)) {
+        const uint32_t tap = k / (uint32_t)q.Cp, ci = k - tap * (uint32_t)q.Cp;
+        if (ci < (uint32_t)q.Cin) v = q.w[((size_t)co * q.Cin + ci) * (q.KH * q.KW) + tap];      // [kh][kw] flattened = tap
+    }
+    ((h16*)q.out)[idx] = mh_f2bf(v);
+}
+// weight gradient of every convolution: g[Cout][Cin][KH][KW] (+)= scale * sum over the split-K slabs (fixed order) of
+// gk[s][Cout][ldk]
+struct FinishJobs {
+    int n;
+    int pad_;
+    MhConvWgradJob j[MH_CONV_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void wgrad_finish_batched_kernel(const FinishJobs J) {
+    int ji = 0;
+    for (int i = 1; i < J.n; ++i)
+        if ((int)blockIdx.x >= J.j[i].block_start) ji = i;
+    const MhConvWgradJob& q = J.j[ji];
+    // threads walk the SLAB order (co, tap, ci): the nsplit reads are coalesced, the one write per element is strided by KH*KW
+    const uint32_t taps = (uint32_t)(q.KH * q.KW), per_co = taps * (uint32_t)q.Cin;
+    const uint32_t idx = (uint32_t)(blockIdx.x - q.block_start) * 256u + threadIdx.x;
+    if (idx >= (uint32_t)q.Cout * per_co) return;
+    const uint32_t co = idx / per_co, r = idx - co * per_co;
+    const uint32_t tap = r / (uint32_t)q.Cin, ci = r - tap * (uint32_t)q.Cin;
+    const size_t src = (size_t)co * q.ldk + (size_t)tap * q.Cp + ci;
+    const size_t slab = (size_t)q.Cout * q.ldk;
+    float acc = 0.f;
+    for (int sidx = 0; sidx < q.nsplit; ++sidx) acc += q.slabs[(size_t)sidx * slab + src];
+    acc *= q.scale;
+    float* dst = q.g + ((size_t)co * q.Cin + ci) * taps + tap;
+    if (q.accumulate) acc += *dst;
+    *dst = acc;
+}
+
 // ---- BatchNorm2d over a [M][C] 16-bit matrix (M = B*H*W) ---------------------------------------------------------
-// stats pass: block b sums rows [b*RPB, ..): part[b][0][c] = sum x, part[b][1][c] = sum x^2 (f32; RPB rows keep the sums
+// stats pass: block b sums rows [b*RPB, ..): part[0][c][b] = sum x, part[1][c][b] = sum x^2 -- block index fastest, so the
+// finish kernel (a wave per channel, the lanes over the blocks) reads its partials coalesced -- (f32; RPB rows keep the sums
 // small); finish in double.  grid (ceil(C/256)... thread = 8 channels) x nblk
-constexpr int BN_RPB = 128;
+constexpr int BN_RPB_MAX = 128;
+// rows per block: 128 for the wide early layers, fewer for the deep ones (M = B*7*7 = 1568 rows x 2048 channels would be 13
+// blocks of 128 sequential row loads each -- 82 us for 19 MB), so that a launch has ~500 blocks; a multiple of the block's
+// row lanes (256 threads / min(C/8, 256) channel groups)
+static int bn_rpb(int M, int C) {
+    const int c8 = C / 8, c8w = c8 < 256 ? c8 : 256, nty = 256 / c8w;
+    int rpb = (M + 511) / 512;
+    rpb = (rpb + nty - 1) / nty * nty;
+    if (rpb < nty) rpb = nty;
+    if (rpb > BN_RPB_MAX) rpb = BN_RPB_MAX;
+    return rpb;
+}
 // thread layout of the two statistics kernels: tx = 8-channel group (c8w = min(C/8, 256) of them per block), ty = row lane
 // (256 / c8w of them): narrow layers (C = 64: 8 groups) still use all 256 threads; partial sums meet in LDS.
-MH_DEV void bn_block_reduce(float (&s)[8], float (&q)[8], float* __restrict__ part, int blk, int C, int t, int ty, int nty, int c8w) {
+MH_DEV void bn_block_reduce(float (&s)[8], float (&q)[8], float* __restrict__ part, int blk, int nblk, int C, int t, int ty, int nty,
+                            int c8w) {
     __shared__ float red[256][17];
     const int tid = threadIdx.x;
 #pragma unroll
@@ -114,18 +177,18 @@ MH_DEV void bn_block_reduce(float (&s)[8], float (&q)[8], float* __restrict__ pa
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += red[tid + y * c8w][e]; q[e] += red[tid + y * c8w][8 + e]; }
         }
-        float* p0 = part + ((size_t)blk * 2) * C + t * 8;
-        float* p1 = p0 + C;
+        float* p0 = part + (size_t)(t * 8) * nblk + blk;
+        float* p1 = p0 + (size_t)C * nblk;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { p0[e] = s[e]; p1[e] = q[e]; }
+        for (int e = 0; e < 8; ++e) { p0[(size_t)e * nblk] = s[e]; p1[(size_t)e * nblk] = q[e]; }
     }
 }
-__global__ __launch_bounds__(256) void bn2d_stats_kernel(const h16* __restrict__ x, float* __restrict__ part, int M, int C) {
+__global__ __launch_bounds__(256) void bn2d_stats_kernel(const h16* __restrict__ x, float* __restrict__ part, int M, int C, int rpb) {
     const int c8 = C / 8, c8w = min(c8, 256), nty = 256 / c8w;
     const int tx = threadIdx.x % c8w, ty = threadIdx.x / c8w;
     const int t = blockIdx.x * c8w + tx;
     const int blk = blockIdx.y;
-    const int r0 = blk * BN_RPB, r1 = min(M, r0 + BN_RPB);
+    const int r0 = blk * rpb, r1 = min(M, r0 + rpb);
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (t < c8 && ty < nty) {
         for (int r = r0 + ty; r < r1; r += nty) {
@@ -139,7 +202,7 @@ __global__ __launch_bounds__(256) void bn2d_stats_kernel(const h16* __restrict__
             }
         }
     }
-    bn_block_reduce(s, q, part, blk, C, t < c8 ? t : C, ty, nty, c8w);
+    bn_block_reduce(s, q, part, blk, (int)gridDim.y, C, t < c8 ? t : C, ty, nty, c8w);
 }
 MH_DEV double wave_sum_f64(double v) {
 #pragma unroll
@@ -155,8 +218,8 @@ __global__ __launch_bounds__(256) void bn2d_finish_kernel(const float* __restric
     if (c >= C) return;
     double s = 0.0, q = 0.0;
     for (int b = lane; b < nblk; b += 64) {
-        s += (double)part[((size_t)b * 2) * C + c];
-        q += (double)part[((size_t)b * 2 + 1) * C + c];
+        s += (double)part[(size_t)c * nblk + b];
+        q += (double)part[((size_t)C + c) * nblk + b];
     }
     s = wave_sum_f64(s);
     q = wave_sum_f64(q);
@@ -202,12 +265,12 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const h16* __restrict__
 __global__ __launch_bounds__(256) void bn2d_bwd_stats_kernel(const h16* __restrict__ dy, const h16* __restrict__ x,
                                                              const h16* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, float* __restrict__ part, int M,
-                                                             int C, int relu) {
+                                                             int C, int relu, int rpb) {
     const int c8 = C / 8, c8w = min(c8, 256), nty = 256 / c8w;
     const int tx = threadIdx.x % c8w, ty = threadIdx.x / c8w;
     const int t = blockIdx.x * c8w + tx;
     const int blk = blockIdx.y;
-    const int r0 = blk * BN_RPB, r1 = min(M, r0 + BN_RPB);
+    const int r0 = blk * rpb, r1 = min(M, r0 + rpb);
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (t < c8 && ty < nty) {
         float mu[8], rs[8];
@@ -228,25 +291,26 @@ __global__ __launch_bounds__(256) void bn2d_bwd_stats_kernel(const h16* __restri
             }
         }
     }
-    bn_block_reduce(s, q, part, blk, C, t < c8 ? t : C, ty, nty, c8w);
+    bn_block_reduce(s, q, part, blk, (int)gridDim.y, C, t < c8 ? t : C, ty, nty, c8w);
 }
 __global__ __launch_bounds__(256) void bn2d_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, float scale,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ sums /*[2][C]: sum dy', sum dy' xhat*/) {
+                                                              float* __restrict__ sums /*[2][C]: sum dy', sum dy' xhat*/,
+                                                              int accumulate) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
     for (int b = lane; b < nblk; b += 64) {
-        s += (double)part[((size_t)b * 2) * C + c];
-        q += (double)part[((size_t)b * 2 + 1) * C + c];
+        s += (double)part[(size_t)c * nblk + b];
+        q += (double)part[((size_t)C + c) * nblk + b];
     }
     s = wave_sum_f64(s);
     q = wave_sum_f64(q);
     if (lane != 0) return;
     sums[c] = (float)s;
     sums[C + c] = (float)q;
-    if (dbeta) dbeta[c] = (float)s * scale;
-    if (dgamma) dgamma[c] = (float)q * scale;
+    if (dbeta) dbeta[c] = (float)s * scale + (accumulate ? dbeta[c] : 0.f);
+    if (dgamma) dgamma[c] = (float)q * scale + (accumulate ? dgamma[c] : 0.f);
 }
 // dx = gamma rstd (dy' - mean(dy') - xhat mean(dy' xhat)) ; dres = dy' (the gradient of the residual branch), optional
 __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const h16* __restrict__ dy, const h16* __restrict__ x,
@@ -419,6 +483,49 @@ extern "C" int mh_conv_weight_unpack(const float* gk, float* g, int Cout, int Ci
                        Cin, KH, KW, Cp, ldk, scale);
     return mh_launch_status();
 }
+extern "C" int mh_conv_weight_pack_batched(const MhConvPackJob* jobs, int n, mh_stream_t stream) {
+    if (!jobs || n < 1 || n > MH_CONV_MAX_JOBS) return MH_EINVAL;
+    PackJobs J;
+    J.n = n;
+    J.pad_ = 0;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        MhConvPackJob q = jobs[i];
+        if (!q.w || !q.out) return MH_EINVAL;
+        if (q.Cout < 1 || q.Cin < 1 || q.KH < 1 || q.KW < 1 || q.Cp < q.Cin || q.ldk < q.KH * q.KW * q.Cp) return MH_ESHAPE;
+        if ((size_t)q.Cout * q.ldk >= 0x7fffffffULL) return MH_ESHAPE;
+        q.block_start = (int)total;
+        total += grid1((size_t)q.Cout * q.ldk);
+        J.j[i] = q;
+    }
+    if (total > 0x7fffffffL) return MH_ESHAPE;
+    hipLaunchKernelGGL(weight_pack_batched_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, J);
+    return mh_launch_status();
+}
+extern "C" int mh_conv_wgrad_finish_batched(const MhConvWgradJob* jobs, int n, mh_stream_t stream) {
+    if (!jobs || n < 1 || n > MH_CONV_MAX_JOBS) return MH_EINVAL;
+    FinishJobs J;
+    J.n = n;
+    J.pad_ = 0;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        MhConvWgradJob q = jobs[i];
+        if (!q.slabs || !q.g) return MH_EINVAL;
+        if (q.Cout < 1 || q.Cin < 1 || q.KH < 1 || q.KW < 1 || q.Cp < q.Cin || q.ldk < q.KH * q.KW * q.Cp || q.nsplit < 1) return MH_ESHAPE;
+        if ((size_t)q.Cout * q.Cin * q.KH * q.KW >= 0x7fffffffULL) return MH_ESHAPE;
+        q.block_start = (int)total;
+        total += grid1((size_t)q.Cout * q.Cin * q.KH * q.KW);
+        J.j[i] = q;
+    }
+    if (total > 0x7fffffffL) return MH_ESHAPE;
+    hipLaunchKernelGGL(wgrad_finish_batched_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, J);
+    return mh_launch_status();
+}
+extern "C" int64_t mh_bn2d_workspace_elems(int M, int C) {
+    if (M < 1 || C < 8 || (C % 8)) return 0;
+    const int rpb = bn_rpb(M, C);
+    return ((int64_t)((M + rpb - 1) / rpb) * 2 + 2) * C;
+}
 extern "C" int mh_bn2d_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                            const void* residual, void* y, float* save_mean, float* save_rstd, float* workspace, int M, int C, float eps,
                            float momentum, int training, int relu, mh_stream_t stream) {
@@ -427,8 +534,8 @@ extern "C" int mh_bn2d_fwd(const void* x, const float* gamma, const float* beta,
     hipStream_t s = (hipStream_t)stream;
     if (training) {
         if (!workspace) return MH_EINVAL;
-        const int nblk = (M + BN_RPB - 1) / BN_RPB;
-        hipLaunchKernelGGL(bn2d_stats_kernel, dim3((C / 8 + 255) / 256, nblk), dim3(256), 0, s, (const h16*)x, workspace, M, C);
+        const int rpb = bn_rpb(M, C), nblk = (M + rpb - 1) / rpb;
+        hipLaunchKernelGGL(bn2d_stats_kernel, dim3((C / 8 + 255) / 256, nblk), dim3(256), 0, s, (const h16*)x, workspace, M, C, rpb);
         hipLaunchKernelGGL(bn2d_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, M, C, eps, momentum, save_mean,
                            save_rstd, running_mean, running_var);
     } else {
@@ -450,16 +557,18 @@ extern "C" int mh_bn2d_apply(const void* x, const float* mean, const float* rstd
 }
 extern "C" int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
                            const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* workspace, int M, int C,
-                           int relu, float scale, mh_stream_t stream) {
+                           int flags, float scale, mh_stream_t stream) {
+    const int relu = (flags & MH_BN_RELU) ? 1 : 0, accumulate = (flags & MH_BN_ACCUM_PARAM_GRADS) ? 1 : 0;
     if (!dy || !x || !gamma || !save_mean || !save_rstd || !dx || !workspace) return MH_EINVAL;
     if (relu && !y) return MH_EINVAL;
     if (M < 1 || C < 8 || (C % 8)) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (M + BN_RPB - 1) / BN_RPB;
+    const int rpb = bn_rpb(M, C), nblk = (M + rpb - 1) / rpb;
     float* sums = workspace + (size_t)nblk * 2 * C;
     hipLaunchKernelGGL(bn2d_bwd_stats_kernel, dim3((C / 8 + 255) / 256, nblk), dim3(256), 0, s, (const h16*)dy, (const h16*)x,
-                       (const h16*)y, save_mean, save_rstd, workspace, M, C, relu);
-    hipLaunchKernelGGL(bn2d_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, scale, dgamma, dbeta, sums);
+                       (const h16*)y, save_mean, save_rstd, workspace, M, C, relu, rpb);
+    hipLaunchKernelGGL(bn2d_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, scale, dgamma, dbeta, sums,
+                       accumulate);
     hipLaunchKernelGGL(bn2d_bwd_apply_kernel, dim3(grid1((size_t)M * (C / 8))), dim3(256), 0, s, (const h16*)dy, (const h16*)x,
                        (const h16*)y, save_mean, save_rstd, gamma, sums, (h16*)dx, (h16*)dres, (size_t)M, C, relu);
     return mh_launch_status();

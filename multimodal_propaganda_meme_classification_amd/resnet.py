@@ -34,6 +34,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _grad_target(p: nn.Parameter, grads: dict):
+    """Where a parameter's gradient is written: straight into an existing f32 .grad (accumulated by the kernel; autograd gets
+    None for it -- no add launch per parameter), or a fresh tensor handed to autograd."""
+    g = p.grad
+    if g is not None and g.dtype == F32 and g.is_contiguous() and g.device == p.device:
+        grads[id(p)] = None
+        return g, True
+    g = torch.empty_like(p)
+    grads[id(p)] = g
+    return g, False
+
+
 class _Conv:
     """One convolution's geometry + launches."""
 
@@ -50,14 +62,8 @@ class _Conv:
     def out_hw(self, H, W):
         return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
 
-    def pack_weight(self, lib, T16):
-        wk = torch.empty((self.cout, self.ldk), dtype=T16, device=self.mod.weight.device)
-        check(lib.mh_conv_weight_pack(self.mod.weight.data_ptr(), wk.data_ptr(), self.cout, self.cin, self.kh, self.kw, self.cp, self.ldk,
-                                      _stream()), "mh_conv_weight_pack")
-        return wk
-
-    def forward(self, lib, x, B, H, W, T16):
-        """x: [B*H*W, cp] 16-bit -> (y [B*Ho*Wo, cout] 16-bit, saved A matrix, wk, Ho, Wo)"""
+    def forward(self, lib, x, B, H, W, T16, wk):
+        """x: [B*H*W, cp] 16-bit, wk: the packed weight [cout, ldk] -> (y [B*Ho*Wo, cout] 16-bit, saved A matrix, wk, Ho, Wo)"""
         Ho, Wo = self.out_hw(H, W)
         M = B * Ho * Wo
         if self.direct:
@@ -66,20 +72,17 @@ class _Conv:
             A = torch.empty((M, self.ldk), dtype=T16, device=x.device)
             check(lib.mh_im2col_nhwc(x.data_ptr(), A.data_ptr(), B, H, W, self.cp, self.kh, self.kw, self.stride, self.pad, self.ldk,
                                      _stream()), "mh_im2col_nhwc")
-        wk = self.pack_weight(lib, T16)
         y = torch.empty((M, self.cout), dtype=T16, device=x.device)
         ops.gemm_grouped([ops.Gemm(A, wk, y, M, self.cout, self.ldk, self.ldk, self.ldk, self.cout)], False, False)
         return y, A, wk, Ho, Wo
 
-    def backward(self, lib, dy, A, wk, B, H, W, Ho, Wo, gscale, grads, need_dx=True):
-        """dy [M, cout] 16-bit -> dx [B*H*W, cp] 16-bit (or None); the weight gradient goes to grads[id(weight)]"""
+    def backward(self, lib, dy, A, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True):
+        """dy [M, cout] 16-bit -> dx [B*H*W, cp] 16-bit (or None); the weight gradient's split-K slabs are queued in `wjobs`
+        (summed, un-packed and added to .grad for all convolutions at once at the end of the backward)"""
         M = B * Ho * Wo
         dev = dy.device
-        gk = ops.wgrad_splitk(dy, A, self.cout, self.ldk, M, self.cout, self.ldk, alpha=1.0 / gscale)
-        g = torch.empty_like(self.mod.weight)
-        check(lib.mh_conv_weight_unpack(gk.data_ptr(), g.data_ptr(), self.cout, self.cin, self.kh, self.kw, self.cp, self.ldk, 1.0,
-                                        _stream()), "mh_conv_weight_unpack")
-        grads[id(self.mod.weight)] = g
+        slabs, sp = ops.wgrad_slabs(dy, A, self.cout, self.ldk, M, self.cout, self.ldk, alpha=1.0 / gscale)
+        wjobs.append((self, slabs, sp))
         if not need_dx:
             return None
         dA = torch.empty((M, self.ldk), dtype=dy.dtype, device=dev)
@@ -98,7 +101,7 @@ class _BN:
         self.C = mod.num_features
 
     def _ws(self, M, dev):
-        return torch.empty(((M + 127) // 128 * 2 + 2) * self.C, dtype=F32, device=dev)
+        return torch.empty(int(_lib.load().mh_bn2d_workspace_elems(M, self.C)), dtype=F32, device=dev)
 
     def forward(self, lib, x, M, residual, relu, training):
         m = self.mod
@@ -109,20 +112,23 @@ class _BN:
                               None if residual is None else residual.data_ptr(), y.data_ptr(), sm.data_ptr(), sr.data_ptr(),
                               ws.data_ptr(), M, self.C, float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
                               int(training), int(relu), _stream()), "mh_bn2d_fwd")
-        if training:
-            m.num_batches_tracked += 1
         return y, sm, sr
 
     def backward(self, lib, dy, x, y, sm, sr, M, relu, want_dres, gscale, grads):
         m = self.mod
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_dres else None
-        dg, db = torch.empty_like(m.weight), torch.empty_like(m.bias)
+        dg, acc_g = _grad_target(m.weight, grads)
+        db, acc_b = _grad_target(m.bias, grads)
+        if acc_g != acc_b:      # (one of the two has a usable .grad and the other does not: take the slow path for both)
+            dg, db = torch.empty_like(m.weight), torch.empty_like(m.bias)
+            grads[id(m.weight)], grads[id(m.bias)] = dg, db
+            acc_g = False
         ws = self._ws(M, x.device)
+        flags = (_lib.MH_BN_RELU if relu else 0) | (_lib.MH_BN_ACCUM_PARAM_GRADS if acc_g else 0)
         check(lib.mh_bn2d_bwd(dy.data_ptr(), x.data_ptr(), None if y is None else y.data_ptr(), m.weight.data_ptr(), sm.data_ptr(),
                               sr.data_ptr(), dx.data_ptr(), None if dres is None else dres.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                              ws.data_ptr(), M, self.C, int(relu), 1.0 / gscale, _stream()), "mh_bn2d_bwd")
-        grads[id(m.weight)], grads[id(m.bias)] = dg, db
+                              ws.data_ptr(), M, self.C, flags, 1.0 / gscale, _stream()), "mh_bn2d_bwd")
         return dx, dres
 
 
@@ -211,9 +217,11 @@ class ResNet50(nn.Module):
         img32 = image.to(F32).contiguous()      # named: a temporary would be freed (and its block re-used) before the launch
         check(lib.mh_nchw_to_nhwc(img32.data_ptr(), x.data_ptr(), B, 3, H, W, 8, _stream()), "mh_nchw_to_nhwc")
 
+        packed = self._pack_all_weights(lib, T16)
+
         def conv_bn(conv_mod, bn_mod, xin, h, w, residual=None, relu=True, cin_pad=None):
             cv, bn = _Conv(conv_mod, cin_pad), _BN(bn_mod)
-            z, A, wk, ho, wo = cv.forward(lib, xin, B, h, w, T16)
+            z, A, wk, ho, wo = cv.forward(lib, xin, B, h, w, T16, packed[id(conv_mod)])
             M = B * ho * wo
             y, sm, sr = bn.forward(lib, z, M, residual, relu, training)
             tape["ops"].append(("conv_bn", cv, bn, A, wk, z, y, sm, sr, h, w, ho, wo, relu, residual is not None))
@@ -241,7 +249,37 @@ class ResNet50(nn.Module):
         pooled = torch.empty((B, Cf), dtype=F32, device=image.device)
         check(lib.mh_avgpool_fwd(x.data_ptr(), pooled.data_ptr(), B, h * w, Cf, _stream()), "mh_avgpool_fwd")
         tape.update(pooled=pooled, last_hw=(h, w), T16=T16)
+        if training:      # nn.BatchNorm2d's step counter, all 53 of them in one multi-tensor launch
+            torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)], 1)
         return tape
+
+    def _convs(self):
+        """(conv module, input channels of its NHWC activation) in a fixed order"""
+        out = [(self.conv1, 8)]
+        for blk in self._blocks():
+            out += [(blk.conv1, None), (blk.conv2, None), (blk.conv3, None)]
+            if blk.downsample is not None:
+                out.append((blk.downsample[0], None))
+        return out
+
+    def _pack_all_weights(self, lib, T16):
+        """f32 [Cout][Cin][kh][kw] -> 16-bit [Cout][(kh,kw,c)] for every convolution: one buffer, mh_conv_weight_pack_batched
+        launches of <= 64 jobs."""
+        convs = [_Conv(m, cp) for m, cp in self._convs()]
+        total = sum(c.cout * c.ldk for c in convs)
+        buf = torch.empty(total, dtype=T16, device=self.conv1.weight.device)
+        packed, off = {}, 0
+        for i in range(0, len(convs), _lib.MH_CONV_MAX_JOBS):
+            chunk = convs[i:i + _lib.MH_CONV_MAX_JOBS]
+            jobs = (_lib.MhConvPackJob * len(chunk))()
+            for j, c in enumerate(chunk):
+                wk = buf[off:off + c.cout * c.ldk].view(c.cout, c.ldk)
+                off += c.cout * c.ldk
+                packed[id(c.mod)] = wk
+                jobs[j].w, jobs[j].out = c.mod.weight.data_ptr(), wk.data_ptr()
+                jobs[j].Cout, jobs[j].Cin, jobs[j].KH, jobs[j].KW, jobs[j].Cp, jobs[j].ldk = c.cout, c.cin, c.kh, c.kw, c.cp, c.ldk
+            check(lib.mh_conv_weight_pack_batched(jobs, len(chunk), _stream()), "mh_conv_weight_pack_batched")
+        return packed
 
     def _backward_tape(self, tape, d_pooled: torch.Tensor):
         lib = self._lib()
@@ -254,13 +292,14 @@ class ResNet50(nn.Module):
         check(lib.mh_avgpool_bwd(dp32.data_ptr(), dx.data_ptr(), B, h * w, Cf, self.gscale, _stream()), "mh_avgpool_bwd")
         ops_ = tape["ops"]
         i = len(ops_) - 1
-        grads = {}      # id(parameter) -> gradient tensor (returned to autograd, which accumulates into .grad)
+        grads = {}      # id(parameter) -> gradient tensor for autograd, or None when it was accumulated into .grad in place
+        wjobs = []      # (conv, split-K slabs of its weight gradient, nsplit): finished in one launch at the end
 
         def conv_bn_bwd(op, dy, want_dres, need_dx=True):
             _, cv, bn, A, wk, z, y, sm, sr, hh, ww, ho, wo, relu, has_res = op
             M = B * ho * wo
             dz, dres = bn.backward(lib, dy, z, y if relu else None, sm, sr, M, relu, want_dres, self.gscale, grads)
-            dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, grads, need_dx)
+            dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx)
             return dxin, dres
 
         while i >= 0:
@@ -297,6 +336,15 @@ class ResNet50(nn.Module):
                 i -= 1
                 continue
             raise AssertionError(kind)
+        for i0 in range(0, len(wjobs), _lib.MH_CONV_MAX_JOBS):
+            chunk = wjobs[i0:i0 + _lib.MH_CONV_MAX_JOBS]
+            jobs = (_lib.MhConvWgradJob * len(chunk))()
+            for j, (cv, slabs, sp) in enumerate(chunk):
+                g, acc = _grad_target(cv.mod.weight, grads)
+                jobs[j].slabs, jobs[j].g = slabs.data_ptr(), g.data_ptr()
+                jobs[j].Cout, jobs[j].Cin, jobs[j].KH, jobs[j].KW, jobs[j].Cp, jobs[j].ldk = cv.cout, cv.cin, cv.kh, cv.kw, cv.cp, cv.ldk
+                jobs[j].nsplit, jobs[j].accumulate, jobs[j].scale = sp, int(acc), 1.0
+            check(lib.mh_conv_wgrad_finish_batched(jobs, len(chunk), _stream()), "mh_conv_wgrad_finish_batched")
         return grads
 
     # ---- nn.Module surface ------------------------------------------------------------------------------------------

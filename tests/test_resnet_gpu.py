@@ -92,7 +92,7 @@ def test_batchnorm2d_train_fwd_bwd_matches_torch(pkg):
         yd = torch.empty_like(xd)
         sm, sr = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
         rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
-        ws = torch.empty(((M + 127) // 128 * 2 + 2) * C, device="cuda")
+        ws = torch.empty(int(lib.mh_bn2d_workspace_elems(M, C)), device="cuda")
         pkg._lib.check(lib.mh_bn2d_fwd(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(),
                                        rd.data_ptr() if res else None, yd.data_ptr(), sm.data_ptr(), sr.data_ptr(), ws.data_ptr(), M, C, 1e-5,
                                        0.1, 1, int(relu), st), "bn2d_fwd")
@@ -173,6 +173,47 @@ def test_resnet_tower_forward_backward_matches_the_oracle(pkg, dtype, ftol, gtol
     assert float((sd["bn1.running_mean"].cpu() - st["bn1.running_mean"]).abs().max()) < 2e-3
     assert float((sd["layer4.0.bn3.running_var"].cpu() - st["layer4.0.bn3.running_var"]).abs().max()) < 2e-2
     assert int(sd["bn1.num_batches_tracked"]) == 1
+
+
+def test_resnet_gradients_accumulate_in_place_like_autograd(pkg):
+    """With an existing f32 .grad (flattened parameters, or any second backward) the tower adds its gradients to it inside the
+    producing kernels -- mh_conv_wgrad_finish_batched, mh_bn2d_bwd(MH_BN_ACCUM_PARAM_GRADS) -- and hands autograd None:
+    the result must equal autograd's own accumulation (first backward fresh tensors, second backward in place = 2x), and the
+    batched weight pack / weight-gradient finish must equal the one-convolution entry points bit for bit."""
+    torch.manual_seed(1)
+    net = pkg.ResNet50(num_classes=10, compute_dtype="fp16", layers=(1, 1, 1, 1)).cuda().train()
+    g = torch.Generator().manual_seed(2)
+    image = torch.randn((4, 3, 64, 64), generator=g).cuda()
+    labels = torch.tensor([1, 7, 3, 3]).cuda()
+    ce = pkg.CrossEntropyLoss()
+    ce(net(image), labels).backward()
+    first = {n: p.grad.clone() for n, p in net.named_parameters()}
+    ce(net(image), labels).backward()          # .grad exists now: the in-place path
+    torch.cuda.synchronize()
+    for n, p in net.named_parameters():
+        ref = 2.0 * first[n]
+        assert float((p.grad - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-12, n
+    assert int(net.bn1.num_batches_tracked) == 2 and int(net.layer4[0].bn3.num_batches_tracked) == 2
+    # batched pack == per-convolution pack (bit-exact), batched finish == colsum + unpack
+    lib = pkg._lib.load("fp16")
+    conv = net.layer2[0].conv2
+    Cout, Cin, KH, KW = conv.weight.shape
+    ldk = (KH * KW * Cin + 63) // 64 * 64
+    one = torch.empty((Cout, ldk), dtype=F16, device="cuda")
+    pkg._lib.check(lib.mh_conv_weight_pack(conv.weight.data_ptr(), one.data_ptr(), Cout, Cin, KH, KW, Cin, ldk, 0), "pack")
+    packed = net._pack_all_weights(lib, F16)
+    torch.cuda.synchronize()
+    assert torch.equal(packed[id(conv)], one)
+    slabs = torch.randn((3, Cout, ldk), device="cuda")
+    tgt = torch.randn_like(conv.weight)
+    want = tgt + 0.5 * slabs.sum(0)[:, :KH * KW * Cin].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+    jobs = (pkg._lib.MhConvWgradJob * 1)()
+    jobs[0].slabs, jobs[0].g = slabs.data_ptr(), tgt.data_ptr()
+    jobs[0].Cout, jobs[0].Cin, jobs[0].KH, jobs[0].KW, jobs[0].Cp, jobs[0].ldk = Cout, Cin, KH, KW, Cin, ldk
+    jobs[0].nsplit, jobs[0].accumulate, jobs[0].scale = 3, 1, 0.5
+    pkg._lib.check(lib.mh_conv_wgrad_finish_batched(jobs, 1, 0), "finish")
+    torch.cuda.synchronize()
+    assert float((tgt - want).abs().max()) < 1e-5
 
 
 def test_resnet50_state_dict_is_torchvisions(pkg):
