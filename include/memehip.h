@@ -414,6 +414,18 @@ int mh_conv_fold_f32(const float* da, float* dh, int B, int S, int D, int taps, 
 int mh_softmax_gate_fwd(const float* g, const float* c, float* y, int B, int F, mh_stream_t stream);
 int mh_softmax_gate_bwd(const float* g, const float* c, const float* dy, float* dg, float* dc, int B, int F, mh_stream_t stream);
 
+/* MCA3, the reference's fusion_method = "mca" (Multimodal_example_task2C.py:423-448), on 2-D features as its forward feeds it:
+ * pa = W1 text + b1, pc = W3 caption + b3, pi = W2 image + b2 (all [B][U], computed by mh_gemm_f32);
+ * score[i][j] = tanh(pa[j] + pc[j] + pi[i]) (the reference's [B,1,U] broadcast), e = V . score + bv, w[i][:] = softmax_j,
+ * ctx[i] = [sum_j w[i][j] text[j] | sum_j w[i][j] caption[j]]  ([B][2U], the input of its `reduce` Linear).  B <= 1024.
+ * bwd: from dctx: dpa (= dpc), dpi, dtext / dcaption (the direct paths), per-row partials dV_part [B][U] and dbv_part [B]
+ * (summed by mh_colsum_f32); de_ws: workspace [B][B]. */
+int mh_mca3_fwd(const float* pa, const float* pc, const float* pi, const float* Vw, const float* bv, const float* text,
+                const float* caption, float* w, float* ctx, int B, int U, mh_stream_t stream);
+int mh_mca3_bwd(const float* pa, const float* pc, const float* pi, const float* Vw, const float* text, const float* caption,
+                const float* w, const float* dctx, float* de_ws, float* dpa, float* dpi, float* dtext, float* dcaption,
+                float* dV_part, float* dbv_part, int B, int U, mh_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Conv tower (BASELINE config 2: torchvision ResNet-50 as wired at Multimodal_example_task2C.txt:164-165,183-184).
  * Activations are NHWC 16-bit = a row-major [B*H*W][C] matrix, so a convolution is mh_gemm_bf16_grouped:

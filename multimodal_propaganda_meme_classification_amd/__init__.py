@@ -9,8 +9,8 @@ from .config import ImageConfig, Layout, ModelConfig, TextConfig  # noqa: F401
 from .model import (Adam, BatchNorm1d, CrossEntropyLoss, GraphedStep, MultimodalClassifier, SigmoidFocalLoss,  # noqa: F401
                     TextEncoder, flatten_parameters, get_linear_schedule_with_warmup)
 from . import fused  # noqa: F401
-from .heads import (ConcatAttention3, FineTuneMLP, KevinMultimodalClassifier, LinearBNReLU, OrganizersMultimodalClassifier,  # noqa: F401
-                    SequencePooling, TextClassifier, TrainerModel)
+from .heads import (MCA3, ConcatAttention3, FineTuneMLP, KevinMultimodalClassifier, LinearBNReLU,  # noqa: F401
+                    OrganizersMultimodalClassifier, SequencePooling, TextClassifier, TrainerModel)
 from .data import HashTokenizer, MultimodalDataset, id2l, l2id, normalize_images, read_data  # noqa: F401
 from .train import evaluate, test, train  # noqa: F401
 from .resnet import Bottleneck, ResNet50, ResNetClassifier  # noqa: F401

@@ -142,6 +142,8 @@ _PROTOS = {
     "mh_relu_max_fwd": [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p],
     "mh_relu_max_bwd": [c_void_p, c_void_p, c_void_p] + [c_int] * 3 + [c_void_p],
     "mh_conv_fold_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "mh_mca3_fwd": [c_void_p] * 9 + [c_int, c_int, c_void_p],
+    "mh_mca3_bwd": [c_void_p] * 15 + [c_int, c_int, c_void_p],
     "mh_softmax_gate_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "mh_softmax_gate_bwd": [c_void_p] * 5 + [c_int, c_int, c_void_p],
     "mh_nchw_to_nhwc": [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],

@@ -430,6 +430,129 @@ __global__ __launch_bounds__(256) void softmax_gate_bwd_kernel(const float* __re
     }
 }
 
+// ---- MCA3 fusion (Multimodal_example_task2C.py:423-448) -------------------------------------------------------------
+// The reference feeds it 2-D features: text / caption projections pa, pc [B][U] and an image projection pi that it un-squeezes
+// to [B][1][U], so the sum broadcasts to score[i][j][:] = tanh(pa[j] + pc[j] + pi[i]) -- an attention of every IMAGE row i
+// over the TEXT rows j of the batch.  e[i][j] = V . score[i][j] + bv ; w[i][:] = softmax_j e[i][:] ;
+// ctx[i] = [ sum_j w[i][j] text[j] | sum_j w[i][j] caption[j] ].   One workgroup per i.
+constexpr int MCA_MAXB = 1024;
+__global__ __launch_bounds__(256) void mca3_fwd_kernel(const float* __restrict__ pa, const float* __restrict__ pc,
+                                                       const float* __restrict__ pi, const float* __restrict__ Vw, const float* __restrict__ bv,
+                                                       const float* __restrict__ text, const float* __restrict__ cap,
+                                                       float* __restrict__ w, float* __restrict__ ctx, int B, int U) {
+    __shared__ float e[MCA_MAXB];
+    __shared__ float red[2];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pii = pi + (size_t)i * U;
+    for (int j = wave; j < B; j += 4) {
+        float acc = 0.f;
+        for (int k = lane; k < U; k += 64) acc += Vw[k] * tanhf(pa[(size_t)j * U + k] + pc[(size_t)j * U + k] + pii[k]);
+        acc = wave_sum(acc);
+        if (lane == 0) e[j] = acc + bv[0];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float m = -INFINITY;
+        for (int j = lane; j < B; j += 64) m = fmaxf(m, e[j]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int j = lane; j < B; j += 64) l += expf(e[j] - m);
+        l = wave_sum(l);
+        if (lane == 0) { red[0] = m; red[1] = 1.0f / l; }
+    }
+    __syncthreads();
+    const float m = red[0], inv = red[1];
+    for (int j = tid; j < B; j += 256) {
+        const float p = expf(e[j] - m) * inv;
+        e[j] = p;
+        w[(size_t)i * B + j] = p;
+    }
+    __syncthreads();
+    for (int k = tid; k < U; k += 256) {
+        float c1 = 0.f, c2 = 0.f;
+        for (int j = 0; j < B; ++j) {
+            c1 += e[j] * text[(size_t)j * U + k];
+            c2 += e[j] * cap[(size_t)j * U + k];
+        }
+        ctx[(size_t)i * 2 * U + k] = c1;
+        ctx[(size_t)i * 2 * U + U + k] = c2;
+    }
+}
+// backward, image side (one workgroup per i): dw -> de (softmax backward), d pi[i], this row's share of dV / dbv
+__global__ __launch_bounds__(256) void mca3_bwd_i_kernel(const float* __restrict__ pa, const float* __restrict__ pc,
+                                                         const float* __restrict__ pi, const float* __restrict__ Vw,
+                                                         const float* __restrict__ text, const float* __restrict__ cap,
+                                                         const float* __restrict__ w, const float* __restrict__ dctx,
+                                                         float* __restrict__ de, float* __restrict__ dpi, float* __restrict__ dV_part,
+                                                         float* __restrict__ dbv_part, int B, int U) {
+    __shared__ float d[MCA_MAXB];
+    __shared__ float red;
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* d1 = dctx + (size_t)i * 2 * U;
+    const float* d2 = d1 + U;
+    for (int j = wave; j < B; j += 4) {      // dw[i][j] = dctx1[i] . text[j] + dctx2[i] . cap[j]
+        float acc = 0.f;
+        for (int k = lane; k < U; k += 64) acc += d1[k] * text[(size_t)j * U + k] + d2[k] * cap[(size_t)j * U + k];
+        acc = wave_sum(acc);
+        if (lane == 0) d[j] = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float t = 0.f;
+        for (int j = lane; j < B; j += 64) t += w[(size_t)i * B + j] * d[j];
+        t = wave_sum(t);
+        if (lane == 0) red = t;
+    }
+    __syncthreads();
+    const float t = red;
+    __syncthreads();
+    for (int j = tid; j < B; j += 256) {
+        const float v = w[(size_t)i * B + j] * (d[j] - t);
+        d[j] = v;
+        de[(size_t)i * B + j] = v;
+    }
+    __syncthreads();
+    const float* pii = pi + (size_t)i * U;
+    for (int k = tid; k < U; k += 256) {
+        float gp = 0.f, gv = 0.f;
+        for (int j = 0; j < B; ++j) {
+            const float th = tanhf(pa[(size_t)j * U + k] + pc[(size_t)j * U + k] + pii[k]);
+            gv += d[j] * th;
+            gp += d[j] * (1.0f - th * th);
+        }
+        dpi[(size_t)i * U + k] = gp * Vw[k];
+        dV_part[(size_t)i * U + k] = gv;
+    }
+    if (wave == 0) {
+        float sb = 0.f;
+        for (int j = lane; j < B; j += 64) sb += d[j];
+        sb = wave_sum(sb);
+        if (lane == 0) dbv_part[i] = sb;
+    }
+}
+// backward, text side (one workgroup per j): d(pa + pc)[j], and the direct paths d text[j], d caption[j]
+__global__ __launch_bounds__(256) void mca3_bwd_j_kernel(const float* __restrict__ pa, const float* __restrict__ pc,
+                                                         const float* __restrict__ pi, const float* __restrict__ Vw,
+                                                         const float* __restrict__ w, const float* __restrict__ de,
+                                                         const float* __restrict__ dctx, float* __restrict__ dpa,
+                                                         float* __restrict__ dtext, float* __restrict__ dcap, int B, int U) {
+    const int j = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < U; k += 256) {
+        const float base = pa[(size_t)j * U + k] + pc[(size_t)j * U + k];
+        float gp = 0.f, g1 = 0.f, g2 = 0.f;
+        for (int i = 0; i < B; ++i) {
+            const float th = tanhf(base + pi[(size_t)i * U + k]);
+            gp += de[(size_t)i * B + j] * (1.0f - th * th);
+            const float wij = w[(size_t)i * B + j];
+            g1 += wij * dctx[(size_t)i * 2 * U + k];
+            g2 += wij * dctx[(size_t)i * 2 * U + U + k];
+        }
+        dpa[(size_t)j * U + k] = gp * Vw[k];
+        dtext[(size_t)j * U + k] = g1;
+        dcap[(size_t)j * U + k] = g2;
+    }
+}
+
 int grid1(size_t n) { return (int)((n + 255) / 256); }
 
 }  // namespace
@@ -534,6 +657,26 @@ extern "C" int mh_conv_fold_f32(const float* da, float* dh, int B, int S, int D,
     if (B < 1 || S < 1 || D < 1 || taps < 1 || pad < 0 || Sp < S || rows < 1) return MH_ESHAPE;
     hipLaunchKernelGGL(conv_fold_kernel, dim3(grid1((size_t)B * S * D)), dim3(256), 0, (hipStream_t)stream, da, dh, B, S, D, taps,
                        pad, Sp, rows);
+    return mh_launch_status();
+}
+extern "C" int mh_mca3_fwd(const float* pa, const float* pc, const float* pi, const float* Vw, const float* bv, const float* text,
+                           const float* caption, float* w, float* ctx, int B, int U, mh_stream_t stream) {
+    if (!pa || !pc || !pi || !Vw || !bv || !text || !caption || !w || !ctx) return MH_EINVAL;
+    if (B < 1 || B > MCA_MAXB || U < 1) return MH_ESHAPE;
+    hipLaunchKernelGGL(mca3_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pa, pc, pi, Vw, bv, text, caption, w, ctx, B, U);
+    return mh_launch_status();
+}
+extern "C" int mh_mca3_bwd(const float* pa, const float* pc, const float* pi, const float* Vw, const float* text, const float* caption,
+                           const float* w, const float* dctx, float* de_ws, float* dpa, float* dpi, float* dtext, float* dcaption,
+                           float* dV_part, float* dbv_part, int B, int U, mh_stream_t stream) {
+    if (!pa || !pc || !pi || !Vw || !text || !caption || !w || !dctx || !de_ws || !dpa || !dpi || !dtext || !dcaption || !dV_part ||
+        !dbv_part)
+        return MH_EINVAL;
+    if (B < 1 || B > MCA_MAXB || U < 1) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mca3_bwd_i_kernel, dim3(B), dim3(256), 0, s, pa, pc, pi, Vw, text, caption, w, dctx, de_ws, dpi, dV_part, dbv_part,
+                       B, U);
+    hipLaunchKernelGGL(mca3_bwd_j_kernel, dim3(B), dim3(256), 0, s, pa, pc, pi, Vw, w, de_ws, dctx, dpa, dtext, dcaption, B, U);
     return mh_launch_status();
 }
 extern "C" int mh_softmax_gate_fwd(const float* g, const float* c, float* y, int B, int F, mh_stream_t stream) {

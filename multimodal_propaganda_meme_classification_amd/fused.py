@@ -191,6 +191,46 @@ def softmax_gate(gate_in, features):
     return _SoftmaxGateFn.apply(gate_in, features)
 
 
+class _Mca3Fn(torch.autograd.Function):
+    """The attention core of MCA3 (everything between its three input Linears and its ``reduce`` Linear)."""
+
+    @staticmethod
+    def forward(ctx, pa, pc, pi, Vw, bv, text, cap):
+        pa2, pc2, pi2, V2, b2, t2, c2 = (_f(t) for t in (pa, pc, pi, Vw, bv, text, cap))
+        B, U = pa2.shape
+        w = torch.empty((B, B), dtype=F32, device=pa2.device)
+        out = torch.empty((B, 2 * U), dtype=F32, device=pa2.device)
+        check(_lib.load().mh_mca3_fwd(pa2.data_ptr(), pc2.data_ptr(), pi2.data_ptr(), V2.data_ptr(), b2.data_ptr(), t2.data_ptr(),
+                                      c2.data_ptr(), w.data_ptr(), out.data_ptr(), B, U, _stream()), "mh_mca3_fwd")
+        ctx.save_for_backward(pa2, pc2, pi2, V2, t2, c2, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        pa2, pc2, pi2, V2, t2, c2, w = ctx.saved_tensors
+        B, U = pa2.shape
+        d = _f(dctx)
+        dev = pa2.device
+        de = torch.empty((B, B), dtype=F32, device=dev)
+        dpa, dpi, dt, dc = (torch.empty((B, U), dtype=F32, device=dev) for _ in range(4))
+        dVp, dbp = torch.empty((B, U), dtype=F32, device=dev), torch.empty((B,), dtype=F32, device=dev)
+        check(_lib.load().mh_mca3_bwd(pa2.data_ptr(), pc2.data_ptr(), pi2.data_ptr(), V2.data_ptr(), t2.data_ptr(), c2.data_ptr(),
+                                      w.data_ptr(), d.data_ptr(), de.data_ptr(), dpa.data_ptr(), dpi.data_ptr(), dt.data_ptr(),
+                                      dc.data_ptr(), dVp.data_ptr(), dbp.data_ptr(), B, U, _stream()), "mh_mca3_bwd")
+        dV = colsum(dVp, B, U).view(1, U)
+        dbv = colsum(dbp, B, 1)
+        return dpa, dpa, dpi, dV, dbv, dt, dc
+
+
+def mca3_attention(pa, pc, pi, V_weight, V_bias, text_features, caption_features):
+    """MCA3's core on 2-D features (Multimodal_example_task2C.py:433-444): w[i][:] = softmax_j(V . tanh(pa[j] + pc[j] + pi[i]) + bv),
+    returns [sum_j w[i][j] text[j] | sum_j w[i][j] caption[j]]  ([B, 2U])."""
+    _dev(pa, pc, pi, V_weight, V_bias, text_features, caption_features)
+    if pa.dim() != 2 or pa.shape != pc.shape or pa.shape != pi.shape:
+        raise ValueError("mca3_attention expects three [B, U] projections")
+    return _Mca3Fn.apply(pa, pc, pi, V_weight, V_bias, text_features, caption_features)
+
+
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h):

@@ -243,6 +243,27 @@ class ConcatAttention3(nn.Module):
         return self.reduce(attended)
 
 
+class MCA3(nn.Module):
+    """Multimodal_example_task2C.py:423-448 (``fusion_method="mca"``): additive attention of every image row over the text rows
+    of the batch (the reference un-squeezes only the image features, so its tanh score broadcasts to [B, B, units]), softmax
+    over dim 1, the attended text and caption features concatenated and reduced.  Same submodule names as the reference."""
+
+    def __init__(self, units: int):
+        super().__init__()
+        self.W1, self.W2, self.W3 = nn.Linear(units, units), nn.Linear(units, units), nn.Linear(units, units)
+        self.V = nn.Linear(units, 1)
+        self.reduce = nn.Linear(2 * units, units)
+
+    def forward(self, text_features, image_features, caption_features):
+        if text_features.dim() != 2:
+            raise ValueError("MCA3 on the HIP path takes [B, units] features (what the reference's forward feeds it)")
+        pa = fused.linear(text_features, self.W1.weight, self.W1.bias)
+        pi = fused.linear(image_features, self.W2.weight, self.W2.bias)
+        pc = fused.linear(caption_features, self.W3.weight, self.W3.bias)
+        ctx = fused.mca3_attention(pa, pc, pi, self.V.weight, self.V.bias, text_features, caption_features)
+        return fused.linear(ctx, self.reduce.weight, self.reduce.bias)
+
+
 class KevinMultimodalClassifier(_Composite):
     """``MultimodalClassifier(fusion_method)`` of Multimodal_example_task2C.py:587-685 on the HIP towers.
 
@@ -255,7 +276,9 @@ class KevinMultimodalClassifier(_Composite):
                  image: Optional[ImageConfig] = None, caption: Optional[TextConfig] = None, proj: int = 512,
                  compute_dtype: str = "bf16", seed: int = 0):
         super().__init__()
-        if fusion_method != "concatenation":
+        # the reference lists four methods (:86); "cross_modal" and "self_attention" build two-input modules that its own
+        # three-input forward (:677) cannot call (TypeError on the first batch), so only the two that run are offered
+        if fusion_method not in ("concatenation", "mca"):
             raise ValueError(f"Unsupported fusion method: {fusion_method}")
         tc, ic = text or TextConfig(), image or ImageConfig()
         cc = caption or TextConfig(vocab_size=30522)
@@ -266,7 +289,7 @@ class KevinMultimodalClassifier(_Composite):
         self.text_fc = LinearBNReLU(tc.hidden, proj)
         self.caption_text_fc = LinearBNReLU(cc.hidden, proj)
         self.image_fine_tune = FineTuneMLP(ic.hidden, proj)
-        self.fusion_layer = ConcatAttention3(3 * proj, proj)
+        self.fusion_layer = ConcatAttention3(3 * proj, proj) if fusion_method == "concatenation" else MCA3(proj)
         self.output_fc = LinearBNReLU(proj, 1, relu=False)
         self._head_flat = False
 

@@ -146,11 +146,13 @@ def gemm_grouped(problems: Sequence[Gemm], a_kmajor: bool, b_kmajor: bool):
     check(_L(problems[0].A).mh_gemm_bf16_grouped(arr, n, int(a_kmajor), int(b_kmajor), _stream()), "mh_gemm_bf16_grouped")
 
 
-def wgrad_slabs(dy, x, M, N, K, lda, ldb, alpha=1.0, target_tiles: int = 1024, max_split: int = 64):
+def wgrad_slabs(dy, x, M, N, K, lda, ldb, alpha=1.0, target_tiles: int = 512, max_split: int = 64):
     """The split-K weight-gradient GEMM of wgrad_splitk WITHOUT the slab sum: returns (slabs f32 [nsplit][M][N], nsplit); the
     caller sums the slabs in order (mh_conv_wgrad_finish_batched does it for every convolution of a tower in one launch)."""
     lib = _L(dy)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    import os      # (A/B knob; ResNet-50 step, ms: 1024 tiles 8.80, 512 8.68, 256 8.69, 128 9.10 -- the slabs are HBM traffic too)
+    target_tiles = int(os.environ.get("MEMEHIP_WGRAD_TILES", target_tiles))
     want = max(1, min(max_split, -(-target_tiles // tiles), K // 256))
     sp = max(1, lib.mh_gemm_ksplit_for(int(K), int(want)))
     slabs = torch.empty((sp, M, N), dtype=F32, device=dy.device)

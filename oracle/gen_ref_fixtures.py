@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE.  ``python -m oracle.gen_ref_fixtures`` reads
 /root/reference/example_scripts/Multimodal_example_task2C.py as text, takes the class definitions it needs out of its
-AST -- ``LLMWithClassificationHead`` (:307-392, the pooling branches), ``ConcatAttention3`` (:476-499) and
+AST -- ``LLMWithClassificationHead`` (:307-392, the pooling branches), ``ConcatAttention3`` (:476-499), ``MCA3`` (:423-448) and
 ``MultimodalClassifier`` (:587-685, for ``get_params`` only; the class is never constructed: its __init__ downloads
 checkpoints) -- executes exactly those definitions with ``torch / nn / F`` in scope, and records inputs and outputs in
 tests/golden/ref_kevin_heads.npz.  The script as a whole cannot be imported (torchvision / timm / network); nothing of the
@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 REF = "/root/reference/example_scripts/Multimodal_example_task2C.py"
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-WANT = ("LLMWithClassificationHead", "ConcatAttention3", "MultimodalClassifier")
+WANT = ("LLMWithClassificationHead", "ConcatAttention3", "MCA3", "MultimodalClassifier")
 
 
 class _HiddenHolder(nn.Module):
@@ -112,6 +112,22 @@ def main():
     ca.eval()
     with torch.no_grad():
         out["ca_out_eval"] = ca(*[f_.detach() for f_ in feats]).numpy()
+    # ---- MCA3 (fusion_method = "mca") on 2-D features, as MultimodalClassifier.forward feeds it -------------------------------
+    Um, Bm = 64, 6
+    torch.manual_seed(13)
+    mca = ns["MCA3"](Um)
+    for n_, t_ in mca.state_dict().items():
+        out[f"mca_init_{n_}"] = t_.numpy().copy()
+    mf = [torch.randn((Bm, Um), generator=g).requires_grad_(True) for _ in range(3)]
+    rm = torch.randn((Bm, Um), generator=g)
+    ym = mca(*mf)
+    (ym * rm).sum().backward()
+    out.update(mca_text=mf[0].detach().numpy(), mca_image=mf[1].detach().numpy(), mca_caption=mf[2].detach().numpy(),
+               mca_r=rm.numpy(), mca_out=ym.detach().numpy())
+    for i, nm in enumerate(("text", "image", "caption")):
+        out[f"mca_d{nm}"] = mf[i].grad.numpy().copy()
+    for n_, p_ in mca.named_parameters():
+        out[f"mca_grad_{n_}"] = p_.grad.numpy().copy()
     # ---- get_params grouping (Multimodal_example_task2C.py:645-664) --------------------------------------------
     dummy = nn.Module()
     dummy.text_model = nn.Module()

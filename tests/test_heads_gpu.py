@@ -167,11 +167,61 @@ def test_concat_attention3_matches_the_reference_class(pkg, ref):
         close(ca(*[f_.detach() for f_ in feats]), ref["ca_out_eval"], 3e-5, what="eval out")
 
 
-def _small_kevin(pkg, dtype="fp16"):
+def test_mca3_matches_the_reference_class(pkg, ref):
+    """fusion_method = "mca": MCA3 (Multimodal_example_task2C.py:423-448) run by oracle/gen_ref_fixtures.py on 2-D features --
+    output, input gradients and every parameter gradient of the HIP path (three mh_gemm_f32 Linears, mh_mca3_fwd / _bwd,
+    the reduce Linear) against the reference class's own; its [B,1,U] image broadcast makes this an attention across the
+    rows of the batch, which is what is reproduced."""
+    U = 64
+    m = pkg.MCA3(U)
+    sd = {k[len("mca_init_"):]: torch.from_numpy(ref[k]) for k in ref.files if k.startswith("mca_init_")}
+    assert sorted(sd) == sorted(m.state_dict()), "state_dict keys differ from the reference module's"
+    m.load_state_dict(sd)
+    m.cuda().train()
+    feats = [torch.from_numpy(ref[f"mca_{n}"]).cuda().requires_grad_(True) for n in ("text", "image", "caption")]
+    y = m(*feats)
+    (y * torch.from_numpy(ref["mca_r"]).cuda()).sum().backward()
+    close(y, ref["mca_out"], 2e-5, what="out")
+    for f_, n in zip(feats, ("text", "image", "caption")):
+        close(f_.grad, ref[f"mca_d{n}"], 2e-5, 2e-4, what=f"d{n}")
+    for n, p in m.named_parameters():
+        if n == "V.bias":              # softmax is shift-invariant: analytically 0, rounding noise on both sides
+            assert float(p.grad.abs().max()) < 1e-4
+            continue
+        close(p.grad, ref[f"mca_grad_{n}"], 3e-5, 3e-4, what=f"d{n}")
+
+
+def test_kevin_model_with_mca_fusion_trains(pkg):
+    model, tc, ic, cc = _small_kevin(pkg, fusion="mca")
+    model.cuda().train()
+    assert isinstance(model.fusion_layer, pkg.MCA3)
+    g = torch.Generator().manual_seed(5)
+    B = 8
+    text = torch.randint(5, tc.vocab_size, (B, 16), generator=g).cuda()
+    cap = torch.randint(5, cc.vocab_size, (B, 12), generator=g).cuda()
+    mask, cmask = torch.ones((B, 16), dtype=torch.long).cuda(), torch.ones((B, 12), dtype=torch.long).cuda()
+    image = torch.randn((B, 3, 32, 32), generator=g).cuda()
+    labels = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1.0]).cuda()
+    opt = pkg.Adam(model.get_params(2e-3), max_grad_norm=1.0)
+    crit = pkg.SigmoidFocalLoss()
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        out = model(text, image, mask, cap, cmask)
+        loss = crit(out, labels)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert out.shape == (B,) and np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    with pytest.raises(ValueError, match="Unsupported fusion method"):
+        pkg.KevinMultimodalClassifier("cross_modal", text=tc, image=ic, caption=cc, proj=64)
+
+
+def _small_kevin(pkg, dtype="fp16", fusion="concatenation"):
     tc = pkg.TextConfig(vocab_size=600, hidden=128, layers=2, heads=2, intermediate=256, max_position=64)
     ic = pkg.ImageConfig(image_size=32, hidden=128, layers=2, heads=2, intermediate=256)
     cc = pkg.TextConfig(vocab_size=500, hidden=128, layers=1, heads=2, intermediate=256, max_position=64)
-    return pkg.KevinMultimodalClassifier("concatenation", text=tc, image=ic, caption=cc, proj=64, compute_dtype=dtype, seed=3), tc, ic, cc
+    return pkg.KevinMultimodalClassifier(fusion, text=tc, image=ic, caption=cc, proj=64, compute_dtype=dtype, seed=3), tc, ic, cc
 
 
 def test_get_params_groups_like_the_reference(pkg, ref):
