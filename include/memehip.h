@@ -509,7 +509,22 @@ int mh_add_h16(const void* a, const void* b, void* y, int64_t n, mh_stream_t str
  *     the identity (with weight_decay == 0): skipping it is bit-identical to torch.optim.Adam and saves 28 B/element
  *     of HBM traffic on the 49 M-element table (a batch touches at most B*S of its 64 000 rows).
  *   mh_cast_f32_bf16: shadow refresh on its own (after load_state_dict).
+ *   mh_adam_skip_account (steps that may be skipped: fp16 runs, GradScaler semantics): after the gradient norm is known and
+ *     before the update launches -- counts a non-finite norm in state[0] (state[1] = this step was skipped) and rewrites every
+ *     group's bias corrections hyper[5..6] for t = *step_dev - state[0]: as with GradScaler.step, which does not call
+ *     optimizer.step() after an overflow, a skipped step does not advance Adam's t.  betas are passed as doubles
+ *     (1 - beta^t in double, like the host).
  * ------------------------------------------------------------------------------------------ */
+#define MH_ADAM_MAX_GROUPS 8
+typedef struct MhAdamSkipGroups {
+    float* hyper[MH_ADAM_MAX_GROUPS];      /* device f32[8] per parameter group */
+    double beta1[MH_ADAM_MAX_GROUPS];
+    double beta2[MH_ADAM_MAX_GROUPS];
+    int32_t n;
+    int32_t reserved_;
+} MhAdamSkipGroups;
+int mh_adam_skip_account(const MhAdamSkipGroups* groups, const float* gnorm_sq /*device*/, int32_t* state /*device int32[2]*/,
+                         const int32_t* step_dev /*device: the host's step count*/, mh_stream_t stream);
 int mh_sumsq_f32(const float* g, int64_t n, float* workspace /*>=1024 f32*/, float* out,
                  mh_stream_t stream);
 int mh_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t n,

@@ -53,6 +53,14 @@ MH_CONV_MAX_JOBS = 64
 MH_BN_RELU, MH_BN_ACCUM_PARAM_GRADS = 1, 2
 
 
+MH_ADAM_MAX_GROUPS = 8
+
+
+class MhAdamSkipGroups(C.Structure):
+    _fields_ = [("hyper", c_void_p * MH_ADAM_MAX_GROUPS), ("beta1", C.c_double * MH_ADAM_MAX_GROUPS), ("beta2", C.c_double * MH_ADAM_MAX_GROUPS),
+                ("n", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class MhLnFwdJob(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "gamma", "beta", "y", "y_f32", "mean", "rstd")] + \
                [("rows", C.c_int32), ("eps", C.c_float), ("rows_dev", c_void_p)]
@@ -164,6 +172,7 @@ _PROTOS = {
     "mh_add_h16": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
     "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p],
+    "mh_adam_skip_account": [C.POINTER(MhAdamSkipGroups), c_void_p, c_void_p, c_void_p, c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     "mh_adam_step": [c_void_p] * 5 + [c_int64, c_int64, c_void_p, c_int, c_void_p, c_float, c_void_p],
     "mh_adam_step_rows": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p],

@@ -82,6 +82,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// GradScaler bookkeeping on the device: a step whose gradient norm is not finite is skipped by the update kernels; here
+// it is COUNTED, and the bias corrections of every group are recomputed for the effective step t = host step - skipped
+// steps (torch's GradScaler.step does not call optimizer.step() at all after an overflow, so Adam's t does not advance).
+struct SkipGroups {
+    float* hyper[MH_ADAM_MAX_GROUPS];
+    double b1[MH_ADAM_MAX_GROUPS], b2[MH_ADAM_MAX_GROUPS];
+    int n;
+};
+__global__ __launch_bounds__(64) void adam_skip_account_kernel(const SkipGroups G, const float* __restrict__ gnorm_sq,
+                                                               int32_t* __restrict__ state, const int32_t* __restrict__ step_dev) {
+    __shared__ int t_eff;
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(gnorm_sq[0]) * fabsf(G.hyper[0][7]);
+        const int bad = !(nrm <= 3.0e38f);
+        if (bad) state[0] += 1;
+        state[1] = bad;
+        t_eff = step_dev[0] - state[0];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G.n) {
+        const double t = (double)(t_eff < 1 ? 1 : t_eff);
+        float* h = G.hyper[threadIdx.x];
+        h[5] = (float)(1.0 / (1.0 - pow(G.b1[threadIdx.x], t)));
+        h[6] = (float)(1.0 / sqrt(1.0 - pow(G.b2[threadIdx.x], t)));
+    }
+}
+
 // the same update over a [rows][D] table, one wave per row, rows without a gradient history skipped
 __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m,
                                                         float* __restrict__ v, const float* __restrict__ g,
@@ -171,6 +198,22 @@ extern "C" int mh_sumsq_f32(const float* g, int64_t n, float* workspace, float* 
     const int nb = grid_for(n / 4 / 8 + 1) > 1024 ? 1024 : grid_for(n / 4 / 8 + 1);
     hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(256), 0, s, g, n, workspace);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, workspace, nb, out);
+    return mh_launch_status();
+}
+
+extern "C" int mh_adam_skip_account(const MhAdamSkipGroups* groups, const float* gnorm_sq, int32_t* state, const int32_t* step_dev,
+                                    mh_stream_t stream) {
+    if (!groups || !gnorm_sq || !state || !step_dev) return MH_EINVAL;
+    if (groups->n < 1 || groups->n > MH_ADAM_MAX_GROUPS) return MH_ESHAPE;
+    SkipGroups G;
+    G.n = groups->n;
+    for (int i = 0; i < MH_ADAM_MAX_GROUPS; ++i) {
+        G.hyper[i] = i < G.n ? groups->hyper[i] : nullptr;
+        G.b1[i] = groups->beta1[i];
+        G.b2[i] = groups->beta2[i];
+        if (i < G.n && (!G.hyper[i] || !(G.b1[i] >= 0.0 && G.b1[i] < 1.0) || !(G.b2[i] >= 0.0 && G.b2[i] < 1.0))) return MH_EINVAL;
+    }
+    hipLaunchKernelGGL(adam_skip_account_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, G, gnorm_sq, state, step_dev);
     return mh_launch_status();
 }
 

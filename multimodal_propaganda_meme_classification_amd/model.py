@@ -17,6 +17,7 @@ fp32 views of a second one, GEMM operands a bf16 shadow of the matrix prefix.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 import weakref
 from typing import Dict, Optional
@@ -707,7 +708,12 @@ class Adam(torch.optim.Optimizer):
         dev = buckets[0]["P"].device
         shared = dict(hyper=[torch.zeros(8, device=dev) for _ in self.param_groups],
                       ring=[torch.zeros((len(self.param_groups), 8), dtype=F32).pin_memory() for _ in range(32)],
-                      nrm_total=torch.zeros(1, device=dev))
+                      nrm_total=torch.zeros(1, device=dev),
+                      # GradScaler bookkeeping (mh_adam_skip_account): [skipped steps, last step skipped]; the host's step count
+                      skip_state=torch.zeros(2, dtype=torch.int32, device=dev), step_dev=torch.zeros(1, dtype=torch.int32, device=dev),
+                      step_ring=[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(32)])
+        if len(self.param_groups) > _lib.MH_ADAM_MAX_GROUPS and (self.max_grad_norm is not None or self.skip_nonfinite):
+            raise ValueError(f"memehip.Adam: at most {_lib.MH_ADAM_MAX_GROUPS} parameter groups with clipping / skip_nonfinite")
         for bk in buckets:
             bk.update(shared)
         self._buckets = buckets
@@ -739,6 +745,8 @@ class Adam(torch.optim.Optimizer):
             host[gi].copy_(torch.tensor([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1.0 / (1.0 - b1 ** t),
                                          1.0 / math.sqrt(1.0 - b2 ** t), self.grad_scale], dtype=F32))
             self._flat["hyper"][gi].copy_(host[gi], non_blocking=True)
+        self._flat["step_ring"][t % 32][0] = t
+        self._flat["step_dev"].copy_(self._flat["step_ring"][t % 32], non_blocking=True)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -755,10 +763,37 @@ class Adam(torch.optim.Optimizer):
         if self.max_grad_norm is not None or self.skip_nonfinite:
             assert only is None, "clipping / the non-finite check need the global gradient norm before any update"
             nrm = self._global_norm_sq()
+            self._skip_account(nrm)
         for bi, f in enumerate(self._buckets):
             if bi > 0 and only is not None:
                 break
             self._launch_bucket(f, nrm, only if bi == 0 else None, skip if bi == 0 else None)
+
+    def _skip_account(self, nrm):
+        """A step with a non-finite gradient norm is skipped by the update kernels; count it on the device and recompute the
+        bias corrections for the steps actually taken (GradScaler.step never calls optimizer.step() after an overflow, so
+        torch's Adam does not advance t either).  One 64-thread launch, graph-replayable (the host's step count is read from
+        device memory)."""
+        f = self._flat
+        grp = _lib.MhAdamSkipGroups()
+        grp.n = len(self.param_groups)
+        for gi, g in enumerate(self.param_groups):
+            grp.hyper[gi] = f["hyper"][gi].data_ptr()
+            grp.beta1[gi], grp.beta2[gi] = float(g["betas"][0]), float(g["betas"][1])
+        _lib.check(_lib.load().mh_adam_skip_account(C.byref(grp), nrm.data_ptr(), f["skip_state"].data_ptr(), f["step_dev"].data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), "mh_adam_skip_account")
+
+    @property
+    def skipped_steps(self) -> int:
+        """Steps skipped so far because the gradient norm was inf / nan (synchronises; read it lazily, e.g. once per epoch, to
+        lower a static fp16 gradient-stream scale or to warn about a run that keeps overflowing)."""
+        self._bind()
+        return int(self._flat["skip_state"][0])
+
+    @property
+    def last_step_skipped(self) -> bool:
+        self._bind()
+        return bool(int(self._flat["skip_state"][1]))
 
     def _global_norm_sq(self) -> torch.Tensor:
         """Sum of squares of every gradient this optimizer owns (device f32[1]): one mh_sumsq_f32 per flat buffer."""
@@ -845,7 +880,7 @@ class Adam(torch.optim.Optimizer):
         ms = [f["M"].clone() for f in self._buckets]
         vs = [f["V"].clone() for f in self._buckets]
         one = len(self._buckets) == 1
-        return dict(step=self._step, exp_avg=ms[0] if one else ms, exp_avg_sq=vs[0] if one else vs,
+        return dict(step=self._step, skipped=int(self._flat["skip_state"][0]), exp_avg=ms[0] if one else ms, exp_avg_sq=vs[0] if one else vs,
                     param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
 
     def load_state_dict(self, state_dict):
@@ -871,6 +906,7 @@ class Adam(torch.optim.Optimizer):
                 live = ((f["M"][ta:tb].view(V, D) != 0) | (f["V"][ta:tb].view(V, D) != 0)).any(dim=1)
                 f["row_live"].copy_(live.to(torch.uint8))
         self._step = int(state_dict["step"])
+        self._flat["skip_state"].copy_(torch.tensor([int(state_dict.get("skipped", 0)), 0], dtype=torch.int32))
         groups = state_dict.get("param_groups")
         if groups is not None:
             if len(groups) != len(self.param_groups):

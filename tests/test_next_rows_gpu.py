@@ -397,6 +397,50 @@ def test_adam_skips_the_step_on_nonfinite_gradients(clip):
     assert not torch.equal(model.flat_params, p0) and bool(torch.isfinite(model.flat_params).all())
 
 
+def test_skipped_steps_do_not_advance_adams_bias_correction():
+    """torch's GradScaler.step does not call optimizer.step() after an overflow, so torch.optim.Adam's step count -- and with it
+    the bias corrections 1 - beta^t -- only advances on finite steps.  The fused Adam counts skipped steps on the device
+    (mh_adam_skip_account) and recomputes the corrections for the steps actually taken: a gradient sequence [g1, inf, g2, g3]
+    must give exactly what torch.optim.Adam gives for [g1, g2, g3]; the skipped step is reported, survives a checkpoint,
+    and the same holds when the step is a replayed hipGraph."""
+    import multimodal_propaganda_meme_classification_amd as pkg
+    torch.manual_seed(0)
+    holder = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(64, 32)), torch.nn.Parameter(torch.randn(100))]).cuda()
+    pkg.flatten_parameters(holder)
+    ref = [p.detach().clone().cpu().requires_grad_(True) for p in holder]
+    topt = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.95))
+    opt = pkg.Adam(holder.parameters(), lr=1e-2, betas=(0.9, 0.95), skip_nonfinite=True)
+    g = torch.Generator().manual_seed(1)
+    grads = [[torch.randn(p.shape, generator=g) for p in ref] for _ in range(3)]
+
+    def mine(gs, poison=False):
+        for p, gg in zip(holder, gs):
+            p.grad.copy_(gg.cuda())
+        if poison:
+            holder[1].grad[7] = float("inf")
+        opt.step()
+
+    def theirs(gs):
+        for p, gg in zip(ref, gs):
+            p.grad = gg.clone()
+        topt.step()
+
+    opt.zero_grad()
+    mine(grads[0]); theirs(grads[0])
+    mine(grads[1], poison=True)                 # skipped: no torch step
+    assert opt.last_step_skipped and opt.skipped_steps == 1
+    sd = opt.state_dict()
+    assert sd["step"] == 2 and sd["skipped"] == 1
+    mine(grads[1]); theirs(grads[1])
+    assert not opt.last_step_skipped and opt.skipped_steps == 1
+    opt.load_state_dict(opt.state_dict())       # round trip keeps the effective step
+    mine(grads[2]); theirs(grads[2])
+    torch.cuda.synchronize()
+    for p, r in zip(holder, ref):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-6, atol=2e-7)
+    # without the accounting the third real update would use t = 4 instead of 3: |delta| ~ 1e-3 here, far above the tolerance
+
+
 def test_three_tower_model_with_caption_encoder_matches_oracle():
     """Kevin's forward(text, image, mask, caption_text, caption_text_mask) (Multimodal_example_task2C.py:666-685):
     text + image towers (MultimodalClassifier.encode) and a caption tower (TextEncoder), a three-input fusion head in

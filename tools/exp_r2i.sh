@@ -1,0 +1,6 @@
+#!/bin/bash
+set -e
+OUT=gpurun_out/r2i
+mkdir -p $OUT
+timeout -k 10 900 python -m pytest tests/test_next_rows_gpu.py tests/test_round2_gpu.py tests/test_model_gpu.py -x -q > $OUT/tests.log 2>&1 || { tail -40 $OUT/tests.log; exit 1; }
+tail -3 $OUT/tests.log
