@@ -707,11 +707,13 @@ class Adam(torch.optim.Optimizer):
             self._model = buckets[0]["model"]
         dev = buckets[0]["P"].device
         shared = dict(hyper=[torch.zeros(8, device=dev) for _ in self.param_groups],
-                      ring=[torch.zeros((len(self.param_groups), 8), dtype=F32).pin_memory() for _ in range(32)],
+                      # (ONE pinned allocation each: an optimizer used to pin 64 small blocks, and a long process -- the GPU test
+                      #  suite builds ~100 optimizers -- ran the host allocator into a segfault inside hipGraphLaunch)
+                      ring=torch.zeros((32, len(self.param_groups), 8), dtype=F32).pin_memory(),
                       nrm_total=torch.zeros(1, device=dev),
                       # GradScaler bookkeeping (mh_adam_skip_account): [skipped steps, last step skipped]; the host's step count
                       skip_state=torch.zeros(2, dtype=torch.int32, device=dev), step_dev=torch.zeros(1, dtype=torch.int32, device=dev),
-                      step_ring=[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(32)])
+                      step_ring=torch.zeros((32, 1), dtype=torch.int32).pin_memory())
         if len(self.param_groups) > _lib.MH_ADAM_MAX_GROUPS and (self.max_grad_norm is not None or self.skip_nonfinite):
             raise ValueError(f"memehip.Adam: at most {_lib.MH_ADAM_MAX_GROUPS} parameter groups with clipping / skip_nonfinite")
         for bk in buckets:

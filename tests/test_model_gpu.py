@@ -246,9 +246,24 @@ def test_config3_logits_match_golden_and_oracle(pkg, golden_dir):
     print("worst relative grad error", name, worst)
 
 
+@pytest.fixture(scope="module")
+def rccl_world1():
+    """ONE 1-rank RCCL communicator for every data-parallel test of this module.  (A communicator per test -- five
+    init / destroy cycles in one process, next to the 12-GB config-5 tests -- made a LATER, unrelated hipGraphLaunch segfault
+    inside the HIP runtime, deterministically; three cycles did not.  The product creates one communicator per process.)"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        yield dist
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("clip", [1.0, None])
 @pytest.mark.parametrize("ddp_mode", ["stream", "segments"])
-def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode):
+def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode, rccl_world1):
     """The N > 1 code path on a 1-rank RCCL group, both schedules -- "stream": forward graph + eagerly launched two-stream
     backward with the all-reduce of every completed gradient slice behind a fence stream; "segments": one hipGraph per
     backward segment, the all-reduce between graph launches -- with 1/world folded into Adam and, without clipping, each
@@ -259,10 +274,7 @@ def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode):
     cfg = O.tiny_config("cls")
     text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=11)
     dev = [t.cuda() for t in (text, image, mask, labels)]
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(29600 + (os.getpid() + (0 if clip else 151) + (0 if ddp_mode == "stream" else 77)) % 300)      # a fresh port per group
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-    try:
+    if True:
         m1, _ = _make(pkg, O, cfg, 13)
         m2, _ = _make(pkg, O, cfg, 13)
         o1 = pkg.Adam(m1.parameters(), lr=LR, max_grad_norm=clip)
@@ -287,11 +299,9 @@ def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode):
             assert len(g2.graphs) == 1       # the forward; the backward is stream-ordered eager launches
         else:
             assert 4 <= len(g2.graphs) <= len(g2.plan.bwd) + 3   # fwd, opt, gather marker + segments (paired)
-    finally:
-        dist.destroy_process_group()
 
 
-def test_ddp_bf16_compressed_exchange_world1(pkg):
+def test_ddp_bf16_compressed_exchange_world1(pkg, rccl_world1):
     """ddp.GradientReducer(compress="bf16") on a real RCCL communicator (1 rank): all-to-all + fp32 shard sum + all-gather
     between the backward segments' graphs.  The gradients arrive bf16-rounded, so the step is not bit-identical to the fp32
     exchange: after 3 steps every parameter is within one Adam step size of it and the mean difference is ~1 % of lr."""
@@ -301,10 +311,7 @@ def test_ddp_bf16_compressed_exchange_world1(pkg):
     cfg = O.tiny_config("cls")
     text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=12)
     dev = [t.cuda() for t in (text, image, mask, labels)]
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(29950 + os.getpid() % 40)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-    try:
+    if True:
         m1, _ = _make(pkg, O, cfg, 14)
         m2, _ = _make(pkg, O, cfg, 14)
         o1, o2 = pkg.Adam(m1.parameters(), lr=LR), pkg.Adam(m2.parameters(), lr=LR)
@@ -325,8 +332,6 @@ def test_ddp_bf16_compressed_exchange_world1(pkg):
         # the exchanged gradients are exactly bf16 values
         gsl = m2.flat_grads[:4096]
         assert torch.equal(gsl, gsl.to(torch.bfloat16).float())
-    finally:
-        dist.destroy_process_group()
 
 
 def test_ddp_two_ranks_on_one_gpu_match_the_global_batch():
