@@ -271,11 +271,18 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
 // with the LDS-DMA issued but never waited for it runs exactly as fast as the real kernel (730-950 TF/s).  So the
 // loop is not waiting for data: the LDS itself (fragment reads + DMA writes, ~640 LDS cycles per 512 MFMA cycles
 // per K step) is the limiter, and a deeper ring (variant 6) cannot help.
-template <int LA, int LB, int DMA, int NW = 4, bool DROP = true, bool PREF = true>
+// DBUF (variant 7, LDS-DMA staging only): the MFMA fragments are double-buffered in registers -- the reads of K half kk+1 are
+// issued before the MFMAs of half kk, so no MFMA group waits for the LDS reads issued just in front of it.
+// KSW (variant 8, 8 waves): the two halves of a 64-deep K tile go to two groups of four waves, each wave a 64x64 output tile
+// (8 fragment reads per 16 MFMAs instead of 12 -- a third fewer LDS reads per flop, with the eight waves kept for latency);
+// the two groups' accumulators meet in the f32 staging tile of the epilogue.
+template <int LA, int LB, int DMA, int NW = 4, bool DROP = true, bool PREF = true, bool DBUF = false, bool KSW = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g) {
     static_assert(NW == 4 || DMA == 1, "register staging is written for 256 threads");
-    constexpr int NWM = NW == 16 ? 4 : 2;      // waves along M
-    constexpr int NWN = NW / NWM;              // waves along N
+    static_assert(!KSW || (NW == 8 && DMA == 1 && !DBUF), "K-split waves: the 8-wave LDS-DMA kernel");
+    constexpr int NWT = KSW ? 4 : NW;          // waves that tile the output (the others repeat it on the other K half)
+    constexpr int NWM = NWT == 16 ? 4 : 2;     // waves along M
+    constexpr int NWN = NWT / NWM;             // waves along N
     constexpr int NI = BM / NWM / 16;          // 16-row A fragments per wave
     constexpr int NJ = BN / NWN / 16;          // 16-column B fragments per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,7 +328,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     const int kbeg = ksplit_idx * kchunk;                       // 0 without split-K
     const int kend = kchunk > 0 ? min(K, kbeg + kchunk) : K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave / NWN) * (NI * 16), wn0 = (wave % NWN) * (NJ * 16);
+    const int wt = KSW ? (wave & 3) : wave;          // position in the output tiling
+    const int kgrp = KSW ? (wave >> 2) : 0;          // K half of this wave (KSW)
+    const int wm0 = (wt / NWN) * (NI * 16), wn0 = (wt % NWN) * (NJ * 16);
 
     const uint32_t a_bytes = (LA == 0) ? (uint32_t)((M - 1) * P.lda + K) * 2u
                                        : (uint32_t)((K - 1) * P.lda + M) * 2u;
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     f32x4 accb[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wave % NWN) == 0);
+    const bool do_rowsum = (LA == 1) && (P.rowsum != nullptr) && (tn == 0) && ((wt % NWN) == 0);
     h16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (h16)1.0f;
@@ -348,7 +357,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
         const char* la = cur;
         const char* lb = cur + BM * BK * 2;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kq = 0; kq < (KSW ? 1 : 2); ++kq) {
+            const int kk = KSW ? kgrp : kq;
             h16x8 fa[NI], fb[NJ];
 #pragma unroll
             for (int i = 0; i < NI; ++i) fa[i] = read_frag<LA>(la, wm0 + i * 16, kk, lane);
@@ -366,7 +376,52 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
             }
         }
     };
-    if (DMA) {
+    if (DMA && DBUF) {
+        h16x8 fa[2][NI], fb[2][NJ];
+        auto reads = [&](const char* st, int kk, int slot) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fa[slot][i] = read_frag<LA>(st, wm0 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[slot][j] = read_frag<LB>(st + BM * BK * 2, wn0 + j * 16, kk, lane);
+        };
+        auto mfmas = [&](int slot) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = MH_MFMA_16x16x32(fa[slot][i], fb[slot][j], acc[i][j], 0, 0, 0);
+            if (do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) accb[i] = MH_MFMA_16x16x32(fa[slot][i], ones, accb[i], 0, 0, 0);
+            }
+        };
+        if (nk > 0) {
+            dma_tile<LA, 16 / NW>(ra, P.lda, m0, kbeg, wave, lane, smem);
+            dma_tile<LB, 16 / NW>(rb, P.ldb, n0, kbeg, wave, lane, smem + BM * BK * 2);
+            __syncthreads();
+            if (nk > 1) {
+                dma_tile<LA, 16 / NW>(ra, P.lda, m0, kbeg + BK, wave, lane, smem + STAGE_BYTES);
+                dma_tile<LB, 16 / NW>(rb, P.ldb, n0, kbeg + BK, wave, lane, smem + STAGE_BYTES + BM * BK * 2);
+            }
+            reads(smem, 0, 0);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE_BYTES;
+            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            reads(cur, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0);
+            __builtin_amdgcn_sched_barrier(0);      // (keeps the waitcnt + barrier BEHIND the MFMA group: the compiler hoists it)
+            __syncthreads();             // every wave has its second-half fragments in registers; the next stage has landed
+            if (kt + 2 < nk) {           // `cur` is free: the tile after next goes there, a whole K step ahead of its use
+                dma_tile<LA, 16 / NW>(ra, P.lda, m0, kbeg + (kt + 2) * BK, wave, lane, cur);
+                dma_tile<LB, 16 / NW>(rb, P.ldb, n0, kbeg + (kt + 2) * BK, wave, lane, cur + BM * BK * 2);
+            }
+            if (kt + 1 < nk) reads(nxt, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(1);
+        }
+        __syncthreads();
+    } else if (DMA) {
         dma_tile<LA, 16 / NW>(ra, P.lda, m0, kbeg, wave, lane, smem);
         dma_tile<LB, 16 / NW>(rb, P.ldb, n0, kbeg, wave, lane, smem + BM * BK * 2);
         __syncthreads();
@@ -405,7 +460,24 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
-    if (do_rowsum && (lane & 15) == 0) {
+    if (KSW && (LA == 1) && (P.rowsum != nullptr) && (tn == 0)) {      // (uniform per workgroup) second K group's row sums -> LDS
+        float* rs = (float*)smem;                                      // [128] (the main loop ended with a barrier)
+        if (do_rowsum && kgrp == 1 && (lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rs[wm0 + i * 16 + (lane >> 4) * 4 + r] = accb[i][r];
+        }
+        __syncthreads();
+        if (do_rowsum && kgrp == 0 && (lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accb[i][r] += rs[wm0 + i * 16 + (lane >> 4) * 4 + r];
+        }
+        __syncthreads();
+    }
+    if (do_rowsum && kgrp == 0 && (lane & 15) == 0) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -414,18 +486,36 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
                 if (row < M) P.rowsum[row] = accb[i][r] * (P.alpha == 0.f ? 1.0f : P.alpha);
             }
     }
+    // accumulators -> f32 staging tile; KSW: first K group stores, second adds (two passes, one barrier between)
+    auto stage_acc = [&](float* cs) {
+        if (!KSW || kgrp == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cs[cs_index(wm0 + i * 16 + (lane >> 4) * 4 + r, wn0 + j * 16 + (lane & 15))] = acc[i][j][r];
+        }
+        if (KSW) {
+            __syncthreads();
+            if (kgrp == 1) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            cs[cs_index(wm0 + i * 16 + (lane >> 4) * 4 + r, wn0 + j * 16 + (lane & 15))] += acc[i][j][r];
+            }
+        }
+    };
     // (issuing these under the last K tile's MFMAs instead was measured 20 % slower: the extra live registers
     //  across the main loop cost more than the remaining exposed latency)
     if (kchunk > 0) {       // split-K partial: plain f32 store of alpha * acc into this split's slab, no epilogue operands
         __syncthreads();
         float* cs = (float*)smem;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    cs[cs_index(wm0 + i * 16 + (lane >> 4) * 4 + r, wn0 + j * 16 + (lane & 15))] = acc[i][j][r];
+        stage_acc(cs);
         __syncthreads();
         float* slab = (float*)P.C + (size_t)ksplit_idx * (size_t)P.M * (size_t)P.ldc;
         const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
@@ -444,16 +534,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     EpiPrefetch<BM, NW * 64> pf;
     if (PREF) epilogue_prefetch<BM, NW * 64>(P, m0, n0, tid, M, pf);
     float* cs = (float*)smem;  // [128][128] f32
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm0 + i * 16 + (lane >> 4) * 4 + r;
-                const int col = wn0 + j * 16 + (lane & 15);
-                cs[cs_index(row, col)] = acc[i][j][r];
-            }
+    stage_acc(cs);
     __syncthreads();
 
     epilogue_rows<BM, NW * 64, DROP, PREF>(P, cs, m0, n0, tid, M, &pf);
@@ -1084,6 +1165,42 @@ int launch_nw3(const GemmGroup& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<LA, LB, 1, NW, DROP, PREF>), dim3(g.total_tiles), dim3(NW * 64), LDS_BYTES, s, g);
     return mh_launch_status();
 }
+template <int LA, int LB, bool DROP>
+int launch_db2(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB, 1, 8, DROP, true, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<LA, LB, 1, 8, DROP, true, true>), dim3(g.total_tiles), dim3(512), LDS_BYTES, s, g);
+    return mh_launch_status();
+}
+template <int LA, int LB, bool DROP>
+int launch_ksw2(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB, 1, 8, DROP, true, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<LA, LB, 1, 8, DROP, true, false, true>), dim3(g.total_tiles), dim3(512), LDS_BYTES, s, g);
+    return mh_launch_status();
+}
+template <int LA, int LB>
+int launch_ksw(const GemmGroup& g, hipStream_t s) {
+    bool any_drop = false;
+    for (int i = 0; i < g.n; ++i) any_drop |= (g.d[i].p.drop_rng != nullptr && g.d[i].p.drop_p > 0.f);
+    if (LA == 0 && LB == 0 && any_drop) return launch_ksw2<LA, LB, true>(g, s);
+    return launch_ksw2<LA, LB, false>(g, s);
+}
+template <int LA, int LB>
+int launch_db(const GemmGroup& g, hipStream_t s) {
+    bool any_drop = false;
+    for (int i = 0; i < g.n; ++i) any_drop |= (g.d[i].p.drop_rng != nullptr && g.d[i].p.drop_p > 0.f);
+    if (LA == 0 && LB == 0 && any_drop) return launch_db2<LA, LB, true>(g, s);
+    return launch_db2<LA, LB, false>(g, s);
+}
 template <int LA, int LB, int NW, bool DROP>
 int launch_nw2(const GemmGroup& g, hipStream_t s) {
     static int pref = -1;     // A/B switch: MEMEHIP_GEMM_EPI_PREFETCH=0 loads the epilogue operands inside the store loop
@@ -1161,6 +1278,8 @@ int launch_wide(const GemmGroup& g, hipStream_t s) {
 }
 template <int LA, int LB>
 int launch(const GemmGroup& g, hipStream_t s) {
+    if (g_variant == 8) return launch_ksw<LA, LB>(g, s);
+    if (g_variant == 7) return launch_db<LA, LB>(g, s);
     if (g_variant == 6) return launch_s4<LA, LB>(g, s);
     if (g_variant == 0) return launch1<LA, LB, 0>(g, s);
     if (g_variant == 1) return launch1<LA, LB, 1>(g, s);
@@ -1178,7 +1297,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     if (g_variant < 0) {
         const char* e = getenv("MEMEHIP_GEMM_VARIANT");
         g_variant = e ? atoi(e) : 4;
-        if (g_variant < 0 || g_variant > 6) g_variant = 4;
+        if (g_variant < 0 || g_variant > 8) g_variant = 4;
     }
     const int tile_m = (g_variant == 2 || g_variant == 3) ? R_BM : BM;
     // the wide (128x256) kernel: only the default variant, only K-contiguous A, every N a multiple of 256, and only
@@ -1189,7 +1308,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         wide_mode = e ? atoi(e) : 0;
     }
     // (measured: forward layout 620 vs 756 TF/s on FFN up -- slower; dgrad layout 805 vs 723 TF/s on FFN-down dgrad)
-    bool wide = (g_variant == 4) && !a_kmajor && wide_mode > 0 && (b_kmajor || wide_mode == 2);
+    bool wide = (g_variant == 4 || g_variant == 7 || g_variant == 8) && !a_kmajor && wide_mode > 0 && (b_kmajor || wide_mode == 2);
     if (wide) {
         long t4 = 0, t7 = 0;
         for (int i = 0; i < n_problems; ++i) {
@@ -1223,7 +1342,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         g.d[i].kchunk = 0;
         int splits = 1;
         if (p.ksplit > 1) {       // split-K: f32 output slabs [ksplit][M][ldc], default kernel variant only, no fused epilogue
-            if (g_variant != 4 || wide || !(p.flags & MH_GEMM_OUT_F32) || (p.flags & (MH_GEMM_ACCUM | MH_GEMM_GELU)) || p.bias ||
+            if ((g_variant != 4 && g_variant != 7 && g_variant != 8) || wide || !(p.flags & MH_GEMM_OUT_F32) || (p.flags & (MH_GEMM_ACCUM | MH_GEMM_GELU)) || p.bias ||
                 p.residual || p.aux || p.mul || p.rowsum || p.rows_dev || p.drop_rng)
                 return MH_EINVAL;
             const int kc = ((p.K + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
@@ -1259,7 +1378,7 @@ extern "C" int mh_gemm_ksplit_for(int K, int want) {
 
 // experiment knob (A/B in one process): 0 = register-staged tiles, 1 = LDS-DMA staged tiles
 extern "C" int mh_gemm_set_variant(int v) {
-    if (v < 0 || v > 6) return MH_EINVAL;
+    if (v < 0 || v > 8) return MH_EINVAL;
     g_variant = v;
     return MH_OK;
 }
