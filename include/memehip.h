@@ -105,8 +105,9 @@ int mh_gemm_ksplit_for(int K, int want);
  * groups in ping-pong read/MFMA slots; 4 = LDS-DMA, 8 waves of 64x32 (default: 4 waves/SIMD hide the
  * barrier + LDS latency best on this path's shapes); 5 = LDS-DMA, 16 waves of 32x32; 6 = variant 4's tile with a
  * four-slot ring of 32-deep K steps and counted vmcnt (slower: a barrier per 8 MFMAs).
- * Default 4 (or env MEMEHIP_GEMM_VARIANT at first launch).  * 7 = variant 4 with the MFMA fragments double-buffered in registers; 8 = variant 4's tile with the two halves of a K tile on
- * two groups of four waves (64x64 per wave), accumulators merged in the epilogue (both measured slower or equal: DESIGN.md 5.1). */
+ * 7 = variant 4 with the MFMA fragments double-buffered in registers; 8 = variant 4's tile with the two halves of a K tile on
+ * two groups of four waves (64x64 per wave), accumulators merged in the epilogue (both measured slower or equal: DESIGN.md 5.1).
+ * Default 4 (or env MEMEHIP_GEMM_VARIANT at first launch). */
 int mh_gemm_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------
