@@ -381,9 +381,12 @@ def test_distilbert_known_parameter_count(pkg):
     assert model.n_parameters() == 135_326_210          # DistilBERT_example_task2A.ipynb:4301
 
 
-def test_hf_trainer_runs_the_text_classifier(pkg, golden_dir, tmp_path):
+@pytest.mark.parametrize("size", ["small", "distilbert-base-multilingual-cased"])
+def test_hf_trainer_runs_the_text_classifier(pkg, golden_dir, tmp_path, size):
     """BASELINE config 1 through transformers.Trainer itself (the reference's caller, DistilBERT_example_task2A.py:324-334):
-    DistilBERT-shaped encoder, seq 64, batch 8, the dev JSON sample."""
+    seq 64, batch 8, the dev JSON sample -- with a small DistilBERT-shaped encoder, and at the true shape of the reference's
+    checkpoint (6 x 768, vocabulary 119 547, no token-type table: the 135 326 210-parameter model of the notebook), random-init,
+    `head="distilbert"` (pre_classifier + classifier, as DistilBertForSequenceClassification)."""
     transformers = pytest.importorskip("transformers")
     from transformers import Trainer, TrainingArguments, default_data_collator
     df = pkg.read_data(os.path.join(golden_dir, "dev_sample12.json"))
@@ -397,9 +400,14 @@ def test_hf_trainer_runs_the_text_classifier(pkg, golden_dir, tmp_path):
             e = tok.encode_plus(df["text"].iloc[i], add_special_tokens=True, max_length=64, padding="max_length", truncation=True)
             return {"input_ids": e["input_ids"][0], "attention_mask": e["attention_mask"][0], "labels": int(pkg.l2id[df["label"].iloc[i]])}
 
-    tc = pkg.TextConfig(vocab_size=2000, hidden=128, layers=2, heads=2, intermediate=256, max_position=64, type_vocab=0)
-    model = pkg.TextClassifier(tc, pooling_type="attention", num_classes=2, attention_hidden_size=64, compute_dtype="fp16")
-    args = TrainingArguments(output_dir=str(tmp_path), learning_rate=2e-4, num_train_epochs=3, per_device_train_batch_size=8,
+    if size == "small":
+        tc = pkg.TextConfig(vocab_size=2000, hidden=128, layers=2, heads=2, intermediate=256, max_position=64, type_vocab=0)
+        model = pkg.TextClassifier(tc, pooling_type="attention", num_classes=2, attention_hidden_size=64, compute_dtype="fp16")
+    else:
+        tc = pkg.TextConfig(vocab_size=119547, hidden=768, layers=6, heads=12, intermediate=3072, max_position=512, type_vocab=0)
+        model = pkg.TextClassifier(tc, pooling_type="cls", num_classes=2, head="distilbert", compute_dtype="fp16")
+        assert model.n_parameters() == 135_326_210
+    args = TrainingArguments(output_dir=str(tmp_path), learning_rate=2e-4 if size == "small" else 5e-5, num_train_epochs=3, per_device_train_batch_size=8,
                              per_device_eval_batch_size=8, save_strategy="no", report_to=[], logging_steps=1, seed=42,
                              remove_unused_columns=False)
     trainer = Trainer(model=model, args=args, train_dataset=DS(), eval_dataset=DS(), data_collator=default_data_collator)
