@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import weakref
 from typing import Dict, Optional
 
@@ -972,7 +973,6 @@ class GraphedStep:
         if reducer is not None:
             optimizer.grad_scale = reducer.grad_scale
         self.graphs = None
-        import os
         ddp_mode = ddp_mode or os.environ.get("MEMEHIP_DDP_MODE", "segments")
         if ddp_mode not in ("stream", "segments"):
             raise ValueError(f"ddp_mode must be 'stream' or 'segments', got {ddp_mode!r}")
@@ -1006,7 +1006,6 @@ class GraphedStep:
         if self.side is None and not self.ddp_stream:
             # data parallel: `ddp_group` consecutive layer segments share one hipGraph and one all-reduce bucket (their
             # gradient ranges are adjacent in the flat buffer): fewer graph boundaries, larger RCCL messages
-            import os
             # (measured on a 1-rank RCCL group: 11.21 ms/step with one graph per layer, 10.99 in pairs, 10.97 in threes).
             # The last two layers keep their own buckets, so the all-reduce left exposed after the backward stays small.
             group = max(1, int(os.environ.get("MEMEHIP_DDP_GROUP", "2")))
@@ -1056,7 +1055,6 @@ class GraphedStep:
                 events = {}
                 done = []
                 red = self.reducer if self.ddp_stream else None
-                import os
                 group = max(1, int(os.environ.get("MEMEHIP_DDP_GROUP", "2")))
                 n_layer_segs = sum(1 for sg in p.bwd if sg.name.startswith("bwd_layer_"))
                 pend, pend_ev, seen = [], [], 0

@@ -274,31 +274,30 @@ def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode, rccl_world1):
     cfg = O.tiny_config("cls")
     text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=11)
     dev = [t.cuda() for t in (text, image, mask, labels)]
-    if True:
-        m1, _ = _make(pkg, O, cfg, 13)
-        m2, _ = _make(pkg, O, cfg, 13)
-        o1 = pkg.Adam(m1.parameters(), lr=LR, max_grad_norm=clip)
-        o2 = pkg.Adam(m2.parameters(), lr=LR, max_grad_norm=clip)
-        ddp.broadcast_parameters(m2.flat_params)
-        red = ddp.GradientReducer(m2.flat_grads, bucket_cap_elems=1 << 16)
-        g1 = pkg.GraphedStep(m1, o1, 4, 16)
-        g2 = pkg.GraphedStep(m2, o2, 4, 16, reducer=red, ddp_mode=ddp_mode)
-        assert g2.ddp_opt_in_bwd == (clip is None)
-        end = ddp.check_bucket_cover(g2.plan.bucket_after, m2.layout.n_total)
-        assert end == m2.layout.spec["bert.embeddings.token_type_embeddings.weight"].offset   # tables go by gather
-        for _ in range(3):
-            g1.load_batch(*dev)
-            g2.load_batch(*dev)
-            l1, _ = g1.step()
-            l2, _ = g2.step()
-            torch.cuda.synchronize()
-            assert float(l1) == float(l2)
-            assert torch.equal(m1.flat_params, m2.flat_params)
-        assert red.reduced_elems == 3 * end
-        if ddp_mode == "stream":
-            assert len(g2.graphs) == 1       # the forward; the backward is stream-ordered eager launches
-        else:
-            assert 4 <= len(g2.graphs) <= len(g2.plan.bwd) + 3   # fwd, opt, gather marker + segments (paired)
+    m1, _ = _make(pkg, O, cfg, 13)
+    m2, _ = _make(pkg, O, cfg, 13)
+    o1 = pkg.Adam(m1.parameters(), lr=LR, max_grad_norm=clip)
+    o2 = pkg.Adam(m2.parameters(), lr=LR, max_grad_norm=clip)
+    ddp.broadcast_parameters(m2.flat_params)
+    red = ddp.GradientReducer(m2.flat_grads, bucket_cap_elems=1 << 16)
+    g1 = pkg.GraphedStep(m1, o1, 4, 16)
+    g2 = pkg.GraphedStep(m2, o2, 4, 16, reducer=red, ddp_mode=ddp_mode)
+    assert g2.ddp_opt_in_bwd == (clip is None)
+    end = ddp.check_bucket_cover(g2.plan.bucket_after, m2.layout.n_total)
+    assert end == m2.layout.spec["bert.embeddings.token_type_embeddings.weight"].offset   # tables go by gather
+    for _ in range(3):
+        g1.load_batch(*dev)
+        g2.load_batch(*dev)
+        l1, _ = g1.step()
+        l2, _ = g2.step()
+        torch.cuda.synchronize()
+        assert float(l1) == float(l2)
+        assert torch.equal(m1.flat_params, m2.flat_params)
+    assert red.reduced_elems == 3 * end
+    if ddp_mode == "stream":
+        assert len(g2.graphs) == 1       # the forward; the backward is stream-ordered eager launches
+    else:
+        assert 4 <= len(g2.graphs) <= len(g2.plan.bwd) + 3   # fwd, opt, gather marker + segments (paired)
 
 
 def test_ddp_bf16_compressed_exchange_world1(pkg, rccl_world1):
@@ -311,27 +310,26 @@ def test_ddp_bf16_compressed_exchange_world1(pkg, rccl_world1):
     cfg = O.tiny_config("cls")
     text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=12)
     dev = [t.cuda() for t in (text, image, mask, labels)]
-    if True:
-        m1, _ = _make(pkg, O, cfg, 14)
-        m2, _ = _make(pkg, O, cfg, 14)
-        o1, o2 = pkg.Adam(m1.parameters(), lr=LR), pkg.Adam(m2.parameters(), lr=LR)
-        r1 = ddp.GradientReducer(m1.flat_grads, bucket_cap_elems=1 << 16)
-        r2 = ddp.GradientReducer(m2.flat_grads, bucket_cap_elems=1 << 16, compress="bf16")
-        g1 = pkg.GraphedStep(m1, o1, 4, 16, reducer=r1)
-        g2 = pkg.GraphedStep(m2, o2, 4, 16, reducer=r2)
-        for k in range(3):
-            g1.load_batch(*dev)
-            g2.load_batch(*dev)
-            l1, _ = g1.step()
-            l2, _ = g2.step()
-            torch.cuda.synchronize()
-            assert abs(float(l1) - float(l2)) < 1e-4
-            d = (m1.flat_params - m2.flat_params).abs()
-            assert float(d.max()) <= 2.05 * LR * (k + 1) and float(d.mean()) < 0.05 * LR, (float(d.max()), float(d.mean()))
-        assert r2.reduced_elems == r1.reduced_elems and r2.wire_bytes == 0          # one rank: nothing crosses a link
-        # the exchanged gradients are exactly bf16 values
-        gsl = m2.flat_grads[:4096]
-        assert torch.equal(gsl, gsl.to(torch.bfloat16).float())
+    m1, _ = _make(pkg, O, cfg, 14)
+    m2, _ = _make(pkg, O, cfg, 14)
+    o1, o2 = pkg.Adam(m1.parameters(), lr=LR), pkg.Adam(m2.parameters(), lr=LR)
+    r1 = ddp.GradientReducer(m1.flat_grads, bucket_cap_elems=1 << 16)
+    r2 = ddp.GradientReducer(m2.flat_grads, bucket_cap_elems=1 << 16, compress="bf16")
+    g1 = pkg.GraphedStep(m1, o1, 4, 16, reducer=r1)
+    g2 = pkg.GraphedStep(m2, o2, 4, 16, reducer=r2)
+    for k in range(3):
+        g1.load_batch(*dev)
+        g2.load_batch(*dev)
+        l1, _ = g1.step()
+        l2, _ = g2.step()
+        torch.cuda.synchronize()
+        assert abs(float(l1) - float(l2)) < 1e-4
+        d = (m1.flat_params - m2.flat_params).abs()
+        assert float(d.max()) <= 2.05 * LR * (k + 1) and float(d.mean()) < 0.05 * LR, (float(d.max()), float(d.mean()))
+    assert r2.reduced_elems == r1.reduced_elems and r2.wire_bytes == 0          # one rank: nothing crosses a link
+    # the exchanged gradients are exactly bf16 values
+    gsl = m2.flat_grads[:4096]
+    assert torch.equal(gsl, gsl.to(torch.bfloat16).float())
 
 
 def test_ddp_two_ranks_on_one_gpu_match_the_global_batch():
