@@ -17,7 +17,6 @@ returns ``(loss, logits)`` for HF Trainer.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import List, Optional
 
 import torch

@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import ast
 import os
-import sys
 from types import SimpleNamespace
 
 import numpy as np
