@@ -67,6 +67,9 @@ const char* mh_status_str(int status);
 #define MH_GEMM_OUT_F32 2
 #define MH_GEMM_ACCUM 4
 #define MH_GEMM_QUICK_GELU 8 /* the activation (MH_GEMM_GELU) and the derivative (mul) are quick-GELU x*sigmoid(1.702x): CLIP towers */
+#define MH_GEMM_DERIV_AUX 16 /* with MH_GEMM_GELU: aux receives act'(v) instead of v (same exponential as the activation);
+                              * with `mul`: the operand IS that stored derivative and is multiplied in as it is -- the pair moves
+                              * the erf / exp of the backward epilogue into the forward one, where it is computed anyway */
 
 typedef struct MhGemmProblem {
     const void* A;        /* bf16 */

@@ -19,6 +19,7 @@ MH_GEMM_GELU = 1
 MH_GEMM_OUT_F32 = 2
 MH_GEMM_ACCUM = 4
 MH_GEMM_QUICK_GELU = 8
+MH_GEMM_DERIV_AUX = 16
 MH_COLSUM_MAX_JOBS = 64
 MH_LN_MAX_JOBS = 4
 MH_ATTN_MAX_GROUP = 2

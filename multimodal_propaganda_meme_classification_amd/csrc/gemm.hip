@@ -211,26 +211,51 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= mh_drop_mul(drop, dr * (uint64_t)P.N + (uint64_t)(gn + e));
         }
-        if (P.aux) {
+        if ((flags & MH_GEMM_GELU) && (flags & MH_GEMM_DERIV_AUX) && P.aux) {
+            // activation and its derivative from the same exponential: aux receives act'(v), which the dgrad launch multiplies
+            // by as it is (no transcendental math in the backward epilogue)
             Pack8 u;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) u.e[e] = mh_f2bf(v[e]);
-            *(i32x4*)((h16*)P.aux + o) = u.v;
-        }
-        if (flags & MH_GEMM_GELU) {
             if (flags & MH_GEMM_QUICK_GELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = qgelu_f(v[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float sg = qgelu_sig(v[e]);
+                    u.e[e] = mh_f2bf(sg * (1.0f + 1.702f * v[e] * (1.0f - sg)));
+                    v[e] *= sg;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const GeluParts gp = gelu_parts(v[e]);
+                    u.e[e] = mh_f2bf(gp.cdf + v[e] * gp.pdf);
+                    v[e] *= gp.cdf;
+                }
+            }
+            *(i32x4*)((h16*)P.aux + o) = u.v;
+        } else {
+            if (P.aux) {
+                Pack8 u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u.e[e] = mh_f2bf(v[e]);
+                *(i32x4*)((h16*)P.aux + o) = u.v;
+            }
+            if (flags & MH_GEMM_GELU) {
+                if (flags & MH_GEMM_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = qgelu_f(v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                }
             }
         }
         if (P.mul) {
             Pack8 u;
             if (PREF) u.v = pf->mul[it];
             else u.v = *(const i32x4*)((const h16*)P.mul + o);
-            if (flags & MH_GEMM_QUICK_GELU) {
+            if (flags & MH_GEMM_DERIV_AUX) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= mh_bf2f(u.e[e]);
+            } else if (flags & MH_GEMM_QUICK_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dqgelu_f(mh_bf2f(u.e[e]));
             } else {

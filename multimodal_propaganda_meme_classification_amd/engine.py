@@ -23,13 +23,14 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MH_GEMM_QUICK_GELU, MhAttnProblem, MhColsumJob, MhGemmProblem, MhHeadGrads,
+from ._lib import (MH_GEMM_ACCUM, MH_GEMM_DERIV_AUX, MH_GEMM_GELU, MH_GEMM_OUT_F32, MH_GEMM_QUICK_GELU, MhAttnProblem, MhColsumJob, MhGemmProblem, MhHeadGrads,
                    MhHeadParams, MhLnBwdJob, MhLnFwdJob)
 from .config import Layout, ModelConfig
 
 BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
 import os as _os
 LN_PARTS = int(_os.environ.get("MEMEHIP_LN_PARTS", "512"))     # workgroups (= sets of dgamma/dbeta partials) per LayerNorm backward
+DERIV_AUX = _os.environ.get("MEMEHIP_GEMM_DERIV_AUX", "1") != "0"     # FFN-up epilogue stores gelu'(x) for the backward (A/B: 0 = store x)
 
 
 class Segment:
@@ -202,7 +203,8 @@ class Engine:
             e.mul, e.rowsum = _ptr(d.get("mul")), _ptr(d.get("rowsum"))
             e.M, e.N, e.K, e.lda, e.ldb, e.ldc = M, N, K, lda, ldb, ldc
             e.flags = (MH_GEMM_GELU if d.get("gelu") else 0) | (MH_GEMM_OUT_F32 if Cm.dtype == F32 else 0) | \
-                      (MH_GEMM_ACCUM if d.get("accum") else 0) | (MH_GEMM_QUICK_GELU if d.get("quick") else 0)
+                      (MH_GEMM_ACCUM if d.get("accum") else 0) | (MH_GEMM_QUICK_GELU if d.get("quick") else 0) | \
+                      (MH_GEMM_DERIV_AUX if d.get("deriv_aux") else 0)
             e.alpha = float(d.get("alpha", 1.0))
             if d.get("drop") is not None:
                 e.drop_rng, e.drop_p, e.drop_stream = d["drop"]
@@ -519,14 +521,15 @@ class Engine:
                                  a["y"], a["m1"], a["r1"], Tt, Dt, t.ln_eps, **tp) if has_t else None,
                 self._ln_fwd_job(b_["xp"], LI + "layernorm_after.weight", LI + "layernorm_after.bias", b_["w"], b_["m2"],
                                  b_["r2"], Ti, Di, v.ln_eps) if has_i else None])
-            # FFN up + GELU (pre-activation kept for the backward)
+            # FFN up + GELU; "h" keeps gelu'(pre-activation) for the backward (computed here from the activation's own exponential:
+            # MH_GEMM_DERIV_AUX; MEMEHIP_GEMM_DERIV_AUX=0 keeps the pre-activation and evaluates gelu' in the backward epilogue)
             pr = []
             if has_t:
                 pr.append(self._fwd_prob(a["y"], self.w(LT + "intermediate.dense.weight"), a["g"], Tt, It, Dt,
-                                         bias=self.p(LT + "intermediate.dense.bias"), aux=a["h"], gelu=True, **tp))
+                                         bias=self.p(LT + "intermediate.dense.bias"), aux=a["h"], gelu=True, deriv_aux=DERIV_AUX, **tp))
             if has_i:
                 pr.append(self._fwd_prob(b_["w"], self.w(LI + "intermediate.dense.weight"), b_["g"], Ti, Ii, Di,
-                                         bias=self.p(LI + "intermediate.dense.bias"), aux=b_["h"], gelu=True, **quick))
+                                         bias=self.p(LI + "intermediate.dense.bias"), aux=b_["h"], gelu=True, deriv_aux=DERIV_AUX, **quick))
             self._gemm(pl, f, pr, False, False)
             # FFN down + residual
             pr = []
@@ -654,9 +657,10 @@ class Engine:
             # d gelu_in = (d_out @ W2) * gelu'(h)
             pr = []
             if has_t:
-                pr.append(self._dgrad_prob(t_dfm, self.w(LT + "output.dense.weight"), t_dh, Tt, Dt, It, mul=a["h"], **tp))
+                pr.append(self._dgrad_prob(t_dfm, self.w(LT + "output.dense.weight"), t_dh, Tt, Dt, It, mul=a["h"], deriv_aux=DERIV_AUX, **tp))
             if has_i:
-                pr.append(self._dgrad_prob(dXi[ci], self.w(LI + "output.dense.weight"), i_dh, Ti, Di, Ii, mul=b_["h"], **quick))
+                pr.append(self._dgrad_prob(dXi[ci], self.w(LI + "output.dense.weight"), i_dh, Ti, Di, Ii, mul=b_["h"], deriv_aux=DERIV_AUX,
+                                           **quick))
             self._gemm(pl, s, pr, False, True)
             # through W1 (text adds the residual branch df)
             pr = []

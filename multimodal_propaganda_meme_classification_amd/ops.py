@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (MH_GEMM_ACCUM, MH_GEMM_GELU, MH_GEMM_OUT_F32, MH_GEMM_QUICK_GELU, MhColsumJob, MhGemmProblem, MhHeadGrads,
+from ._lib import (MH_GEMM_ACCUM, MH_GEMM_DERIV_AUX, MH_GEMM_GELU, MH_GEMM_OUT_F32, MH_GEMM_QUICK_GELU, MhColsumJob, MhGemmProblem, MhHeadGrads,
                    MhHeadParams, check)
 
 BF16, F16, F32, I64 = torch.bfloat16, torch.float16, torch.float32, torch.int64
@@ -61,7 +61,8 @@ class Gemm:
                  "flags", "alpha", "drop", "rows_dev", "drop_rows", "ksplit")
 
     def __init__(self, A, B, C, M, N, K, lda, ldb, ldc, bias=None, residual=None, aux=None, mul=None,
-                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None, rows_dev=None, drop_rows=None, quick=False, ksplit=0):
+                 rowsum=None, gelu=False, accum=False, alpha=1.0, drop=None, rows_dev=None, drop_rows=None, quick=False, ksplit=0,
+                 deriv_aux=False):
         self.alpha = alpha
         self.ksplit = int(ksplit)      # > 1: split-K, C holds [ksplit][M][ldc] f32 slabs (see MhGemmProblem.ksplit)
         self.rows_dev, self.drop_rows = rows_dev, drop_rows     # packed token rows: device int32 [1] / int32 [M]
@@ -70,7 +71,7 @@ class Gemm:
         self.bias, self.residual, self.aux, self.mul, self.rowsum = bias, residual, aux, mul, rowsum
         self.M, self.N, self.K, self.lda, self.ldb, self.ldc = M, N, K, lda, ldb, ldc
         self.flags = (MH_GEMM_GELU if gelu else 0) | (MH_GEMM_OUT_F32 if C.dtype == F32 else 0) | \
-                     (MH_GEMM_ACCUM if accum else 0) | (MH_GEMM_QUICK_GELU if quick else 0)
+                     (MH_GEMM_ACCUM if accum else 0) | (MH_GEMM_QUICK_GELU if quick else 0) | (MH_GEMM_DERIV_AUX if deriv_aux else 0)
 
 
 def _rng(t: Optional[torch.Tensor]):
@@ -179,25 +180,25 @@ def wgrad_splitk(dy, x, M, N, K, lda, ldb, alpha=1.0, target_tiles: int = 1024, 
     return out
 
 
-def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False, drop=None, quick=False):
+def linear_fwd(x, w, bias=None, out=None, residual=None, aux=None, gelu=False, drop=None, quick=False, deriv_aux=False):
     """y[T,N] = epi(x[T,K] @ w[N,K]^T)"""
     T, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((T, N), dtype=x.dtype, device=x.device)
     gemm_grouped([Gemm(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), bias=bias, residual=residual,
-                       aux=aux, gelu=gelu, drop=drop, quick=quick)], False, False)
+                       aux=aux, gelu=gelu, drop=drop, quick=quick, deriv_aux=deriv_aux)], False, False)
     return out
 
 
-def linear_dgrad(dy, w, out=None, mul=None, residual=None, quick=False):
+def linear_dgrad(dy, w, out=None, mul=None, residual=None, quick=False, deriv_aux=False):
     """dx[T,K] = dy[T,N] @ w[N,K]  (optionally * gelu'(mul), + residual)"""
     T, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = torch.empty((T, K), dtype=dy.dtype, device=dy.device)
     gemm_grouped([Gemm(dy, w, out, T, K, N, dy.stride(0), w.stride(0), out.stride(0), mul=mul, residual=residual,
-                       quick=quick)], False, True)
+                       quick=quick, deriv_aux=deriv_aux)], False, True)
     return out
 
 

@@ -116,6 +116,20 @@ def test_gemm_epilogues_and_grouping(ops):
     pf = pre.float().requires_grad_(True)
     torch.nn.functional.gelu(pf).backward(dy.float() @ w2.float())
     close(dx, pf.grad, 1e-2, 3e-3, "dgrad*gelu'")
+    # MH_GEMM_DERIV_AUX: the forward epilogue stores gelu'(pre) (erf and quick form), the dgrad multiplies by it as it is
+    for quick in (False, True):
+        aD = torch.empty_like(o2)
+        oD = torch.empty_like(o2)
+        ops.gemm_grouped([ops.Gemm(x2, w2, oD, T2, N, K, K, K, N, bias=b2, aux=aD, gelu=True, quick=quick, deriv_aux=True)], False, False)
+        pre2 = (x2.float() @ w2.float().t() + b2).requires_grad_(True)
+        act = pre2 * torch.sigmoid(1.702 * pre2) if quick else torch.nn.functional.gelu(pre2)
+        act.sum().backward()
+        close(oD, act.detach(), 8e-3, 2e-3, f"activation (quick={quick})")
+        close(aD, pre2.grad, 6e-3, 4e-3, f"stored derivative (quick={quick})")
+        dyD = rnd(T2, K, seed=11)       # a gradient of the [T2, K]-shaped FFN output going back through w [K <- N]
+        wD = rnd(K, N, scale=0.05, seed=12)
+        dxD = ops.linear_dgrad(dyD, wD, mul=aD, quick=quick, deriv_aux=True)
+        close(dxD, (dyD.float() @ wD.float()) * aD.float(), 1e-2, 3e-3, f"dgrad * stored derivative (quick={quick})")
 
 
 def test_gemm_rejects_bad_shapes(ops):
