@@ -47,6 +47,36 @@ MH_DEV void stage_tile(const h16* __restrict__ base, size_t pitch, int row0, int
     }
 }
 
+// the same in two halves for the streaming kernels: the global loads of tile t+1 are issued before the products of tile t and
+// land in registers while they run; the LDS images are written once every wave has left tile t (one LDS slot, no exposed
+// load latency per tile).  TILE * 8 = 512 16-B chunks per tile: two per thread at 256 or 448 threads.
+template <int NT>
+struct TileRegs {
+    static constexpr int CH = (TILE * 8 + NT - 1) / NT;
+    i32x4 v[CH];
+};
+template <int NT>
+MH_DEV void tile_load(const h16* __restrict__ base, size_t pitch, int row0, int nrows, int tid, TileRegs<NT>& R) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<NT>::CH; ++i) {
+        const int q = tid + i * NT;
+        const int r = q >> 3, c = q & 7;
+        R.v[i] = i32x4{0, 0, 0, 0};
+        if (q < TILE * 8 && row0 + r < nrows) R.v[i] = *(const i32x4*)(base + (size_t)(row0 + r) * pitch + c * 8);
+    }
+}
+template <int NT>
+MH_DEV void tile_store(const TileRegs<NT>& R, int tid, char* row_img, char* tr_img) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<NT>::CH; ++i) {
+        const int q = tid + i * NT;
+        if (q >= TILE * 8) continue;
+        const int r = q >> 3, c = q & 7;
+        if (row_img) *(i32x4*)(row_img + row_img_off(r, c)) = R.v[i];
+        if (tr_img) *(i32x4*)(tr_img + tr_img_off(r, c >> 1) + ((c & 1) << 4)) = R.v[i];
+    }
+}
+
 // A/B fragment from a row image: rows rb..rb+31 (lane&31), d = 16 s + 8 h + j
 MH_DEV h16x8 frag_rows(const char* img, int rb, int s, int lane) {
     Pack8 u;
@@ -198,13 +228,38 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
 #pragma unroll
             for (int g = 0; g < 16; ++g) o[i][g] = 0.f;
         float m = NEG_BIG, l = 0.f;
+        TileRegs<NT> Rk, Rv;       // streaming: the next K / V tile on its way (registers), key mask of thread tid's key
+        int64_t Rm = 0;
+        auto pre_load = [&](int t) {
+            tile_load<NT>(kb, pitch, t * TILE, Sb, tid, Rk);
+            tile_load<NT>(vb, pitch, t * TILE, Sb, tid, Rv);
+            if (tid < TILE) {
+                const int key = t * TILE + tid;
+                Rm = (key < Sb && (!key_mask || key_mask[r0 + key] != 0)) ? 1 : 0;
+            }
+        };
+        auto pre_store = [&]() {
+            tile_store<NT>(Rk, tid, k_img, nullptr);
+            tile_store<NT>(Rv, tid, nullptr, v_img);
+            if (tid < TILE) {
+                const float bias = Rm ? 0.f : NEG_BIG;
+                kbias[tid] = bias;
+                const unsigned long long bal = __ballot(bias == 0.f);
+                if (tid == 0) {
+                    kany[0] = (bal & 0xffffffffull) != 0;
+                    kany[1] = (bal >> 32) != 0;
+                }
+            }
+        };
+        if (NT_RES == 0 && ntiles > 0) pre_load(0);
 
         for (int t = 0; t < ntiles; ++t) {
             const int slot = NT_RES > 0 ? t : 0;
             if (NT_RES == 0) {
                 __syncthreads();
-                stage(t, 0);
+                pre_store();
                 __syncthreads();
+                if (t + 1 < ntiles) pre_load(t + 1);
                 if (!active) continue;
             }
             const char* ki = k_img + slot * IMG;
@@ -362,13 +417,38 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 16; ++g) dq[i][g] = 0.f;
+        TileRegs<NT> Rk, Rv;       // streaming: the next K / V tile on its way (see tile_load)
+        int64_t Rm = 0;
+        auto pre_load = [&](int t) {
+            tile_load<NT>(kb, pitch, t * TILE, Sb, tid, Rk);
+            tile_load<NT>(vb, pitch, t * TILE, Sb, tid, Rv);
+            if (tid < TILE) {
+                const int key = t * TILE + tid;
+                Rm = (key < Sb && (!key_mask || key_mask[r0 + key] != 0)) ? 1 : 0;
+            }
+        };
+        auto pre_store = [&]() {
+            tile_store<NT>(Rk, tid, k_img, kt_img);
+            tile_store<NT>(Rv, tid, v_img, nullptr);
+            if (tid < TILE) {
+                const float bias = Rm ? 0.f : NEG_BIG;
+                kbias[tid] = bias;
+                const unsigned long long bal = __ballot(bias == 0.f);
+                if (tid == 0) {
+                    kany[0] = (bal & 0xffffffffull) != 0;
+                    kany[1] = (bal >> 32) != 0;
+                }
+            }
+        };
+        if (NT_RES == 0 && ntiles > 0) pre_load(0);
 
         for (int t = 0; t < ntiles; ++t) {
             const int slot = NT_RES > 0 ? t : 0;
             if (NT_RES == 0) {
                 __syncthreads();
-                stage(t, 0);
+                pre_store();
                 __syncthreads();
+                if (t + 1 < ntiles) pre_load(t + 1);
                 if (!active) continue;
             }
             const char* ki = k_img + slot * IMG;
@@ -510,13 +590,64 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
         // every key of this wave's tile masked: P == 0 for all queries, so dK = dV = 0 (resident mode has no
         // barriers inside the sweep, so the wave may leave early)
         const bool any_key = __ballot(kbias == 0.f) != 0ull;
+        // streaming: the next Q / dO tile, its log-sum-exp values and (OWN_DELTA) the dO / O row halves delta is summed from
+        TileRegs<NT> Rq, Rdo;
+        float Rl = 0.f, Rd = 0.f;
+        i32x4 Ra[4], Ro[4];
+        auto pre_load = [&](int t) {
+            tile_load<NT>(qb, pitch, t * TILE, Sb, tid, Rq);
+            tile_load<NT>(dob, (size_t)H * HD, t * TILE, Sb, tid, Rdo);
+            if (tid < TILE) {
+                const int qq = t * TILE + tid;
+                Rl = qq < Sb ? lse[((size_t)b * H + hh) * S + qq] * LOG2E : 1.0e30f;
+                if (!OWN_DELTA) Rd = qq < Sb ? delta[((size_t)b * H + hh) * S + qq] : 0.f;
+            }
+            if (OWN_DELTA && tid < 2 * TILE) {
+                const int i = tid >> 1, hf = tid & 1;
+                const int qq = t * TILE + i;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { Ra[s4] = i32x4{0, 0, 0, 0}; Ro[s4] = i32x4{0, 0, 0, 0}; }
+                if (qq < Sb) {
+                    const h16* dr = dob + (size_t)qq * H * HD + 8 * hf;
+                    const h16* orow = outp + (r0 + qq) * (size_t)H * HD + hh * HD + 8 * hf;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        Ra[s4] = *(const i32x4*)(dr + 16 * s4);
+                        Ro[s4] = *(const i32x4*)(orow + 16 * s4);
+                    }
+                }
+            }
+        };
+        auto pre_store = [&]() {
+            tile_store<NT>(Rq, tid, q_img, qt_img);
+            tile_store<NT>(Rdo, tid, do_img, dot_img);
+            if (tid < TILE) {
+                lse_t[tid] = Rl;
+                if (!OWN_DELTA) dl_t[tid] = Rd;
+            }
+            if (OWN_DELTA && tid < 2 * TILE) {     // same summation order as stage() / the dQ kernel: bit-identical delta
+                float dl = 0.f;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    Pack8 a, o;
+                    a.v = Ra[s4];
+                    o.v = Ro[s4];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dl += (float)a.h[j] * (float)o.h[j];
+                }
+                dl += __shfl_xor(dl, 1, 64);
+                if ((tid & 1) == 0) dl_t[tid >> 1] = dl;
+            }
+        };
+        if (NT_RES == 0 && ntiles > 0) pre_load(0);
 
         for (int t = 0; t < ntiles; ++t) {
             const int slot = NT_RES > 0 ? t : 0;
             if (NT_RES == 0) {
                 __syncthreads();
-                stage(t, 0);
+                pre_store();
                 __syncthreads();
+                if (t + 1 < ntiles) pre_load(t + 1);
                 if (!active) continue;
             }
             if (!any_key) continue;
