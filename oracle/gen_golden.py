@@ -311,8 +311,30 @@ def gen_index_fixtures():
     print("wrote index_fixtures.npz")
 
 
+def gen_focal_case():
+    """sigmoid focal loss (Kevin's criterion, Multimodal_example_task2C.py:167,711 = torchvision.ops.sigmoid_focal_loss, not
+    installed here) pinned to the other implementation of the same detectron formula that IS importable: transformers' DETR
+    loss helper (inputs [B, 1], num_boxes = B: loss.mean(1).sum() / B = the mean over the batch)."""
+    from transformers.loss.loss_for_object_detection import sigmoid_focal_loss as hf_focal
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    for i, (alpha, gamma) in enumerate(((0.25, 2.0), (0.5, 1.0), (-1.0, 2.0))):
+        x = (torch.randn(48, generator=g) * 3).requires_grad_(True)
+        t = (torch.rand(48, generator=g) < 0.28).float()
+        loss = hf_focal(x[:, None], t[:, None], num_boxes=x.numel(), alpha=alpha, gamma=gamma)
+        loss.backward()
+        out.update({f"x{i}": x.detach().numpy(), f"t{i}": t.numpy(), f"loss{i}": loss.detach().numpy(), f"dx{i}": x.grad.numpy(),
+                    f"alpha{i}": np.float32(alpha), f"gamma{i}": np.float32(gamma)})
+    path = os.path.join(GOLDEN, "focal_hf.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
 def main():
     torch.set_num_threads(8)
+    if "--only-focal" in sys.argv:
+        gen_focal_case()
+        return
     if "--only-resnet" in sys.argv:
         gen_resnet_case()
         return

@@ -34,6 +34,15 @@ def test_sigmoid_focal_loss_kernel(pkg):
             np.testing.assert_allclose(float(loss), float(ref), rtol=2e-5, atol=1e-7)
             np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=1e-7)
             assert int(crit.last_correct) == int(((x > 0) == (t > 0.5)).sum())
+    # and against the fixture made with transformers' implementation of the same loss (tests/golden/focal_hf.npz)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "focal_hf.npz"))
+    for i in range(3):
+        xd = torch.from_numpy(z[f"x{i}"]).cuda().requires_grad_(True)
+        loss = pkg.SigmoidFocalLoss()(xd, torch.from_numpy(z[f"t{i}"]).cuda(), alpha=float(z[f"alpha{i}"]), gamma=float(z[f"gamma{i}"]),
+                                      reduction="mean")
+        loss.backward()
+        np.testing.assert_allclose(float(loss), float(z[f"loss{i}"]), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(xd.grad.cpu().numpy(), z[f"dx{i}"], rtol=2e-4, atol=1e-7)
 
 
 def test_kevin_style_step_focal_param_groups_warmup_clip(pkg):

@@ -119,6 +119,19 @@ def test_adam_matches_torch_optim():
         np.testing.assert_allclose(p["w"].numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
 
 
+def test_focal_loss_matches_transformers_detr_helper(golden_dir):
+    """The oracle's sigmoid focal loss (torchvision's formula, restated) against fixtures made with transformers' implementation of
+    the same detectron loss (oracle/gen_golden.py --only-focal): value and gradient, three (alpha, gamma) settings."""
+    z = np.load(os.path.join(golden_dir, "focal_hf.npz"))
+    for i in range(3):
+        x = torch.from_numpy(z[f"x{i}"]).requires_grad_(True)
+        t = torch.from_numpy(z[f"t{i}"])
+        loss = O.sigmoid_focal_loss(x, t, alpha=float(z[f"alpha{i}"]), gamma=float(z[f"gamma{i}"]))
+        loss.backward()
+        np.testing.assert_allclose(loss.detach().numpy(), z[f"loss{i}"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(x.grad.numpy(), z[f"dx{i}"], rtol=1e-5, atol=1e-8)
+
+
 def test_clip_matches_torch():
     torch.manual_seed(1)
     w = torch.nn.Parameter(torch.randn(10, 3))
