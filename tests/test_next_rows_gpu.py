@@ -1,6 +1,8 @@
 """SURVEY section 8(f) rank 1 ("Kevin's training-step extras"), the parts built so far: sigmoid focal loss on a
 1-logit head, parameter-group learning rates (0.8x encoders), linear warm-up schedule, gradient clipping.
 GPU box only."""
+import os
+
 import numpy as np
 import pytest
 import torch
