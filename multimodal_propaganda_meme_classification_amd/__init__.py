@@ -13,5 +13,7 @@ from .heads import (MCA3, ConcatAttention3, FineTuneMLP, KevinMultimodalClassifi
                     OrganizersMultimodalClassifier, SequencePooling, TextClassifier, TrainerModel)
 from .data import HashTokenizer, MultimodalDataset, id2l, l2id, normalize_images, read_data  # noqa: F401
 from .train import evaluate, test, train  # noqa: F401
+from . import kevin  # noqa: F401
+from .kevin import KevinMultimodalDataset, kevin_collate  # noqa: F401
 from .resnet import Bottleneck, ResNet50, ResNetClassifier  # noqa: F401
 from .features import dump_features, get_features  # noqa: F401

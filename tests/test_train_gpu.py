@@ -96,3 +96,62 @@ def test_feature_dump_feeds_the_svm_baseline(pkg, golden_dir, tmp_path):
             f.write(f"{i}\t{lab}\timgbert\n")
     lines = open(out).read().splitlines()[1:]
     assert len(lines) == len(id_lab) and all(LINE.match(l) for l in lines)
+
+
+def test_kevin_dataset_and_loops_end_to_end(pkg, tmp_path):
+    """Kevin's callers (Multimodal_example_task2C.py:208-304, 688-871) on the HIP path: the dataset's dict keys, one epoch of
+    train() with focal loss + fused Adam over get_params + warm-up schedule + the device image pipeline (augmentations on),
+    test() -> (loss, accuracy, macro F1, ROC-optimal threshold), evaluate() -> the two TSVs in the reference's formats."""
+    import re
+    from PIL import Image
+    kv = pkg.kevin
+    rng = np.random.default_rng(0)
+    n = 24
+    names = []
+    for i in range(n):                                   # real image files of different sizes: the device resizes them
+        h, w = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+        arr = rng.integers(0, 255, (h, w, 3), dtype=np.uint8)
+        arr[:, :, 0] = (arr[:, :, 0] // 4 + (190 if i % 2 else 10)).astype(np.uint8)      # a learnable cue: red level = label
+        p = tmp_path / f"img{i}.png"
+        Image.fromarray(arr).save(p)
+        names.append(p.name)
+    ids = [f"id{i}" for i in range(n)]
+    texts = [("propaganda words here " if i % 2 else "plain words there ") + str(i) for i in range(n)]
+    labels = [i % 2 for i in range(n)]
+    caps = [f"a meme of thing {i % 3}" for i in range(n)]
+    with pytest.raises(ValueError, match="captions"):
+        kv.KevinMultimodalDataset(ids, texts, names, labels)
+    ds = kv.KevinMultimodalDataset(ids, texts, names, labels, captions=caps, max_seq_len=16, image_size=32, image_root=str(tmp_path),
+                                   vocab_size=600, english_vocab_size=500)
+    item = ds[3]
+    assert sorted(item) == sorted(["id", "text", "text_mask", "caption_text", "caption_text_mask", "image", "label"])      # :290-303
+    assert item["text"].shape == (16,) and item["caption_text_mask"].dtype == torch.int64 and item["image"].dtype == np.uint8
+    assert sorted(kv.KevinMultimodalDataset(ids, texts, names, labels, is_test=True, captions=caps, image_root=str(tmp_path))[0]) == \
+        sorted(["id", "text", "text_mask", "caption_text", "caption_text_mask", "image"])
+    loader = torch.utils.data.DataLoader(ds, batch_size=8, shuffle=False, collate_fn=kv.kevin_collate)
+    tc = pkg.TextConfig(vocab_size=600, hidden=128, layers=2, heads=2, intermediate=256, max_position=64)
+    ic = pkg.ImageConfig(image_size=32, hidden=128, layers=2, heads=2, intermediate=256)
+    cc = pkg.TextConfig(vocab_size=500, hidden=128, layers=1, heads=2, intermediate=256, max_position=64)
+    model = pkg.KevinMultimodalClassifier("concatenation", text=tc, image=ic, caption=cc, proj=64, compute_dtype="fp16", seed=1).cuda()
+    opt = pkg.Adam(model.get_params(2e-3), max_grad_norm=1.0)
+    sched = pkg.get_linear_schedule_with_warmup(opt, num_warmup_steps=1, num_training_steps=12)
+    crit = pkg.SigmoidFocalLoss()
+    dev = torch.device("cuda")
+    pipe_train = pkg.data.DeviceImagePipeline(image_size=32, mode="stretch", augment=True, device=dev)
+    pipe_eval = pkg.data.DeviceImagePipeline(image_size=32, mode="stretch", augment=False, device=dev)
+    calls = []
+    hist = [kv.train(model, loader, crit, opt, sched, dev, epoch, image_pipeline=pipe_train, eval_fn=calls.append, log_every=0)
+            for epoch in range(4)]
+    assert all(np.isfinite(h[0]) for h in hist) and hist[-1][0] < hist[0][0], hist
+    assert calls[:3] == [1, 2, 3]                               # check_interval = 3 // 2 = 1 -> every batch, as the reference computes it
+    loss, acc, f1, thr = kv.test(model, loader, crit, dev, 0, image_pipeline=pipe_eval)
+    assert np.isfinite(loss) and 0.0 <= acc <= 1.0 and 0.0 <= f1 <= 1.0 and np.isfinite(thr)
+    f_lab, f_prob = kv.evaluate(model, loader, thr, dev, team_name="t", fold=2, out_dir=str(tmp_path), image_pipeline=pipe_eval)
+    lines = open(f_lab).read().splitlines()
+    assert lines[0] == "id\tlabel\trun_id" and len(lines) == n + 1
+    assert all(re.fullmatch(r"id\d+\t(not_propaganda|propaganda)\t\S+", ln) for ln in lines[1:])
+    plines = open(f_prob).read().splitlines()
+    assert os.path.basename(f_prob) == "task2C_t_probs_fold_2.tsv" and plines[0] == "id\tlabel\tprob\trun_id"
+    for ln in plines[1:]:
+        _id, lab, prob, _ = ln.split("\t")
+        assert (float(prob) > thr) == (lab == "propaganda")
