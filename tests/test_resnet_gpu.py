@@ -245,6 +245,35 @@ def test_resnet_classifier_trainer_protocol_and_fused_adam(pkg):
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
 
 
+def test_hf_trainer_runs_the_resnet_classifier(pkg, tmp_path):
+    """BASELINE config 2's caller: transformers.Trainer over ``model(pixel_values=..., labels=...) -> (loss, logits)``
+    (ResNet_example_task2B.py:206-221, 269-285), batch 8, a reduced-depth tower, images whose mean encodes the label."""
+    pytest.importorskip("transformers")
+    from transformers import Trainer, TrainingArguments, default_data_collator
+    g = torch.Generator().manual_seed(4)
+    labels = [i % 2 for i in range(16)]
+    images = [torch.randn((3, 64, 64), generator=g) * 0.5 + (1.0 if y else -1.0) for y in labels]
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(labels)
+
+        def __getitem__(self, i):
+            return {"pixel_values": images[i], "labels": labels[i]}
+
+    model = pkg.ResNetClassifier(num_labels=2, compute_dtype="fp16", layers=(1, 1, 1, 1))
+    args = TrainingArguments(output_dir=str(tmp_path), learning_rate=1e-3, num_train_epochs=4, per_device_train_batch_size=8,
+                             per_device_eval_batch_size=8, save_strategy="no", report_to=[], logging_steps=1, seed=1,
+                             remove_unused_columns=False)
+    trainer = Trainer(model=model, args=args, train_dataset=DS(), eval_dataset=DS(), data_collator=default_data_collator)
+    res = trainer.train()
+    assert np.isfinite(res.training_loss)
+    pred = trainer.predict(DS())
+    assert pred.predictions.shape == (16, 2)
+    logs = [h["loss"] for h in trainer.state.log_history if "loss" in h]
+    assert len(logs) >= 4 and min(logs[-2:]) < logs[0]
+
+
 def test_organizers_exact_model_distilbert_plus_resnet50(pkg):
     """Multimodal_example_task2C.txt:152-197 as written: DistilBERT text tower (last position) + ResNet-50 (its 1000 logits) ->
     bert_fc / resnet_fc -> cat -> fusion_fc -> output_fc, reference attribute names and state_dict keys, forward(text, image,
