@@ -17,6 +17,7 @@ returns ``(loss, logits)`` for HF Trainer.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -75,13 +76,22 @@ class _Conv:
         ops.gemm_grouped([ops.Gemm(A, wk, y, M, self.cout, self.ldk, self.ldk, self.ldk, self.cout)], False, False)
         return y, A, wk, Ho, Wo
 
-    def backward(self, lib, dy, A, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True):
+    def backward(self, lib, dy, A, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True, side=None):
         """dy [M, cout] 16-bit -> dx [B*H*W, cp] 16-bit (or None); the weight gradient's split-K slabs are queued in `wjobs`
-        (summed, un-packed and added to .grad for all convolutions at once at the end of the backward)"""
+        (summed, un-packed and added to .grad for all convolutions at once at the end of the backward).  With `side`, the
+        weight-gradient GEMM -- which nothing later in the backward chain reads -- runs on that stream beside the input-gradient
+        GEMM / col2im / BatchNorm chain of the layers below (the operands are kept alive in `wjobs` until the streams join)."""
         M = B * Ho * Wo
         dev = dy.device
-        slabs, sp = ops.wgrad_slabs(dy, A, self.cout, self.ldk, M, self.cout, self.ldk, alpha=1.0 / gscale)
-        wjobs.append((self, slabs, sp))
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                slabs, sp = ops.wgrad_slabs(dy, A, self.cout, self.ldk, M, self.cout, self.ldk, alpha=1.0 / gscale)
+        else:
+            slabs, sp = ops.wgrad_slabs(dy, A, self.cout, self.ldk, M, self.cout, self.ldk, alpha=1.0 / gscale)
+        wjobs.append((self, slabs, sp, dy, A))
         if not need_dx:
             return None
         dA = torch.empty((M, self.ldk), dtype=dy.dtype, device=dev)
@@ -292,13 +302,20 @@ class ResNet50(nn.Module):
         ops_ = tape["ops"]
         i = len(ops_) - 1
         grads = {}      # id(parameter) -> gradient tensor for autograd, or None when it was accumulated into .grad in place
-        wjobs = []      # (conv, split-K slabs of its weight gradient, nsplit): finished in one launch at the end
+        wjobs = []      # (conv, split-K slabs of its weight gradient, nsplit, operands kept alive): finished in one launch at the end
+        side = None
+        # weight-gradient GEMMs on a second stream: measured SLOWER (9.39 vs 8.76 ms/step -- 53 cross-stream edges of ~10 us for
+        # 26-us GEMMs), so off unless MEMEHIP_RESNET_WGRAD_SIDE=1
+        if os.environ.get("MEMEHIP_RESNET_WGRAD_SIDE", "0") == "1":
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            side = self._side
 
         def conv_bn_bwd(op, dy, want_dres, need_dx=True):
             _, cv, bn, A, wk, z, y, sm, sr, hh, ww, ho, wo, relu, has_res = op
             M = B * ho * wo
             dz, dres = bn.backward(lib, dy, z, y if relu else None, sm, sr, M, relu, want_dres, self.gscale, grads)
-            dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx)
+            dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx, side=side)
             return dxin, dres
 
         while i >= 0:
@@ -335,10 +352,12 @@ class ResNet50(nn.Module):
                 i -= 1
                 continue
             raise AssertionError(kind)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         for i0 in range(0, len(wjobs), _lib.MH_CONV_MAX_JOBS):
             chunk = wjobs[i0:i0 + _lib.MH_CONV_MAX_JOBS]
             jobs = (_lib.MhConvWgradJob * len(chunk))()
-            for j, (cv, slabs, sp) in enumerate(chunk):
+            for j, (cv, slabs, sp, _dy, _A) in enumerate(chunk):
                 g, acc = _grad_target(cv.mod.weight, grads)
                 jobs[j].slabs, jobs[j].g = slabs.data_ptr(), g.data_ptr()
                 jobs[j].Cout, jobs[j].Cin, jobs[j].KH, jobs[j].KW, jobs[j].Cp, jobs[j].ldk = cv.cout, cv.cin, cv.kh, cv.kw, cv.cp, cv.ldk
