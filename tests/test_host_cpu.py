@@ -236,3 +236,30 @@ def test_pil_resample_restatement_is_bit_exact():
         ref2 = np.asarray(Image.fromarray(img).resize((224, 224), Image.BILINEAR))
         got2 = resample_u8_reference(img, *pil_resample_coeffs(w, 224), *pil_resample_coeffs(h, 224))
         assert np.array_equal(got2, ref2), (h, w)
+
+
+def test_kevin_dataset_keys_and_collate_on_the_host():
+    """Kevin's dataset (Multimodal_example_task2C.py:208-304): constructor order, dict keys with and without labels, captions
+    required (the BLIP captioner is not part of this package) or produced by a caller's function, kevin_collate."""
+    import multimodal_propaganda_meme_classification_amd as pkg
+    kv = pkg.kevin
+    ids, texts, imgs, labels = ["a", "b", "c"], ["one two", "three", "four five six"], ["x.png", "y.png", "z.png"], [0, 1, 0]
+    with pytest.raises(ValueError, match="captions"):
+        kv.KevinMultimodalDataset(ids, texts, imgs, labels)
+    with pytest.raises(ValueError, match="2 captions for 3"):
+        kv.KevinMultimodalDataset(ids, texts, imgs, labels, captions=["p", "q"])
+    seen = []
+    ds = kv.KevinMultimodalDataset(ids, texts, imgs, labels, caption_fn=lambda paths: seen.extend(paths) or [f"a meme of {i}" for i in range(3)],
+                                   max_seq_len=12, image_size=16, synthetic_images=True, image_root="root")
+    assert seen == [os.path.join("root", p) for p in imgs] and len(ds) == 3
+    it = ds[1]
+    assert list(it) == ["id", "text", "text_mask", "caption_text", "caption_text_mask", "image", "label"]      # the reference's order (:290-300)
+    assert it["text"].shape == (12,) and it["caption_text"].shape == (12,) and int(it["label"]) == 1
+    assert it["image"].dtype == np.uint8 and it["image"].shape == (16, 16, 3)
+    ds_t = kv.KevinMultimodalDataset(ids, texts, imgs, None, is_test=True, captions=["p", "q", "r"], synthetic_images=True, image_size=16)
+    assert "label" not in ds_t[0]
+    with pytest.raises(FileNotFoundError):
+        kv.KevinMultimodalDataset(ids, texts, imgs, labels, captions=["p", "q", "r"])[0]
+    batch = kv.kevin_collate([ds[0], ds[2]])
+    assert batch["text"].shape == (2, 12) and batch["label"].tolist() == [0, 0] and batch["id"] == ["a", "c"]
+    assert isinstance(batch["image"], list) and len(batch["image"]) == 2
