@@ -346,8 +346,12 @@ int mh_pool_bwd(const float* d_pooled, void* d_text_hidden, void* d_image_hidden
 /* BatchNorm1d over f32 [B][F] (+ optional fused ReLU): Kevin's `Linear + BatchNorm1d + ReLU` projections and the 1-logit
  * `Linear(512,1) + BatchNorm1d(1)` (Multimodal_example_task2C.py:603-605, :641-643).  Training: batch statistics
  * (biased variance), running statistics updated with momentum (unbiased variance), mean / rstd saved for the
- * backward.  Eval (training = 0): running statistics.  bwd (training mode): dx, dgamma, dbeta (overwritten); with relu,
- * y (the forward output) masks the incoming gradient.  B <= 1024. */
+ * backward.  Eval (training = 0): running statistics (also written to save_mean / save_rstd).  bwd: dx, dgamma, dbeta
+ * (overwritten); `relu` is a bit set: MH_BN_RELU -- y (the forward output) masks the incoming gradient; MH_BN_FROZEN_STATS --
+ * the forward ran in eval mode, the statistics are constants and dx = gamma rstd dy' (the reference's train() goes on
+ * training in eval mode after its mid-epoch test(), Multimodal_example_task2C.py:755-780).  B <= 1024. */
+#define MH_BN_RELU 1
+#define MH_BN_FROZEN_STATS 2
 int mh_bn1d_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* running_mean, float* running_var,
                 float* y, int ldy, float* save_mean, float* save_rstd, int B, int F, float eps, float momentum,
                 int training, int relu, mh_stream_t stream);

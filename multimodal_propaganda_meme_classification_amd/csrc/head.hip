@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
     }
 }
 
-// dx = gamma rstd (dy' - mean(dy') - xhat mean(dy' xhat)),  dy' = dy * (y > 0) with ReLU;  dgamma, dbeta overwritten
+// dx = gamma rstd (dy' - mean(dy') - xhat mean(dy' xhat)),  dy' = dy * (y > 0) with ReLU;  dgamma, dbeta overwritten.
+// relu bit 1 (MH_BN_FROZEN_STATS): the forward ran in eval mode, mean / rstd are constants (the running statistics) and
+// dx = gamma rstd dy' -- the reference trains in that mode after its mid-epoch test() (Multimodal_example_task2C.py:755-780).
 __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                        int ldx, const float* __restrict__ y, int ldy,
                                                        const float* __restrict__ gamma, const float* __restrict__ save_mean,
@@ -411,6 +413,8 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
                                                        int B, int F, int relu) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
+    const bool frozen = (relu & 2) != 0;
+    relu &= 1;
     const float mu = save_mean[f], rs = save_rstd[f], g = gamma ? gamma[f] : 1.f;
     float sb = 0.f, sg = 0.f;
     for (int b = 0; b < B; ++b) {
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
     }
     if (dgamma) dgamma[f] = sg;
     if (dbeta) dbeta[f] = sb;
-    const float mb = sb / (float)B, mg = sg / (float)B;
+    const float mb = frozen ? 0.f : sb / (float)B, mg = frozen ? 0.f : sg / (float)B;
     for (int b = 0; b < B; ++b) {
         float d = dy[(size_t)b * lddy + f];
         if (relu && !(y[(size_t)b * ldy + f] > 0.f)) d = 0.f;
@@ -446,8 +450,8 @@ extern "C" int mh_bn1d_bwd(const float* dy, int lddy, const float* x, int ldx, c
                            const float* save_mean, const float* save_rstd, float* dx, int lddx, float* dgamma, float* dbeta,
                            int B, int F, int relu, mh_stream_t stream) {
     if (!dy || !x || !save_mean || !save_rstd || !dx) return MH_EINVAL;
-    if (relu && !y) return MH_EINVAL;
-    if (B < 1 || B > 1024 || F < 1 || lddy < F || ldx < F || lddx < F || (relu && ldy < F)) return MH_ESHAPE;
+    if ((relu & 1) && !y) return MH_EINVAL;
+    if (B < 1 || B > 1024 || F < 1 || lddy < F || ldx < F || lddx < F || ((relu & 1) && ldy < F)) return MH_ESHAPE;
     hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, y, ldy,
                        gamma, save_mean, save_rstd, dx, lddx, dgamma, dbeta, B, F, relu);
     return mh_launch_status();

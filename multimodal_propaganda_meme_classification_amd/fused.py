@@ -148,9 +148,9 @@ class _LinearBNFn(torch.autograd.Function):
     def backward(ctx, dy):
         from . import ops
         x2, W2, z, y, gamma, sm, sr = ctx.saved_tensors
-        if not ctx.training:
-            raise RuntimeError("memehip.linear_bn_act: backward in eval mode is not supported")
-        dz, dgamma, dbeta = ops.bn1d_bwd(_f(dy), z, y, gamma, sm, sr, ctx.relu)
+        # eval-mode forward (the reference trains on in eval mode after its mid-epoch test(), Multimodal_example_task2C.py:755-780):
+        # sm / sr hold the running statistics and are constants of the backward
+        dz, dgamma, dbeta = ops.bn1d_bwd(_f(dy), z, y, gamma, sm, sr, ctx.relu, frozen_stats=not ctx.training)
         dx, dW, db = _linear_grads(dz, x2, W2, ctx.needs_input_grad[0])
         return dx, dW, (db if ctx.has_b else None), dgamma, dbeta, None, None, None
 

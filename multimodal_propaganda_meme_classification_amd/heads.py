@@ -325,6 +325,66 @@ class KevinMultimodalClassifier(_Composite):
             attention += list(m.parameters())
         return [{"params": attention, "lr": lr}, {"params": text, "lr": lr * 0.8}, {"params": image, "lr": lr * 0.8}]
 
+    # ---- checkpoints of the reference module ------------------------------------------------------------------------------
+    _REF_PREFIXES = (("text_model.model.", "towers.bert."), ("caption_text_model.model.", "caption_text_model."),
+                     ("image_model.fine_tune.", "image_fine_tune."))
+
+    @staticmethod
+    def _timm_vit_to_hf(sd: dict) -> dict:
+        """timm ``VisionTransformer`` keys (``blocks.N.attn.qkv`` fused, ``patch_embed.proj``, ``cls_token``, ``pos_embed``, ``norm``;
+        what ``timm.create_model(...)`` + ``reset_classifier(0)`` holds, Multimodal_example_task2C.py:569-570) -> the transformers-4.39.2
+        ViTModel keys the towers use."""
+        out = {}
+        top = {"cls_token": "embeddings.cls_token", "pos_embed": "embeddings.position_embeddings",
+               "patch_embed.proj.weight": "embeddings.patch_embeddings.projection.weight",
+               "patch_embed.proj.bias": "embeddings.patch_embeddings.projection.bias", "norm.weight": "layernorm.weight",
+               "norm.bias": "layernorm.bias"}
+        blk = {"norm1": "layernorm_before", "norm2": "layernorm_after", "attn.proj": "attention.output.dense", "mlp.fc1": "intermediate.dense",
+               "mlp.fc2": "output.dense"}
+        for k, v in sd.items():
+            if k in top:
+                out[top[k]] = v
+                continue
+            parts = k.split(".")
+            if parts[0] != "blocks":
+                continue                      # head / fc_norm: Identity after reset_classifier(0)
+            i, rest, wb = parts[1], ".".join(parts[2:-1]), parts[-1]
+            L = f"encoder.layer.{i}."
+            if rest == "attn.qkv":
+                D = v.shape[0] // 3
+                for j, q in enumerate(("query", "key", "value")):
+                    out[L + f"attention.attention.{q}.{wb}"] = v[j * D:(j + 1) * D]
+            elif rest in blk:
+                out[L + blk[rest] + "." + wb] = v
+        return out
+
+    def load_reference_state_dict(self, state_dict: dict, strict: bool = True):
+        """Loads a ``state_dict()`` of the reference's ``MultimodalClassifier`` (Multimodal_example_task2C.py:587-643): ``text_model.model.*``
+        / ``caption_text_model.model.*`` (transformers BertModel keys), ``image_model.image_model.*`` (timm ViT keys, or the
+        transformers ViTModel keys), ``image_model.fine_tune.*``, and the head modules under their own names."""
+        mapped, vit = {}, {}
+        for k, v in state_dict.items():
+            if k.startswith("image_model.image_model."):
+                vit[k[len("image_model.image_model."):]] = v
+                continue
+            for a, b in self._REF_PREFIXES:
+                if k.startswith(a):
+                    k = b + k[len(a):]
+                    break
+            mapped[k] = v
+        if any(k.startswith("blocks.") for k in vit):
+            vit = self._timm_vit_to_hf(vit)
+        mapped.update({"towers.image_model." + k: v for k, v in vit.items()})
+        own = set(self.state_dict().keys())
+        # the towers module carries the organizers' four-Linear head as well (unused here): not part of the reference checkpoint
+        res = self.load_state_dict(mapped, strict=False)
+        missing = [k for k in res.missing_keys if not (k.startswith("towers.") and "_fc." in k)]
+        unexpected = [k for k in res.unexpected_keys if k in mapped and k not in own and not k.endswith("position_ids")
+                      and "token_type_ids" not in k and "pooler." not in k]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_reference_state_dict: missing {missing[:4]} unexpected {unexpected[:4]}")
+        return nn.modules.module._IncompatibleKeys(missing, unexpected)
+
     def forward(self, text, image, mask, caption_text, caption_text_mask):
         for t_ in (text, image, mask, caption_text, caption_text_mask):
             if not t_.is_cuda:

@@ -7,13 +7,14 @@
 * ``train / test / evaluate`` (:688-871): the same loops -- focal loss called as ``criterion(output, labels, alpha=0.25, gamma=2.0,
   reduction='mean')``, gradient norm + clip, ``scheduler.step()`` per batch, accuracy from ``sigmoid(output) > 0.5``; ``test``
   returns ``(loss, accuracy, macro_f1, optimal_threshold)`` with the threshold at the ROC point of maximum ``tpr - fpr``
-  (sklearn, as in the reference); ``evaluate`` writes the two TSVs (``id label run_id`` and ``id label prob run_id``).
+  (sklearn, as in the reference); ``evaluate`` writes the two TSVs (``id label run_id`` and ``id label prob run_id``).  Pinned to the reference's own functions run
+  from its source: tests/golden/ref_kevin_2c.npz (oracle/gen_ref_kevin.py), tests/test_reference_run_gpu.py.
 
 Differences, all on the host side of the hot path: the image transform (``Resize((224, 224))`` + flip + ColorJitter + rotation +
 ToTensor + Normalize, :222-235) runs on the device through ``DeviceImagePipeline(mode="stretch", augment=training)`` on the decoded
 uint8 images of a batch (``kevin_collate`` keeps them as a list); running loss / accuracy are accumulated on the device and read
-once per epoch; the mid-epoch test / validation passes of the reference (globals ``test_df`` / ``val_df``, :758-776) are an optional
-``eval_fn(batch_idx)`` callback.
+once per epoch; the loaders of the reference's mid-epoch test / validation passes (globals ``test_df`` / ``val_df``, :756-769) are keyword
+arguments of ``train``.
 """
 from __future__ import annotations
 
@@ -100,12 +101,28 @@ def _forward(model, data, device, pipeline):
     return model(text, image, mask, cap, cap_mask)
 
 
+best_macro_f1 = 0.0          # the reference's module global (Multimodal_example_task2C.py:74,766-769)
+
+
 def train(model, train_loader, criterion, optimizer, scheduler, device, epoch, scaler=None, image_pipeline: Optional[DeviceImagePipeline] = None,
-          max_grad_norm: Optional[float] = None, eval_fn: Optional[Callable] = None, log_every: int = 10) -> Tuple[float, float]:
-    """Multimodal_example_task2C.py:688-785.  ``scaler`` is accepted for signature compatibility and unused: the fp16 build keeps a
-    static gradient-stream scale and the fused Adam skips non-finite steps itself (``Adam(skip_nonfinite=True)`` / any clipping).
-    With ``memehip.Adam(..., max_grad_norm=...)`` the clip happens inside the fused update (one global norm); for any other
-    optimizer ``max_grad_norm`` (reference: 1.0 under fp16, 10.0 otherwise) is applied with ``clip_grad_norm_``."""
+          max_grad_norm: Optional[float] = None, eval_fn: Optional[Callable] = None, log_every: int = 10, test_df=None, val_df=None,
+          stay_in_eval_mode_after_check: bool = True, evaluate_kwargs: Optional[dict] = None) -> Tuple[float, float]:
+    """Multimodal_example_task2C.py:688-776.
+
+    ``test_df`` / ``val_df`` (the reference reads them as globals, :756-759): when given, the reference's mid-epoch check runs every
+    ``total_batches // 2`` batches and after the last one -- ``test()`` on both loaders, the two report lines, and ``evaluate(model,
+    test_df, threshold, device)`` whenever the test macro-F1 beats ``kevin.best_macro_f1`` (:766-769).  The reference's ``test()``
+    leaves the model in eval mode and its ``train()`` never switches back, so every batch after the first check of an epoch is
+    trained with BatchNorm on its running statistics and dropout off; ``stay_in_eval_mode_after_check=True`` (default) reproduces that,
+    ``False`` returns to train mode.  ``eval_fn(batch_idx)`` is a free-form alternative to the two loaders (always followed by
+    ``model.train()``).
+
+    ``scaler``: a ``memehip.GradScaler`` (or None).  The fp16 build scales the 16-bit gradient streams inside the kernels; the scaler
+    object carries the dynamic scale (halved on a skipped step, doubled after ``growth_interval`` clean ones) the way
+    ``torch.cuda.amp.GradScaler`` does for the reference's fp16 branch (:712-717).  With ``memehip.Adam(..., max_grad_norm=...)`` the
+    clip happens inside the fused update (one global norm); for any other optimizer ``max_grad_norm`` (reference: 1.0 under fp16, 10.0
+    otherwise) is applied with ``clip_grad_norm_``."""
+    global best_macro_f1
     from .model import Adam
     model.train()
     pipe = image_pipeline or DeviceImagePipeline(mode="stretch", augment=True, device=device)
@@ -128,7 +145,11 @@ def train(model, train_loader, criterion, optimizer, scheduler, device, epoch, s
             grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), float("inf"))
             if max_grad_norm is not None:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
-        optimizer.step()
+        if scaler is not None and hasattr(scaler, "step"):
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            optimizer.step()
         scheduler.step()
         loss_sum += loss.detach() * labels.size(0)
         window.append(loss.detach())
@@ -143,9 +164,22 @@ def train(model, train_loader, criterion, optimizer, scheduler, device, epoch, s
             window = []
             print(f"TRAIN | Epoch [{epoch}] | Batch [{batch_idx}/{total_batches}] | Loss: {avg:.4f} | LR: {scheduler.get_last_lr()[0]} | "
                   f"Grad Norm: {float(grad_norm):.4f} |")
-        if eval_fn is not None and (batch_idx % check_interval == 0 or batch_idx == total_batches):
-            eval_fn(batch_idx)
-            model.train()
+        if batch_idx % check_interval == 0 or batch_idx == total_batches:
+            if test_df is not None and val_df is not None:
+                t_loss, t_accuracy, t_macro_f1, t_optimal_threshold = test(model, test_df, criterion, device, epoch, image_pipeline=image_pipeline)
+                v_loss, v_accuracy, v_macro_f1, v_optimal_threshold = test(model, val_df, criterion, device, epoch, image_pipeline=image_pipeline)
+                print(f" TEST | Epoch [{epoch}] | Batch [{batch_idx}/{total_batches}] | Test Loss: {t_loss:.4f} | Acc: {t_accuracy:.4f} | "
+                      f"F1: {t_macro_f1:.4f} | thresh: {t_optimal_threshold}")
+                print(f" VAL | Epoch [{epoch}] | Batch [{batch_idx}/{total_batches}] | Test Loss: {v_loss:.4f} | Acc: {v_accuracy:.4f} | "
+                      f"F1: {v_macro_f1:.4f} | thresh: {v_optimal_threshold}")
+                if t_macro_f1 > best_macro_f1:
+                    best_macro_f1 = t_macro_f1
+                    evaluate(model, test_df, t_optimal_threshold, device, image_pipeline=image_pipeline, **(evaluate_kwargs or {}))
+                if not stay_in_eval_mode_after_check:
+                    model.train()
+            if eval_fn is not None:
+                eval_fn(batch_idx)
+                model.train()
     n = len(train_loader.dataset)
     train_loss, accuracy = float(loss_sum) / n, float(correct) / n
     print(f"TRAIN | Epoch [{epoch}] | Training Loss: {train_loss:.4f} | Accuracy: {accuracy:.4f} |")

@@ -198,9 +198,7 @@ class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, sm, sr = ctx.saved_tensors
-        if not ctx.training:
-            raise RuntimeError("memehip.BatchNorm1d: backward in eval mode is not supported")
-        dx, dg, db = ops.bn1d_bwd(dy.contiguous().to(F32), x, y, gamma, sm, sr, ctx.relu)
+        dx, dg, db = ops.bn1d_bwd(dy.contiguous().to(F32), x, y, gamma, sm, sr, ctx.relu, frozen_stats=not ctx.training)
         return dx, dg, db, None, None
 
 

