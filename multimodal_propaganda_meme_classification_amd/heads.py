@@ -274,7 +274,7 @@ class KevinMultimodalClassifier(_Composite):
 
     def __init__(self, fusion_method: str = "concatenation", text: Optional[TextConfig] = None,
                  image: Optional[ImageConfig] = None, caption: Optional[TextConfig] = None, proj: int = 512,
-                 compute_dtype: str = "bf16", seed: int = 0):
+                 compute_dtype: str = "bf16", seed: int = 0, grad_stream_scale: float = 0.0):
         super().__init__()
         # the reference lists four methods (:86); "cross_modal" and "self_attention" build two-input modules that its own
         # three-input forward (:677) cannot call (TypeError on the first batch), so only the two that run are offered
@@ -283,8 +283,9 @@ class KevinMultimodalClassifier(_Composite):
         tc, ic = text or TextConfig(), image or ImageConfig()
         cc = caption or TextConfig(vocab_size=30522)
         self.fusion_method = fusion_method
-        self.towers = MultimodalClassifier.from_config(ModelConfig(text=tc, image=ic, compute_dtype=compute_dtype), seed=seed)
-        self.caption_text_model = TextEncoder(cc, pool="cls", compute_dtype=compute_dtype, seed=seed + 1)
+        self.towers = MultimodalClassifier.from_config(ModelConfig(text=tc, image=ic, compute_dtype=compute_dtype,
+                                                                   grad_stream_scale=grad_stream_scale), seed=seed)
+        self.caption_text_model = TextEncoder(cc, pool="cls", compute_dtype=compute_dtype, seed=seed + 1, grad_stream_scale=grad_stream_scale)
         self.text_dropout, self.caption_text_dropout = nn.Dropout(0.3), nn.Dropout(0.3)
         self.text_fc = LinearBNReLU(tc.hidden, proj)
         self.caption_text_fc = LinearBNReLU(cc.hidden, proj)

@@ -448,7 +448,7 @@ class MultimodalClassifier(nn.Module):
 
     def forward(self, text: torch.Tensor, image: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         plan = self._prepare(text, image, mask)
-        if torch.is_grad_enabled() and self.training:
+        if torch.is_grad_enabled():          # eval mode only switches dropout off; the reference back-propagates through eval-mode modules too
             anchor = self._params[self._names[0]]
             return _ModelFn.apply(anchor, self, plan)
         _run_forward(plan)
@@ -466,7 +466,7 @@ class MultimodalClassifier(nn.Module):
                 raise _lib.MemehipError("memehip runs on the HIP device only (no CPU fallback): move the batch with .to(device)")
         plan = self._prepare(text, image, mask, features=True)
         Dt = self.config.text.hidden
-        if torch.is_grad_enabled() and self.training:
+        if torch.is_grad_enabled():          # eval mode only switches dropout off; the reference back-propagates through eval-mode modules too
             pooled = _EncodeFn.apply(self._params[self._names[0]], self, plan)
         else:
             _run_forward(plan)
@@ -482,7 +482,7 @@ class MultimodalClassifier(nn.Module):
             if not t_.is_cuda:
                 raise _lib.MemehipError("memehip runs on the HIP device only (no CPU fallback): move the batch with .to(device)")
         plan = self._prepare(text, image, mask, features="sequence")
-        if torch.is_grad_enabled() and self.training:
+        if torch.is_grad_enabled():          # eval mode only switches dropout off; the reference back-propagates through eval-mode modules too
             return _SequenceFn.apply(self._params[self._names[0]], self, plan)
         _run_forward(plan)
         B, S = plan.B, plan.S
@@ -550,14 +550,16 @@ class TextEncoder(nn.Module):
     prefix of the two-tower module; the stub's parameters get zero gradients (the head on top never reads them), so one
     fused ``Adam(encoder.parameters())`` leaves them unchanged."""
 
-    def __init__(self, text: "TextConfig", pool: str = "cls", compute_dtype: str = "bf16", seed: int = 0, naming: str = "bert"):
+    def __init__(self, text: "TextConfig", pool: str = "cls", compute_dtype: str = "bf16", seed: int = 0, naming: str = "bert",
+                 grad_stream_scale: float = 0.0):
         super().__init__()
         if naming not in ("bert", "distilbert"):
             raise ValueError(f"naming must be 'bert' or 'distilbert', got {naming!r}")
         self.naming = naming
         from .config import ImageConfig
         stub = ImageConfig(image_size=16, patch=16, hidden=128, layers=1, heads=2, intermediate=128)
-        cfg = ModelConfig(text=text, image=stub, proj=128, num_classes=2, pool=pool, compute_dtype=compute_dtype)
+        cfg = ModelConfig(text=text, image=stub, proj=128, num_classes=2, pool=pool, compute_dtype=compute_dtype,
+                          grad_stream_scale=grad_stream_scale)
         self.inner = MultimodalClassifier.from_config(cfg, seed=seed)
         self._image = None
 

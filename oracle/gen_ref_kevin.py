@@ -187,7 +187,24 @@ def gen_kevin(cfg=E.KEVIN):
                 n_eval[0] += 1
                 return r
             ns["test"], ns["evaluate"] = test_wrapper, evaluate_wrapper
-            first, lrs = {}, []
+            # ---- test() + evaluate() on the initial state (eval mode, BatchNorm on the checkpoint's running statistics)
+            r0 = ref_test(model, loader, criterion, device, 0)
+            out["initial_test"] = np.array([float(x) for x in r0])
+            out["initial_test_outputs"] = torch.stack([o for ph, t, o in fwd]).numpy()
+            fwd.clear()
+            ref_evaluate(model, loader, r0[3], device)
+            out["initial_evaluate_outputs"] = torch.stack([o for ph, t, o in fwd]).numpy()
+            fwd.clear()
+            out["initial_evaluate_tsv"] = np.array(open("task2C_kevinmathew.tsv", encoding="utf-8").read().split("\n"))
+            out["initial_evaluate_probs_tsv"] = np.array(open("task2C_kevinmathew_probs_fold_0.tsv", encoding="utf-8").read().split("\n"))
+            first, lrs, clip_norms = {}, [], []
+            real_clip = torch.nn.utils.clip_grad_norm_
+
+            def clip_spy(params, max_norm, *a, **k):          # what the reference's two clip calls return (:728-730): the total norm
+                r = real_clip(params, max_norm, *a, **k)
+                clip_norms.append((float(max_norm), float(r)))
+                return r
+            torch.nn.utils.clip_grad_norm_ = clip_spy
 
             def grab(opt, args, kwargs):
                 lrs.append([g["lr"] for g in opt.param_groups])
@@ -197,7 +214,10 @@ def gen_kevin(cfg=E.KEVIN):
             saved = set_dropout(model, 0.0)
             train_loss, acc = ns["train"](model, loader, criterion, optimizer, scheduler, device, 0, None)        # :178-180
             set_dropout(model, saved=saved)
+            torch.nn.utils.clip_grad_norm_ = real_clip
+            out["grad_norm_before_clip"] = np.array([n for mx, n in clip_norms if mx == float("inf")])
             tr = [(t, o) for ph, t, o in fwd if ph == "train"]
+            out["mid_epoch_test_outputs"] = torch.stack([o for ph, t, o in fwd if ph == "test"]).numpy()      # 4 test() calls x 4 batches
             out["train_outputs"] = torch.stack([o for _, o in tr]).numpy()
             out["train_mode_flags"] = np.array([int(t) for t, _ in tr])
             out["train_loss"], out["train_acc"] = np.array(train_loss), np.array(acc)

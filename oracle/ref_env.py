@@ -603,3 +603,24 @@ def bn_buffers_from_fixture(z, prefix: str = "") -> Dict[str, torch.Tensor]:
         out[f"{prefix}{name}.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
         pos += n
     return out
+
+
+def kevin_head_cpu(state: Dict[str, torch.Tensor], t: torch.Tensor, vi: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """Kevin's head (Multimodal_example_task2C.py:599-643,666-685) in fp32 torch on the CPU, train-mode BatchNorm (batch statistics),
+    dropout off: pooled text / image / caption features -> the [B] outputs.  Restated for the tests (checked against the reference's
+    own forward by tests/test_reference_run.py)."""
+    import torch.nn.functional as F
+
+    def lin(name, x):
+        return F.linear(x, state[name + ".weight"], state[name + ".bias"])
+
+    def bn(name, x):
+        return F.batch_norm(x, None, None, state[name + ".weight"], state[name + ".bias"], True, 0.1, 1e-5)
+
+    to = F.relu(bn("text_fc.1", lin("text_fc.0", t)))
+    co = F.relu(bn("caption_text_fc.1", lin("caption_text_fc.0", c)))
+    io = lin("image_model.fine_tune.3", F.relu(lin("image_model.fine_tune.0", vi)))
+    cat = torch.cat((to, io, co), dim=1)
+    att = torch.softmax(F.relu(bn("fusion_layer.attention_layer.1", lin("fusion_layer.attention_layer.0", cat))), dim=1)
+    red = F.relu(bn("fusion_layer.reduce.1", lin("fusion_layer.reduce.0", att * cat)))
+    return bn("output_fc.1", lin("output_fc.0", red)).squeeze(1)

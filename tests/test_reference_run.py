@@ -162,18 +162,6 @@ def test_oracle_reproduces_the_reference_kevin_forward(golden_dir, tmp_path):
         c = O.text_tower(sub("caption_text_model.model.", "bert."), cap, cmask, ccfg)[:, 0]
         vi = O.image_tower(sub("image_model.image_model.", "image_model."), images, icfg)[:, 0]
 
-        def lin(name, x):
-            return F.linear(x, state[name + ".weight"], state[name + ".bias"])
-
-        def bn(name, x):
-            return F.batch_norm(x, None, None, state[name + ".weight"], state[name + ".bias"], True, 0.1, 1e-5)
-
-        to = F.relu(bn("text_fc.1", lin("text_fc.0", t)))
-        co = F.relu(bn("caption_text_fc.1", lin("caption_text_fc.0", c)))
-        io = lin("image_model.fine_tune.3", F.relu(lin("image_model.fine_tune.0", vi)))
-        cat = torch.cat((to, io, co), dim=1)
-        att = torch.softmax(F.relu(bn("fusion_layer.attention_layer.1", lin("fusion_layer.attention_layer.0", cat))), dim=1)
-        red = F.relu(bn("fusion_layer.reduce.1", lin("fusion_layer.reduce.0", att * cat)))
-        out = bn("output_fc.1", lin("output_fc.0", red)).squeeze(1)
+        out = E.kevin_head_cpu(state, t, vi, c)
     np.testing.assert_allclose(out.numpy(), z["train_outputs"][0], atol=2e-4)
     assert abs(float(O.sigmoid_focal_loss(out, labels, 0.25, 2.0)) - float(E.focal_standin(torch.from_numpy(z["train_outputs"][0]), labels, 0.25, 2.0, "mean"))) < 1e-5
