@@ -397,7 +397,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_ddp:
         dist.barrier()
-        dist.destroy_process_group()
+        from multimodal_propaganda_meme_classification_amd import ddp
+        ddp.shutdown()          # GraphedSteps, reducers, gc, then the process group -- in that order
 
 
 if __name__ == "__main__":

@@ -10,10 +10,15 @@ the CPU tests).
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+# everything that holds RCCL work handles, comm streams or hipGraphs built around them: closed, in order, by shutdown()
+_LIVE_REDUCERS: "weakref.WeakSet" = weakref.WeakSet()
+_LIVE_STEPS: "weakref.WeakSet" = weakref.WeakSet()
 
 
 class _EventWork:
@@ -47,6 +52,34 @@ class GradientReducer:
         self.wire_bytes = 0                  # bytes this rank put on the wire per element-pass (accounting for tests / logs)
         self._cstream = torch.cuda.Stream() if (compress and flat_grads.is_cuda) else None
         self._bufs = {}
+        self._had_group = dist.is_initialized()
+        self.closed = False
+        _LIVE_REDUCERS.add(self)
+
+    def _check_open(self):
+        if self.closed:
+            raise RuntimeError("GradientReducer is closed")
+        if self._had_group and not dist.is_initialized():
+            raise RuntimeError("GradientReducer outlived its process group: call ddp.shutdown() (or reducer.close()) BEFORE "
+                               "torch.distributed.destroy_process_group()")
+
+    def close(self):
+        """Finish the pending collectives, drop their work handles, the staging buffers and the comm stream.  Must run while the
+        process group is still alive (ddp.shutdown() does it in the right order); idempotent."""
+        if self.closed:
+            return
+        self.wait()
+        if self.G.is_cuda:
+            torch.cuda.synchronize(self.G.device)
+        self._bufs.clear()
+        self._cstream = None
+        self.closed = True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _reduce_compressed(self, a: int, e: int):
         """all-to-all (bf16) -> fp32 sum of the received shards -> bf16 -> all-gather -> fp32 gradient slice."""
@@ -92,6 +125,7 @@ class GradientReducer:
     def reduce_range(self, rng: Optional[Tuple[int, int]]):
         """Start the all-reduce (SUM) of G[start:end]; returns immediately with the list of work handles started."""
         started: List = []
+        self._check_open()
         if rng is None or not dist.is_initialized():
             return started
         a, b = rng
@@ -116,6 +150,7 @@ class GradientReducer:
 
     def gather(self, pairs):
         """all-gather (local, gathered) tensor pairs in rank order (the embedding-gradient exchange)."""
+        self._check_open()
         if not dist.is_initialized():
             for local, full in pairs:
                 full.copy_(local.reshape(full.shape))
@@ -131,6 +166,23 @@ class GradientReducer:
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
+
+
+def shutdown(destroy_process_group: bool = True):
+    """Tear the data-parallel machinery down in dependency order: every live GraphedStep (its hipGraphs, then the private pool they
+    share, then its side streams), then every live GradientReducer (pending work handles, staging buffers, comm stream), a cyclic
+    garbage collection so that nothing created around the communicator is left for a later collection, and only then the process
+    group.  Objects that hold work handles or graphs built next to a communicator must not outlive it."""
+    import gc
+    for st in list(_LIVE_STEPS):
+        st.close()
+    for red in list(_LIVE_REDUCERS):
+        red.close()
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if destroy_process_group and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group=None):

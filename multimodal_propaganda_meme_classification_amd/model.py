@@ -708,8 +708,8 @@ class Adam(torch.optim.Optimizer):
             self._model = buckets[0]["model"]
         dev = buckets[0]["P"].device
         shared = dict(hyper=[torch.zeros(8, device=dev) for _ in self.param_groups],
-                      # (ONE pinned allocation each: an optimizer used to pin 64 small blocks, and a long process -- the GPU test
-                      #  suite builds ~100 optimizers -- ran the host allocator into a segfault inside hipGraphLaunch)
+                      # ONE pinned allocation per ring (tidiness only: round 3's experiments, profiles/r03_segfault_experiments.md,
+                      # showed that the number of pinned blocks has nothing to do with the round-2 hipGraphLaunch segfault)
                       ring=torch.zeros((32, len(self.param_groups), 8), dtype=F32).pin_memory(),
                       nrm_total=torch.zeros(1, device=dev),
                       # GradScaler bookkeeping (mh_adam_skip_account): [skipped steps, last step skipped]; the host's step count
@@ -994,6 +994,35 @@ class GraphedStep:
                                    and not optimizer.skip_nonfinite)
         self.ddp_side = torch.cuda.Stream() if self.ddp_opt_in_bwd else None
         self.ddp_wside = torch.cuda.Stream() if (reducer is not None and overlap_wgrad and not self.ddp_stream) else None
+        self.closed = False
+        from . import ddp as _ddp
+        _ddp._LIVE_STEPS.add(self)
+
+    def close(self):
+        """Explicit teardown, in dependency order: wait for the device, reset the hipGraphs (last captured first; the data-parallel
+        ones share ONE private memory pool, which is released with the last of them), drop the closures that keep this object in a
+        reference cycle, then the side / fence streams.  With a reducer this has to happen while the process group is alive
+        (``ddp.shutdown()`` closes steps, then reducers, then destroys the group).  Idempotent; ``step()`` raises afterwards."""
+        if self.closed:
+            return
+        self.closed = True
+        if self.reducer is not None and not self.reducer.closed:
+            self.reducer.wait()
+        torch.cuda.synchronize()
+        for g, _, _ in reversed(self.graphs or []):
+            if g is not None:
+                g.reset()
+        self.graphs = None
+        self._tail = None
+        self._opt_done = None
+        self.side = self.ddp_fence = self.ddp_side = self.ddp_wside = None
+        self.plan = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     # ---- pieces ------------------------------------------------------------------------------------------
     def _pieces(self):
@@ -1160,6 +1189,8 @@ class GraphedStep:
 
     def step(self):
         """One step on the batch currently in the static input buffers. Returns (loss, n_correct) device tensors."""
+        if self.closed:
+            raise RuntimeError("GraphedStep is closed")
         opt = self.opt
         if opt._flat is None:
             self.model._attach_grads()

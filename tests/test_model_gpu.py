@@ -246,11 +246,18 @@ def test_config3_logits_match_golden_and_oracle(pkg, golden_dir):
     print("worst relative grad error", name, worst)
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture(scope="function" if os.environ.get("MEMEHIP_DEBUG_PG_PER_TEST") else "module")
 def rccl_world1():
-    """ONE 1-rank RCCL communicator for every data-parallel test of this module.  (A communicator per test -- five
-    init / destroy cycles in one process, next to the 12-GB config-5 tests -- made a LATER, unrelated hipGraphLaunch segfault
-    inside the HIP runtime, deterministically; three cycles did not.  The product creates one communicator per process.)"""
+    """ONE 1-rank RCCL communicator for every data-parallel test of this module, torn down through ddp.shutdown().
+
+    Why one: five create / destroy cycles of an RCCL process group in one process (a communicator per test), next to the 12-GB
+    config-5 tests, make a LATER, unrelated multi-stream hipGraphLaunch segfault inside the HIP runtime, deterministically
+    (round 2).  Round 3 took the candidates apart, one run each (tools/lab/exp_r3a.sh, tools/lab/exp_r3b.sh, summary in
+    profiles/r03_segfault_experiments.md): the crash follows the create / destroy cycles alone -- it is there with a single pinned
+    ring per optimizer, absent with 64 pinned blocks and one communicator, and still there when every GraphedStep / GradientReducer
+    is closed (graphs reset, pool released, streams dropped, gc) BEFORE the group is destroyed.  So it is not an object of this
+    package outliving its communicator; what happens below hipGraphLaunch is not known.  The product creates one communicator per
+    process.  MEMEHIP_DEBUG_PG_PER_TEST=1 (and MEMEHIP_DEBUG_RAW_DESTROY=1) restore the crashing set-up for a reproduction."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
@@ -258,7 +265,11 @@ def rccl_world1():
     try:
         yield dist
     finally:
-        dist.destroy_process_group()
+        if os.environ.get("MEMEHIP_DEBUG_RAW_DESTROY"):
+            dist.destroy_process_group()
+        else:
+            from multimodal_propaganda_meme_classification_amd import ddp
+            ddp.shutdown()          # GraphedSteps, then reducers, then a garbage collection, then the process group
 
 
 @pytest.mark.parametrize("clip", [1.0, None])

@@ -62,4 +62,5 @@ assert all(float(x) == float(lst[0]) for x in lst), lst
 if rank == 0:
     print("DDP2 OK  worst max |param diff|", worst, flush=True)
 dist.barrier()
-dist.destroy_process_group()
+from multimodal_propaganda_meme_classification_amd import ddp as _ddp
+_ddp.shutdown()
