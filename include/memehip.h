@@ -359,13 +359,15 @@ int mh_bn1d_bwd(const float* dy, int lddy, const float* x, int ldx, const float*
                 const float* save_mean, const float* save_rstd, float* dx, int lddx, float* dgamma, float* dbeta, int B,
                 int F, int relu, mh_stream_t stream);
 int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
-                  int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream);
+                  int32_t* n_correct, int B, int C, float grad_scale,
+                  const float* grad_scale_dev /*device f32[1] or NULL: the dynamic loss scale, multiplied into grad_scale*/,
+                  mh_stream_t stream);
 /* sigmoid focal loss over one logit per sample (torchvision.ops.sigmoid_focal_loss(inputs, targets, alpha, gamma,
  * reduction="mean") as called at Multimodal_example_task2C.py:167,711): loss, dlogits (stride ld), #(logit>0 == target).
  * alpha < 0 disables the class weighting, as in torchvision. */
 int mh_focal_fwd_bwd(const float* logits, int ld, const float* targets /*f32 [B] in {0,1}*/, float* loss,
                      float* dlogits, int32_t* n_correct, int B, float alpha, float gamma, float grad_scale,
-                     mh_stream_t stream);
+                     const float* grad_scale_dev /*as in mh_ce_fwd_bwd*/, mh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Heads on top of the towers (SURVEY section 8 f ranks 1-2), all fp32:
@@ -518,11 +520,19 @@ int mh_add_h16(const void* a, const void* b, void* y, int64_t n, mh_stream_t str
  *     the identity (with weight_decay == 0): skipping it is bit-identical to torch.optim.Adam and saves 28 B/element
  *     of HBM traffic on the 49 M-element table (a batch touches at most B*S of its 64 000 rows).
  *   mh_cast_f32_bf16: shadow refresh on its own (after load_state_dict).
- *   mh_adam_skip_account (steps that may be skipped: fp16 runs, GradScaler semantics): after the gradient norm is known and
- *     before the update launches -- counts a non-finite norm in state[0] (state[1] = this step was skipped) and rewrites every
- *     group's bias corrections hyper[5..6] for t = *step_dev - state[0]: as with GradScaler.step, which does not call
- *     optimizer.step() after an overflow, a skipped step does not advance Adam's t.  betas are passed as doubles
- *     (1 - beta^t in double, like the host).
+ *     `overflow` (device int32[1] or NULL) selects the GUARDED form used when a slice is updated before the global norm can
+ *     exist (optimizer-in-backward): a launch that finds *overflow already set does nothing; otherwise a 4-element vector whose
+ *     gradient is not finite keeps its parameters and moments and sets *overflow.  The slices of a step run in backward order on one
+ *     stream, so an overflow at the loss skips the whole step, one further down leaves the layers above it updated.
+ *   mh_adam_skip_account (steps that may be skipped: fp16 runs, the reference's GradScaler, Multimodal_example_task2C.py:60-64,
+ *     712-717): ONE launch per step AFTER the update launches.  A step is "bad" when *gnorm_sq is not finite (exact path: the
+ *     update kernels skipped it as a whole) or *loss_scale->overflow is set (guarded path; cleared here).  It counts bad steps in
+ *     state[0] (state[1] = this step was bad), updates the dynamic loss scale as torch.cuda.amp.GradScaler.update does (bad:
+ *     scale *= backoff_factor, growth counter 0; else counter + 1 and, at growth_interval, scale *= growth_factor; clamped to
+ *     [min_scale, max_scale]) and writes what the NEXT step's update kernels read: every group's bias corrections hyper[5..6] for
+ *     t = *step_dev + 1 - state[0] (as with GradScaler.step, which does not call optimizer.step() after an overflow, a skipped
+ *     step does not advance Adam's t; betas are passed as doubles, 1 - beta^t in double like the host) and, with a loss scale,
+ *     hyper[7] = base_grad_scale / scale.  The loss kernels multiply *scale into dlogits (grad_scale_dev).
  * ------------------------------------------------------------------------------------------ */
 #define MH_ADAM_MAX_GROUPS 8
 typedef struct MhAdamSkipGroups {
@@ -532,18 +542,28 @@ typedef struct MhAdamSkipGroups {
     int32_t n;
     int32_t reserved_;
 } MhAdamSkipGroups;
-int mh_adam_skip_account(const MhAdamSkipGroups* groups, const float* gnorm_sq /*device*/, int32_t* state /*device int32[2]*/,
-                         const int32_t* step_dev /*device: the host's step count*/, mh_stream_t stream);
+typedef struct MhLossScale {
+    float* scale;             /* device f32[1]: the dynamic loss scale, or NULL (only count / bias-correct) */
+    int32_t* growth;          /* device int32[1]: clean steps since the last change */
+    int32_t* overflow;        /* device int32[1] or NULL: raised by the guarded update kernels, cleared here */
+    float growth_factor, backoff_factor, min_scale, max_scale;
+    int32_t growth_interval;
+    float base_grad_scale;    /* 1 / world size */
+} MhLossScale;
+int mh_adam_skip_account(const MhAdamSkipGroups* groups, const float* gnorm_sq /*device or NULL*/, int32_t* state /*device int32[2]*/,
+                         const int32_t* step_dev /*device: the host's step count*/, const MhLossScale* loss_scale /*or NULL*/,
+                         mh_stream_t stream);
 int mh_sumsq_f32(const float* g, int64_t n, float* workspace /*>=1024 f32*/, float* out,
                  mh_stream_t stream);
 int mh_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t n,
                  int64_t n_shadow, const float* hyper /*device f32[8]*/, int decoupled,
-                 const float* gnorm_sq /*device or NULL*/, float max_norm, mh_stream_t stream);
+                 const float* gnorm_sq /*device or NULL*/, float max_norm, int32_t* overflow /*device or NULL*/,
+                 mh_stream_t stream);
 int mh_adam_step_rows(float* p, float* m, float* v, const float* g,
                       uint8_t* row_live /*[rows] optimizer state: 1 = this row's m / v may be non-zero*/,
                       const uint8_t* row_touched /*[rows] or NULL: rows that have received a gradient (mh_bert_embed_bwd);
                       OR-ed into row_live*/, int rows, int D, const float* hyper /*device f32[8]*/, int decoupled,
-                      const float* gnorm_sq, float max_norm, mh_stream_t stream);
+                      const float* gnorm_sq, float max_norm, int32_t* overflow /*device or NULL*/, mh_stream_t stream);
 int mh_cast_f32_bf16(const float* src, void* dst, int64_t n, mh_stream_t stream);
 int mh_cast_bf16_f32(const void* src, float* dst, int64_t n, mh_stream_t stream);
 /* Data-parallel gradient exchange with 16-bit wire format (ddp.GradientReducer(compress="bf16")): out[i] = 16-bit(sum_w

@@ -6,7 +6,7 @@ for gfx950 behind the C ABI in include/memehip.h (libmemehip.so).  No CPU fallba
 from . import _lib  # noqa: F401
 from ._lib import MemehipError  # noqa: F401
 from .config import ImageConfig, Layout, ModelConfig, TextConfig  # noqa: F401
-from .model import (Adam, BatchNorm1d, CrossEntropyLoss, GraphedStep, MultimodalClassifier, SigmoidFocalLoss,  # noqa: F401
+from .model import (Adam, BatchNorm1d, CrossEntropyLoss, GradScaler, GraphedStep, MultimodalClassifier, SigmoidFocalLoss,  # noqa: F401
                     TextEncoder, flatten_parameters, get_linear_schedule_with_warmup)
 from . import fused  # noqa: F401
 from .heads import (MCA3, ConcatAttention3, FineTuneMLP, KevinMultimodalClassifier, LinearBNReLU,  # noqa: F401

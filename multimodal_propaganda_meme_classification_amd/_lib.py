@@ -62,6 +62,11 @@ class MhAdamSkipGroups(C.Structure):
                 ("n", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class MhLossScale(C.Structure):
+    _fields_ = [("scale", c_void_p), ("growth", c_void_p), ("overflow", c_void_p), ("growth_factor", C.c_float), ("backoff_factor", C.c_float),
+                ("min_scale", C.c_float), ("max_scale", C.c_float), ("growth_interval", C.c_int32), ("base_grad_scale", C.c_float)]
+
+
 class MhLnFwdJob(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "gamma", "beta", "y", "y_f32", "mean", "rstd")] + \
                [("rows", C.c_int32), ("eps", C.c_float), ("rows_dev", c_void_p)]
@@ -171,12 +176,12 @@ _PROTOS = {
     "mh_avgpool_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mh_avgpool_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     "mh_add_h16": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
-    "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p],
-    "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p],
-    "mh_adam_skip_account": [C.POINTER(MhAdamSkipGroups), c_void_p, c_void_p, c_void_p, c_void_p],
+    "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p, c_void_p],
+    "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p],
+    "mh_adam_skip_account": [C.POINTER(MhAdamSkipGroups), c_void_p, c_void_p, c_void_p, C.POINTER(MhLossScale), c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
-    "mh_adam_step": [c_void_p] * 5 + [c_int64, c_int64, c_void_p, c_int, c_void_p, c_float, c_void_p],
-    "mh_adam_step_rows": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p],
+    "mh_adam_step": [c_void_p] * 5 + [c_int64, c_int64, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p],
+    "mh_adam_step_rows": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p],
     "mh_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "mh_cast_bf16_f32": [c_void_p, c_void_p, c_int64, c_void_p],
     "mh_sum_shards_16": [c_void_p, c_void_p, c_int, c_int64, c_void_p],

@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256) void head_bwd_stage_kernel(const HeadBwdJobs j
 // cross-entropy forward + dlogits, one block; B <= 1024
 __global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                   float* __restrict__ loss, float* __restrict__ dlogits,
-                                                  int32_t* __restrict__ n_correct, int B, int C, float grad_scale) {
+                                                  int32_t* __restrict__ n_correct, int B, int C, float grad_scale,
+                                                  const float* __restrict__ grad_scale_dev) {
+    if (grad_scale_dev) grad_scale *= grad_scale_dev[0];          // the dynamic loss scale (GradScaler.scale(loss))
     __shared__ float red[16];
     __shared__ int redc[16];
     const int b = threadIdx.x;
@@ -171,7 +173,9 @@ __global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ logi
 __global__ __launch_bounds__(1024) void focal_kernel(const float* __restrict__ logits, int ld,
                                                      const float* __restrict__ targets, float* __restrict__ loss,
                                                      float* __restrict__ dlogits, int32_t* __restrict__ n_correct, int B,
-                                                     float alpha, float gamma, float grad_scale) {
+                                                     float alpha, float gamma, float grad_scale,
+                                                     const float* __restrict__ grad_scale_dev) {
+    if (grad_scale_dev) grad_scale *= grad_scale_dev[0];
     __shared__ float red[16];
     __shared__ int redc[16];
     const int b = threadIdx.x;
@@ -319,23 +323,24 @@ extern "C" int mh_head_bwd(const MhHeadParams* p, const MhHeadGrads* g, const fl
 }
 
 extern "C" int mh_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
-                             int32_t* n_correct, int B, int C, float grad_scale, mh_stream_t stream) {
+                             int32_t* n_correct, int B, int C, float grad_scale, const float* grad_scale_dev,
+                             mh_stream_t stream) {
     if (!logits || !labels || !loss || !dlogits) return MH_EINVAL;
     if (B < 1 || B > 1024 || C < 1) return MH_ESHAPE;
     const int threads = ((B + 63) / 64) * 64;
     hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, logits, labels, loss, dlogits,
-                       n_correct, B, C, grad_scale);
+                       n_correct, B, C, grad_scale, grad_scale_dev);
     return mh_launch_status();
 }
 
 extern "C" int mh_focal_fwd_bwd(const float* logits, int ld, const float* targets, float* loss, float* dlogits,
                                 int32_t* n_correct, int B, float alpha, float gamma, float grad_scale,
-                                mh_stream_t stream) {
+                                const float* grad_scale_dev, mh_stream_t stream) {
     if (!logits || !targets || !loss || !dlogits) return MH_EINVAL;
     if (B < 1 || B > 1024 || ld < 1 || gamma < 0.f) return MH_ESHAPE;
     const int threads = ((B + 63) / 64) * 64;
     hipLaunchKernelGGL(focal_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, logits, ld, targets, loss, dlogits,
-                       n_correct, B, alpha, gamma, grad_scale);
+                       n_correct, B, alpha, gamma, grad_scale, grad_scale_dev);
     return mh_launch_status();
 }
 

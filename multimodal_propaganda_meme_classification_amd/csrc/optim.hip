@@ -41,7 +41,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ v, const float* __restrict__ g,
                                                    h16* __restrict__ shadow, int64_t n, int64_t n_shadow,
                                                    const float* __restrict__ hyper, int decoupled,
-                                                   const float* __restrict__ gnorm_sq, float max_norm) {
+                                                   const float* __restrict__ gnorm_sq, float max_norm,
+                                                   int32_t* __restrict__ overflow) {
+    // guarded form: once a slice of this step has met a non-finite gradient, every later launch of the step is a no-op -- the
+    // slices run in backward order on one stream, so an overflow at the loss skips the whole step (GradScaler.step), one that
+    // appears further down the gradient stream leaves only the layers above it updated, with the finite gradients they had
+    if (overflow && *(volatile int32_t*)overflow) return;
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
     const float inv_bc1 = hyper[5], inv_sqrt_bc2 = hyper[6];
     float gs = hyper[7];
@@ -57,10 +62,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const float l2 = decoupled ? 0.f : wd;
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 gv = *(const f32x4*)(g + 4 * i);
+        if (overflow) {
+            // guarded update (optimizer-in-backward: the slice is updated before the global norm can exist): elements whose
+            // gradient is not finite keep their parameters and moments, and the step is reported through *overflow so that
+            // mh_adam_skip_account counts it and backs the loss scale off
+            const float a = fabsf(gv[0]) + fabsf(gv[1]) + fabsf(gv[2]) + fabsf(gv[3]);
+            if (!(a <= 3.0e38f)) {
+                *overflow = 1;
+                continue;
+            }
+        }
         f32x4 pv = *(const f32x4*)(p + 4 * i);
         f32x4 mv = *(const f32x4*)(m + 4 * i);
         f32x4 vv = *(const f32x4*)(v + 4 * i);
-        const f32x4 gv = *(const f32x4*)(g + 4 * i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float w = pv[e] * decay;
@@ -82,23 +97,49 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
-// GradScaler bookkeeping on the device: a step whose gradient norm is not finite is skipped by the update kernels; here
-// it is COUNTED, and the bias corrections of every group are recomputed for the effective step t = host step - skipped
-// steps (torch's GradScaler.step does not call optimizer.step() at all after an overflow, so Adam's t does not advance).
+// GradScaler bookkeeping on the device, run ONCE PER STEP AFTER the update launches: a step whose gradients were not finite (the
+// norm the exact kernels saw, or the flag the guarded kernels raised) is COUNTED; the dynamic loss scale is halved on such a step
+// and doubled after `growth_interval` clean ones (torch.cuda.amp.GradScaler.update, Multimodal_example_task2C.py:712-717); and the
+// per-step scalars the NEXT step's update kernels read are written: bias corrections for t = host step + 1 - skipped steps
+// (GradScaler.step does not call optimizer.step() after an overflow, so Adam's t does not advance) and grad_scale = base / loss scale.
 struct SkipGroups {
     float* hyper[MH_ADAM_MAX_GROUPS];
     double b1[MH_ADAM_MAX_GROUPS], b2[MH_ADAM_MAX_GROUPS];
     int n;
 };
 __global__ __launch_bounds__(64) void adam_skip_account_kernel(const SkipGroups G, const float* __restrict__ gnorm_sq,
-                                                               int32_t* __restrict__ state, const int32_t* __restrict__ step_dev) {
+                                                               int32_t* __restrict__ state, const int32_t* __restrict__ step_dev,
+                                                               MhLossScale ls, int has_ls) {
     __shared__ int t_eff;
+    __shared__ float inv_scale;
     if (threadIdx.x == 0) {
-        const float nrm = sqrtf(gnorm_sq[0]) * fabsf(G.hyper[0][7]);
-        const int bad = !(nrm <= 3.0e38f);
+        int bad = 0;
+        if (gnorm_sq) {
+            const float nrm = sqrtf(gnorm_sq[0]) * fabsf(G.hyper[0][7]);
+            bad = !(nrm <= 3.0e38f);
+        }
+        if (has_ls && ls.overflow) {
+            bad |= (ls.overflow[0] != 0);
+            ls.overflow[0] = 0;
+        }
         if (bad) state[0] += 1;
         state[1] = bad;
-        t_eff = step_dev[0] - state[0];
+        t_eff = step_dev[0] + 1 - state[0];
+        inv_scale = 1.0f;
+        if (has_ls && ls.scale) {
+            float sc = ls.scale[0];
+            int gr = ls.growth ? ls.growth[0] : 0;
+            if (bad) {
+                sc = fmaxf(sc * ls.backoff_factor, ls.min_scale);
+                gr = 0;
+            } else if (++gr >= ls.growth_interval) {
+                sc = fminf(sc * ls.growth_factor, ls.max_scale);
+                gr = 0;
+            }
+            ls.scale[0] = sc;
+            if (ls.growth) ls.growth[0] = gr;
+            inv_scale = 1.0f / sc;
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < G.n) {
@@ -106,6 +147,7 @@ __global__ __launch_bounds__(64) void adam_skip_account_kernel(const SkipGroups 
         float* h = G.hyper[threadIdx.x];
         h[5] = (float)(1.0 / (1.0 - pow(G.b1[threadIdx.x], t)));
         h[6] = (float)(1.0 / sqrt(1.0 - pow(G.b2[threadIdx.x], t)));
+        if (has_ls) h[7] = ls.base_grad_scale * inv_scale;
     }
 }
 
@@ -115,7 +157,9 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
                                                         uint8_t* __restrict__ row_live,
                                                         const uint8_t* __restrict__ row_touched, int rows, int D,
                                                         const float* __restrict__ hyper, int decoupled,
-                                                        const float* __restrict__ gnorm_sq, float max_norm) {
+                                                        const float* __restrict__ gnorm_sq, float max_norm,
+                                                        int32_t* __restrict__ overflow) {
+    if (overflow && *(volatile int32_t*)overflow) return;
     const int lane = threadIdx.x & 63;
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
     const float inv_bc1 = hyper[5], inv_sqrt_bc2 = hyper[6];
@@ -139,10 +183,17 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
         if (!live) continue;
         const size_t base = (size_t)row * D;
         for (int c = lane * 4; c < D; c += 256) {
+            const f32x4 gv = *(const f32x4*)(g + base + c);
+            if (overflow) {
+                const float a = fabsf(gv[0]) + fabsf(gv[1]) + fabsf(gv[2]) + fabsf(gv[3]);
+                if (!(a <= 3.0e38f)) {
+                    *overflow = 1;
+                    continue;
+                }
+            }
             f32x4 pv = *(const f32x4*)(p + base + c);
             f32x4 mv = *(const f32x4*)(m + base + c);
             f32x4 vv = *(const f32x4*)(v + base + c);
-            const f32x4 gv = *(const f32x4*)(g + base + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float w = pv[e] * decay;
@@ -202,9 +253,17 @@ extern "C" int mh_sumsq_f32(const float* g, int64_t n, float* workspace, float* 
 }
 
 extern "C" int mh_adam_skip_account(const MhAdamSkipGroups* groups, const float* gnorm_sq, int32_t* state, const int32_t* step_dev,
-                                    mh_stream_t stream) {
-    if (!groups || !gnorm_sq || !state || !step_dev) return MH_EINVAL;
+                                    const MhLossScale* loss_scale, mh_stream_t stream) {
+    if (!groups || !state || !step_dev) return MH_EINVAL;
+    if (!gnorm_sq && !(loss_scale && loss_scale->overflow)) return MH_EINVAL;      // nothing that could say "not finite"
     if (groups->n < 1 || groups->n > MH_ADAM_MAX_GROUPS) return MH_ESHAPE;
+    MhLossScale ls = {};
+    if (loss_scale) {
+        ls = *loss_scale;
+        if (ls.scale && (!(ls.growth_factor >= 1.f) || !(ls.backoff_factor > 0.f && ls.backoff_factor <= 1.f) || ls.growth_interval < 1 ||
+                         !(ls.min_scale > 0.f) || !(ls.max_scale >= ls.min_scale)))
+            return MH_EINVAL;
+    }
     SkipGroups G;
     G.n = groups->n;
     for (int i = 0; i < MH_ADAM_MAX_GROUPS; ++i) {
@@ -213,30 +272,31 @@ extern "C" int mh_adam_skip_account(const MhAdamSkipGroups* groups, const float*
         G.b2[i] = groups->beta2[i];
         if (i < G.n && (!G.hyper[i] || !(G.b1[i] >= 0.0 && G.b1[i] < 1.0) || !(G.b2[i] >= 0.0 && G.b2[i] < 1.0))) return MH_EINVAL;
     }
-    hipLaunchKernelGGL(adam_skip_account_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, G, gnorm_sq, state, step_dev);
+    hipLaunchKernelGGL(adam_skip_account_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, G, gnorm_sq, state, step_dev, ls,
+                       loss_scale ? 1 : 0);
     return mh_launch_status();
 }
 
 extern "C" int mh_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t n,
                             int64_t n_shadow, const float* hyper, int decoupled, const float* gnorm_sq,
-                            float max_norm, mh_stream_t stream) {
+                            float max_norm, int32_t* overflow, mh_stream_t stream) {
     if (!p || !m || !v || !g || !hyper) return MH_EINVAL;
     if (n < 4 || (n & 3) || (n_shadow & 3) || n_shadow > n) return MH_ESHAPE;
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
-                       (h16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm);
+                       (h16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm, overflow);
     return mh_launch_status();
 }
 
 extern "C" int mh_adam_step_rows(float* p, float* m, float* v, const float* g, uint8_t* row_live,
                                  const uint8_t* row_touched, int rows, int D, const float* hyper, int decoupled,
-                                 const float* gnorm_sq, float max_norm, mh_stream_t stream) {
+                                 const float* gnorm_sq, float max_norm, int32_t* overflow, mh_stream_t stream) {
     if (!p || !m || !v || !g || !row_live || !hyper) return MH_EINVAL;
     if (rows < 1 || D < 4 || (D & 3)) return MH_ESHAPE;
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
     const int blocks = (rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096;
     hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, row_live, row_touched,
-                       rows, D, hyper, decoupled, gnorm_sq, max_norm);
+                       rows, D, hyper, decoupled, gnorm_sq, max_norm, overflow);
     return mh_launch_status();
 }
 

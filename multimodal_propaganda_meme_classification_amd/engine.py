@@ -161,6 +161,8 @@ class Engine:
         # id index of the embedding-gradient kernel (first position / multiplicity per vocabulary row; self-restoring)
         self.word_first = torch.full((cfg.text.vocab_size,), 0x7fffffff, dtype=torch.int32, device=self.dev)
         self.word_count = torch.zeros(cfg.text.vocab_size, dtype=torch.int32, device=self.dev)
+        # dynamic loss scale read by the fused loss launch (1 = none; a memehip.GradScaler attached to the model owns it)
+        self.loss_scale = torch.ones(1, dtype=F32, device=self.dev)
 
     # ---- parameter / gradient views -----------------------------------------------------------------
     def _slice(self, flat: torch.Tensor, name: str, count: int = 1) -> torch.Tensor:
@@ -575,7 +577,7 @@ class Engine:
         ncorrect = alloc("ncorrect", (1,), torch.int32, zero=True)
         grad_scale = 1.0
         pl.loss.c("mh_ce_fwd_bwd", _ptr(logits), _ptr(labels), _ptr(loss), _ptr(dlogits), _ptr(ncorrect), B, Cn,
-                  float(grad_scale))
+                  float(grad_scale), _ptr(self.loss_scale))
 
         # ------------------------------------------------------------------ backward -----------------
         def seg(name):

@@ -138,10 +138,15 @@ def train(model, train_loader, criterion, optimizer, scheduler, device, epoch, s
         labels = data["label"].to(device).float()
         output = _forward(model, data, device, pipe)
         loss = criterion(output, labels, alpha=0.25, gamma=2.0, reduction="mean")
-        loss.backward()
+        if scaler is not None and hasattr(scaler, "scale"):
+            scaler.scale(loss).backward()                      # :712
+        else:
+            loss.backward()
         if fused:
             grad_norm = optimizer.grad_norm() if (log_every and batch_idx % log_every == 0) else None
         else:
+            if scaler is not None and hasattr(scaler, "unscale_"):
+                scaler.unscale_(optimizer)                      # torch.cuda.amp.GradScaler with a torch optimizer: clip the true gradients
             grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), float("inf"))
             if max_grad_norm is not None:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)

@@ -632,16 +632,27 @@ class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, decoupled_weight_decay: bool = False, max_grad_norm: Optional[float] = None,
                  model: Optional[MultimodalClassifier] = None, skip_untouched_embedding_rows: bool = True,
-                 skip_nonfinite: bool = False):
+                 skip_nonfinite=None):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.decoupled = decoupled_weight_decay
         self.max_grad_norm = max_grad_norm
-        # skip_nonfinite: compute the gradient norm every step even without clipping and skip the update when it is
-        # inf / nan (an overflowed fp16 gradient stream) -- GradScaler's behaviour, Multimodal_example_task2C.py:712-717.
-        # Clipping implies it.  It needs every gradient before any update, so it turns the optimizer-in-backward
-        # overlap off, like clipping does.
-        self.skip_nonfinite = bool(skip_nonfinite)
+        # skip_nonfinite: never let a non-finite gradient (an overflowed fp16 gradient stream) into the master weights -- the
+        # reference's fp16 branch gets this from GradScaler (Multimodal_example_task2C.py:60-64,712-717).
+        #   None (default): on when a model this optimizer updates stores 16-bit values as fp16, or a GradScaler is attached
+        #   True: ``step()`` computes the global norm and skips the whole step when it is inf / nan (all or nothing, exactly
+        #         GradScaler.step); inside GraphedStep's optimizer-in-backward schedule, where a layer's slice is updated before
+        #         the global norm can exist, the GUARDED kernels are used instead: the first slice that meets a non-finite gradient
+        #         stops the step from there on (an overflow at the loss skips all of it, as GradScaler does; one that appears further
+        #         down the gradient stream leaves the layers above it updated with the finite gradients they had), and the step is
+        #         counted as an overflow (loss scale backed off)
+        #   "strict": all or nothing everywhere (turns the optimizer-in-backward overlap off, like clipping does)
+        # Clipping implies the all-or-nothing check.
+        if skip_nonfinite not in (None, True, False, "strict"):
+            raise ValueError(f"skip_nonfinite must be None, True, False or 'strict', got {skip_nonfinite!r}")
+        self.skip_nonfinite = skip_nonfinite
+        self._scaler = None
+        self._hyper_init = False
         self._model = model
         self._flat = None
         self._step = 0
@@ -714,7 +725,11 @@ class Adam(torch.optim.Optimizer):
                       nrm_total=torch.zeros(1, device=dev),
                       # GradScaler bookkeeping (mh_adam_skip_account): [skipped steps, last step skipped]; the host's step count
                       skip_state=torch.zeros(2, dtype=torch.int32, device=dev), step_dev=torch.zeros(1, dtype=torch.int32, device=dev),
+                      overflow=torch.zeros(1, dtype=torch.int32, device=dev),
                       step_ring=torch.zeros((32, 1), dtype=torch.int32).pin_memory())
+        if self.skip_nonfinite is None:
+            self.skip_nonfinite = self._scaler is not None or any(
+                bk["model"] is not None and bk["model"].config.compute_dtype == "fp16" for bk in buckets)
         if len(self.param_groups) > _lib.MH_ADAM_MAX_GROUPS and (self.max_grad_norm is not None or self.skip_nonfinite):
             raise ValueError(f"memehip.Adam: at most {_lib.MH_ADAM_MAX_GROUPS} parameter groups with clipping / skip_nonfinite")
         for bk in buckets:
@@ -740,50 +755,103 @@ class Adam(torch.optim.Optimizer):
                         _LOOSE[sp].zero_()
         return None
 
+    @property
+    def _accounted(self) -> bool:
+        """mh_adam_skip_account runs every step (after the updates) and owns hyper[5..7] from the second step on."""
+        return self.max_grad_norm is not None or bool(self.skip_nonfinite)
+
+    def _resolve_skip(self, model=None):
+        if self.skip_nonfinite is None and model is not None:
+            self.skip_nonfinite = self._scaler is not None or model.config.compute_dtype == "fp16"
+
+    def _attach_scaler(self, scaler):
+        if self._scaler is not None and self._scaler is not scaler:
+            raise ValueError("memehip.Adam: another GradScaler is already attached to this optimizer")
+        if self._scaler is None:
+            self._scaler = scaler
+            self._hyper_init = False
+            if self.skip_nonfinite in (None, False):
+                self.skip_nonfinite = True
+
     def _write_hyper(self):
         t = self._step
         host = self._flat["ring"][t % 32]
+        first = not (self._accounted and self._hyper_init)
+        if first and self._accounted and t > 1:          # re-initialisation mid-run (a scaler attached, a checkpoint loaded)
+            self._host_skipped = int(self._flat["skip_state"][0])
         for gi, g in enumerate(self.param_groups):
             b1, b2 = g["betas"]
-            host[gi].copy_(torch.tensor([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1.0 / (1.0 - b1 ** t),
-                                         1.0 / math.sqrt(1.0 - b2 ** t), self.grad_scale], dtype=F32))
-            self._flat["hyper"][gi].copy_(host[gi], non_blocking=True)
+            t_eff = max(t - (self._host_skipped if first else 0), 1)
+            host[gi].copy_(torch.tensor([g["lr"], b1, b2, g["eps"], g["weight_decay"], 1.0 / (1.0 - b1 ** t_eff),
+                                         1.0 / math.sqrt(1.0 - b2 ** t_eff), self.grad_scale], dtype=F32))
+            if first:
+                self._flat["hyper"][gi].copy_(host[gi], non_blocking=True)
+                if self._scaler is not None and self._scaler.is_enabled():
+                    self._flat["hyper"][gi][7:8].div_(self._scaler._tensor(self._flat["P"].device))
+            else:           # bias corrections and grad_scale / loss scale were written on the device by the last step's accounting
+                self._flat["hyper"][gi][:5].copy_(host[gi][:5], non_blocking=True)
+        self._hyper_init = True
         self._flat["step_ring"][t % 32][0] = t
         self._flat["step_dev"].copy_(self._flat["step_ring"][t % 32], non_blocking=True)
 
+    _host_skipped = 0          # skipped steps known to the host when the device scalars are (re)initialised (load_state_dict)
+
     @torch.no_grad()
     def step(self, closure=None):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("memehip.Adam.step() inside a hipGraph capture would freeze the step count, the bias corrections and "
+                               "the learning rate in the graph: write the per-step scalars outside (optimizer._step += 1; "
+                               "optimizer._write_hyper()) and capture optimizer.launch() -- GraphedStep does exactly that")
         self._bind()
         self._step += 1
         self._write_hyper()
         self.launch()
 
-    def launch(self, only: Optional[tuple] = None, skip: Optional[list] = None):
-        """Enqueue grad-norm (if clipping) + the fused update(s); hyper-parameters are read from device memory.
-        ``only=(a, b)`` updates just that slice of the primary flat buffer (optimizer-in-backward: a layer's matrices are
-        updated on the side stream as soon as their gradients are complete); ``skip`` = slices already done."""
-        nrm = None
-        if self.max_grad_norm is not None or self.skip_nonfinite:
-            assert only is None, "clipping / the non-finite check need the global gradient norm before any update"
-            nrm = self._global_norm_sq()
-            self._skip_account(nrm)
+    def launch(self, only: Optional[tuple] = None, skip: Optional[list] = None, guarded: bool = False):
+        """Enqueue grad-norm (if clipping / all-or-nothing) + the fused update(s) + the per-step accounting; hyper-parameters are
+        read from device memory.  ``only=(a, b)`` updates just that slice of the primary flat buffer (optimizer-in-backward: a
+        layer's matrices are updated on the side stream as soon as their gradients are complete); ``skip`` = slices already done;
+        ``guarded``: this launch belongs to a schedule that updates slices before the global norm exists (see skip_nonfinite)."""
+        nrm, flag = None, None
+        if self._accounted:
+            if guarded and self.max_grad_norm is None and self.skip_nonfinite != "strict":
+                flag = self._flat["overflow"]
+            else:
+                assert only is None, "clipping / the all-or-nothing check need the global gradient norm before any update"
+                nrm = self._global_norm_sq()
         for bi, f in enumerate(self._buckets):
             if bi > 0 and only is not None:
                 break
-            self._launch_bucket(f, nrm, only if bi == 0 else None, skip if bi == 0 else None)
+            self._launch_bucket(f, nrm, only if bi == 0 else None, skip if bi == 0 else None, flag)
+        if self._accounted and only is None:
+            self._skip_account(nrm, flag)
 
-    def _skip_account(self, nrm):
-        """A step with a non-finite gradient norm is skipped by the update kernels; count it on the device and recompute the
-        bias corrections for the steps actually taken (GradScaler.step never calls optimizer.step() after an overflow, so
-        torch's Adam does not advance t either).  One 64-thread launch, graph-replayable (the host's step count is read from
-        device memory)."""
+    def _skip_account(self, nrm, flag=None):
+        """After the update launches of a step: count it if its gradients were not finite (the norm the exact kernels saw / the flag
+        the guarded kernels raised), move the dynamic loss scale (GradScaler.update's rule) and write the bias corrections and
+        grad_scale / loss scale the NEXT step's kernels read -- for the steps actually taken: GradScaler.step never calls
+        optimizer.step() after an overflow, so torch's Adam does not advance t either.  One 64-thread launch, graph-replayable
+        (the host's step count is read from device memory)."""
         f = self._flat
         grp = _lib.MhAdamSkipGroups()
         grp.n = len(self.param_groups)
         for gi, g in enumerate(self.param_groups):
             grp.hyper[gi] = f["hyper"][gi].data_ptr()
             grp.beta1[gi], grp.beta2[gi] = float(g["betas"][0]), float(g["betas"][1])
-        _lib.check(_lib.load().mh_adam_skip_account(C.byref(grp), nrm.data_ptr(), f["skip_state"].data_ptr(), f["step_dev"].data_ptr(),
+        ls = None
+        sc = self._scaler if (self._scaler is not None and self._scaler.is_enabled()) else None
+        if sc is not None or flag is not None:
+            ls = _lib.MhLossScale()
+            dev = f["P"].device
+            ls.scale = sc._tensor(dev).data_ptr() if sc is not None else None
+            ls.growth = sc._growth.data_ptr() if sc is not None else None
+            ls.overflow = flag.data_ptr() if flag is not None else None
+            ls.growth_factor, ls.backoff_factor = (sc.growth_factor, sc.backoff_factor) if sc is not None else (1.0, 1.0)
+            ls.min_scale, ls.max_scale = (sc.min_scale, sc.max_scale) if sc is not None else (1.0, 1.0)
+            ls.growth_interval = sc.growth_interval if sc is not None else 1
+            ls.base_grad_scale = float(self.grad_scale)
+        _lib.check(_lib.load().mh_adam_skip_account(C.byref(grp), None if nrm is None else nrm.data_ptr(), f["skip_state"].data_ptr(),
+                                                    f["step_dev"].data_ptr(), None if ls is None else C.byref(ls),
                                                     torch.cuda.current_stream().cuda_stream), "mh_adam_skip_account")
 
     @property
@@ -812,9 +880,12 @@ class Adam(torch.optim.Optimizer):
         """Global L2 norm of the gradients times the data-parallel scale, what ``clip_grad_norm_(model.parameters(),
         float("inf"))`` returns in the reference's loop (Multimodal_example_task2C.py:713): a device scalar, no sync."""
         self._bind()
-        return self._global_norm_sq().sqrt()[0] * abs(self.grad_scale)
+        n = self._global_norm_sq().sqrt()[0] * abs(self.grad_scale)
+        if self._scaler is not None and self._scaler.is_enabled():
+            n = n / self._scaler._tensor(self._flat["P"].device)[0]
+        return n
 
-    def _launch_bucket(self, f, nrm, only, skip):
+    def _launch_bucket(self, f, nrm, only, skip, flag=None):
         model = f["model"]
         n_shadow = model.layout.n_shadow if model is not None else 0
         runs = []
@@ -843,7 +914,7 @@ class Adam(torch.optim.Optimizer):
                     if a < ta:
                         nxt.append((gi, a, ta))
                     ops.adam_step_rows(f["P"][ta:tb], f["M"][ta:tb], f["V"][ta:tb], f["G"][ta:tb], f["row_live"], touched, V, D,
-                                       f["hyper"][gi], self.decoupled, nrm, float(self.max_grad_norm or 0.0))
+                                       f["hyper"][gi], self.decoupled, nrm, float(self.max_grad_norm or 0.0), flag)
                     if tb < b:
                         nxt.append((gi, tb, b))
                 else:
@@ -853,7 +924,7 @@ class Adam(torch.optim.Optimizer):
             sh_n = max(0, min(b, n_shadow) - a)            # part of this run that has a 16-bit shadow
             shadow = model.flat_shadow[a:a + sh_n] if (model is not None and sh_n > 0) else None
             ops.adam_step(f["P"][a:b], f["M"][a:b], f["V"][a:b], f["G"][a:b], shadow, sh_n, f["hyper"][gi], self.decoupled,
-                          nrm, float(self.max_grad_norm or 0.0))
+                          nrm, float(self.max_grad_norm or 0.0), flag)
         if model is not None and only is None:
             model._shadow_synced()
 
@@ -909,13 +980,110 @@ class Adam(torch.optim.Optimizer):
                 live = ((f["M"][ta:tb].view(V, D) != 0) | (f["V"][ta:tb].view(V, D) != 0)).any(dim=1)
                 f["row_live"].copy_(live.to(torch.uint8))
         self._step = int(state_dict["step"])
-        self._flat["skip_state"].copy_(torch.tensor([int(state_dict.get("skipped", 0)), 0], dtype=torch.int32))
+        self._host_skipped = int(state_dict.get("skipped", 0))
+        self._hyper_init = False          # the next step re-initialises the device-side bias corrections for step - skipped
+        self._flat["skip_state"].copy_(torch.tensor([self._host_skipped, 0], dtype=torch.int32))
         groups = state_dict.get("param_groups")
         if groups is not None:
             if len(groups) != len(self.param_groups):
                 raise ValueError("loaded state dict has a different number of parameter groups")
             for g, sg in zip(self.param_groups, groups):
                 g.update({k: val for k, val in sg.items() if k != "params"})
+
+
+class GradScaler:
+    """``torch.cuda.amp.GradScaler``'s interface (the reference's fp16 branch: ``scaler.scale(loss).backward()``,
+    ``scaler.step(optimizer)``, ``scaler.update()``, Multimodal_example_task2C.py:60-64,712-717) over a DEVICE-RESIDENT scale, so a
+    step never synchronises with the host and a captured hipGraph replays it.
+
+    The fp16 build carries a static power-of-two factor (``ModelConfig.grad_stream_scale``, 8192) on its 16-bit gradient streams
+    inside the kernels; this object holds the DYNAMIC factor on top of it: ``scale(loss)`` multiplies the loss by it (the fused step
+    reads it in the loss kernel), ``memehip.Adam`` divides it out again inside its update (``hyper[7]``), a step whose gradients were
+    not finite is skipped / guarded and halves the factor, ``growth_interval`` clean steps double it -- the rule of
+    ``GradScaler.update``.  ``init_scale`` and ``max_scale`` are relative to the static factor: the defaults 1 and 8 mean 8192 and
+    65536 (torch's initial scale) in total.  With a torch optimizer ``step`` falls back to torch's own unscale-and-check (one host
+    synchronisation per step, as torch.cuda.amp.GradScaler has)."""
+
+    def __init__(self, init_scale: float = 1.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000,
+                 enabled: bool = True, max_scale: float = 8.0, min_scale: float = 2.0 ** -14):
+        if not (growth_factor >= 1.0 and 0.0 < backoff_factor <= 1.0 and growth_interval >= 1 and 0.0 < min_scale <= init_scale <= max_scale):
+            raise ValueError("GradScaler: need growth_factor >= 1, 0 < backoff_factor <= 1, growth_interval >= 1, "
+                             "0 < min_scale <= init_scale <= max_scale")
+        self.init_scale, self.growth_factor, self.backoff_factor = float(init_scale), float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.max_scale, self.min_scale = int(growth_interval), float(max_scale), float(min_scale)
+        self._enabled = bool(enabled)
+        self._scale = None            # device f32[1]
+        self._growth = None           # device i32[1]
+        self._found = None            # torch-optimizer path: device f32[1]
+
+    def is_enabled(self) -> bool:
+        return self._enabled
+
+    def _tensor(self, device) -> torch.Tensor:
+        if self._scale is None:
+            self._scale = torch.full((1,), self.init_scale, dtype=F32, device=device)
+            self._growth = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._scale
+
+    def attach_model(self, model: "MultimodalClassifier"):
+        """The fused step (``forward_backward`` / ``GraphedStep``) computes the loss inside the model's launch plan: its loss kernel
+        reads the model's loss-scale word, which becomes this scaler's tensor."""
+        eng = model._get_engine()
+        if self._scale is None:
+            self._scale = eng.loss_scale
+            self._scale.fill_(self.init_scale)
+            self._growth = torch.zeros(1, dtype=torch.int32, device=self._scale.device)
+        elif self._scale.data_ptr() != eng.loss_scale.data_ptr():
+            raise ValueError("GradScaler.attach_model: this scaler already drives another model / optimizer")
+        return self
+
+    def scale(self, outputs):
+        if not self._enabled:
+            return outputs
+        return outputs * self._tensor(outputs.device)[0]
+
+    def step(self, optimizer, *args, **kwargs):
+        if not self._enabled:
+            return optimizer.step(*args, **kwargs)
+        if isinstance(optimizer, Adam):
+            optimizer._attach_scaler(self)
+            return optimizer.step(*args, **kwargs)
+        grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+        if not grads:
+            return None
+        sc = self._tensor(grads[0].device)
+        self._found = torch.zeros(1, dtype=F32, device=sc.device)
+        torch._amp_foreach_non_finite_check_and_unscale_(grads, self._found, 1.0 / sc)
+        if float(self._found) == 0.0:
+            return optimizer.step(*args, **kwargs)
+        return None
+
+    def update(self, new_scale: Optional[float] = None):
+        if not self._enabled:
+            return
+        if new_scale is not None:
+            self._tensor(self._scale.device if self._scale is not None else "cuda").fill_(float(new_scale))
+            self._growth.zero_()
+        elif self._found is not None:          # torch-optimizer path; with memehip.Adam the step's accounting kernel has done it
+            torch._amp_update_scale_(self._scale, self._growth, self._found, self.growth_factor, self.backoff_factor, self.growth_interval)
+            self._scale.clamp_(self.min_scale, self.max_scale)
+            self._found = None
+
+    def get_scale(self) -> float:
+        """The dynamic factor (synchronises).  Times the model's static ``stream_scale`` it is what torch's get_scale() reports."""
+        return self.init_scale if self._scale is None else float(self._scale)
+
+    def state_dict(self):
+        return dict(scale=self.get_scale(), growth_tracker=0 if self._growth is None else int(self._growth), growth_factor=self.growth_factor,
+                    backoff_factor=self.backoff_factor, growth_interval=self.growth_interval)
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"])
+        if self._scale is None:
+            self.init_scale = float(sd["scale"])
+        else:
+            self._scale.fill_(float(sd["scale"]))
+            self._growth.fill_(int(sd["growth_tracker"]))
 
 
 def flatten_parameters(module: nn.Module) -> nn.Module:
@@ -961,9 +1129,19 @@ class GraphedStep:
     """
 
     def __init__(self, model: MultimodalClassifier, optimizer: Adam, batch: int, seq_len: int, use_graph: bool = True,
-                 reducer=None, overlap_wgrad: bool = True, overlap_optimizer: bool = True, ddp_mode: Optional[str] = None):
+                 reducer=None, overlap_wgrad: bool = True, overlap_optimizer: bool = True, ddp_mode: Optional[str] = None,
+                 scaler: Optional["GradScaler"] = None):
         self.model, self.opt = model, optimizer
         optimizer._model = model
+        optimizer._resolve_skip(model)
+        # fp16 storage: the dynamic loss scale is on by default (GradScaler's rule on the device, no host synchronisation);
+        # ``scaler=GradScaler(enabled=False)`` keeps the static 8192 alone
+        if scaler is None and model.config.compute_dtype == "fp16" and optimizer.skip_nonfinite:
+            scaler = GradScaler()
+        if scaler is not None and scaler.is_enabled():
+            scaler.attach_model(model)
+            optimizer._attach_scaler(scaler)
+        self.scaler = scaler
         eng = model._get_engine()
         self.plan = eng.plan(batch, seq_len, True, gather_world=(reducer.world if reducer is not None else 0))
         if model.weights_changed():
@@ -986,12 +1164,13 @@ class GraphedStep:
         # optimizer-in-backward: the (HBM-bound) Adam update of a layer pair's matrices follows their weight-gradient
         # GEMMs on the side stream, under the (MFMA-bound) backward chain of the layers below; only the tail
         # (embeddings, biases, head) is updated after the backward.  Needs no global clip and a single GPU.
+        # (with skip_nonfinite=True the slices go through the GUARDED update kernels; clipping and "strict" need the global norm first)
         self.opt_in_bwd = bool(overlap_optimizer and self.side is not None and reducer is None and optimizer.max_grad_norm is None
-                               and not optimizer.skip_nonfinite)
+                               and optimizer.skip_nonfinite != "strict")
         # data parallel: the same idea behind the all-reduce -- as soon as a layer pair's gradient slice has been summed
         # over the ranks, its Adam update runs on a side stream under the backward of the layers below
         self.ddp_opt_in_bwd = bool(overlap_optimizer and reducer is not None and optimizer.max_grad_norm is None
-                                   and not optimizer.skip_nonfinite)
+                                   and optimizer.skip_nonfinite != "strict")
         self.ddp_side = torch.cuda.Stream() if self.ddp_opt_in_bwd else None
         self.ddp_wside = torch.cuda.Stream() if (reducer is not None and overlap_wgrad and not self.ddp_stream) else None
         self.closed = False
@@ -1108,7 +1287,7 @@ class GraphedStep:
                             for w in works:
                                 w.wait()
                             for r in layer_rngs:
-                                self.opt.launch(only=r)
+                                self.opt.launch(only=r, guarded=True)
                         done.extend(layer_rngs)
                     pend.clear(); pend_ev.clear(); pend_layer[0] = True
 
@@ -1138,7 +1317,7 @@ class GraphedStep:
                             e.record(main)
                             self.side.wait_event(e)
                         with torch.cuda.stream(self.side):
-                            self.opt.launch(only=rng)
+                            self.opt.launch(only=rng, guarded=True)
                         ev = torch.cuda.Event()
                         ev.record(self.side)
                         events[seg.name] = ev
@@ -1152,7 +1331,8 @@ class GraphedStep:
         if self.ddp_opt_in_bwd and not self.ddp_stream:
             self._opt_done = [p.bucket_after[seg.name] for seg in p.bwd
                               if seg.name.startswith("bwd_layer_") and p.bucket_after.get(seg.name) is not None]
-        pieces.append(("opt", lambda stream: self.opt.launch(skip=getattr(self, "_opt_done", None)), None))
+        pieces.append(("opt", lambda stream: self.opt.launch(skip=getattr(self, "_opt_done", None),
+                                                             guarded=self.opt_in_bwd or self.ddp_opt_in_bwd), None))
         return pieces
 
     def _after_segment(self, name, rng):
@@ -1164,7 +1344,7 @@ class GraphedStep:
             with torch.cuda.stream(self.ddp_side):
                 for w in works:
                     w.wait()
-                self.opt.launch(only=rng)
+                self.opt.launch(only=rng, guarded=True)
 
     def _run_eager(self):
         stream = torch.cuda.current_stream().cuda_stream
@@ -1234,6 +1414,10 @@ class GraphedStep:
         # it does not count as a training step; then capture the same launches
         f = self.opt._flat
         snap = (f["P"].clone(), f["M"].clone(), f["V"].clone())
+        acct = [f["skip_state"], f["overflow"]] + list(f["hyper"])        # the warm-up's accounting launch must not count as a step
+        if self.opt._scaler is not None and self.opt._scaler._scale is not None:
+            acct += [self.opt._scaler._scale, self.opt._scaler._growth]
+        acct_snap = [t.clone() for t in acct]
         counters = (self.reducer.reduced_elems, self.reducer.wire_bytes) if self.reducer is not None else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -1251,6 +1435,8 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         f["P"].copy_(snap[0]); f["M"].copy_(snap[1]); f["V"].copy_(snap[2])
+        for t, c in zip(acct, acct_snap):
+            t.copy_(c)
         if counters is not None:      # (the stream schedule's warm-up ran the collectives for real)
             self.reducer.reduced_elems, self.reducer.wire_bytes = counters
         self.model.refresh_shadow()

@@ -511,23 +511,23 @@ def bn1d_bwd(dy, x, y, gamma, save_mean, save_rstd, relu: bool = False, frozen_s
     return dx, dg, db
 
 
-def ce_fwd_bwd(logits, labels, loss, dlogits, n_correct=None, grad_scale: float = 1.0):
+def ce_fwd_bwd(logits, labels, loss, dlogits, n_correct=None, grad_scale: float = 1.0, grad_scale_dev=None):
     _chk(logits, F32, "logits"), _chk(labels, I64, "labels"), _chk(loss, F32, "loss"), _chk(dlogits, F32, "dlogits")
     B, Cn = logits.shape
     assert labels.numel() >= B and dlogits.numel() >= B * Cn
     if n_correct is not None:
         _chk(n_correct, torch.int32, "n_correct")
     check(_lib.load().mh_ce_fwd_bwd(_p(logits), _p(labels), _p(loss), _p(dlogits), _p(n_correct), B, Cn,
-                                    float(grad_scale), _stream()), "mh_ce_fwd_bwd")
+                                    float(grad_scale), _p(grad_scale_dev), _stream()), "mh_ce_fwd_bwd")
 
 
-def focal_fwd_bwd(logits, targets, loss, dlogits, n_correct=None, alpha=0.25, gamma=2.0, grad_scale=1.0):
+def focal_fwd_bwd(logits, targets, loss, dlogits, n_correct=None, alpha=0.25, gamma=2.0, grad_scale=1.0, grad_scale_dev=None):
     """logits f32 [B] or [B,1]; targets f32 [B]"""
     _chk(logits, F32, "logits"), _chk(targets, F32, "targets"), _chk(loss, F32, "loss"), _chk(dlogits, F32, "dlogits")
     B = targets.numel()
     assert logits.numel() == B == dlogits.numel()
     check(_lib.load().mh_focal_fwd_bwd(_p(logits), 1, _p(targets), _p(loss), _p(dlogits), _p(n_correct), B, float(alpha),
-                                       float(gamma), float(grad_scale), _stream()), "mh_focal_fwd_bwd")
+                                       float(gamma), float(grad_scale), _p(grad_scale_dev), _stream()), "mh_focal_fwd_bwd")
 
 
 def sumsq(g, workspace, out):
@@ -536,7 +536,7 @@ def sumsq(g, workspace, out):
     check(_lib.load().mh_sumsq_f32(_p(g), g.numel(), _p(workspace), _p(out), _stream()), "mh_sumsq_f32")
 
 
-def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0):
+def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0, overflow=None):
     for nm, t in (("p", p), ("m", m), ("v", v), ("g", g), ("hyper", hyper)):
         _chk(t, F32, nm)
     n = p.numel()
@@ -545,10 +545,10 @@ def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=Non
         _chk(shadow, BF16, "shadow")
         assert shadow.numel() >= n_shadow
     check(_L(shadow if shadow is not None else p).mh_adam_step(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, n_shadow if shadow is not None else 0,
-                                   _p(hyper), int(decoupled), _p(gnorm_sq), float(max_norm), _stream()), "mh_adam_step")
+                                   _p(hyper), int(decoupled), _p(gnorm_sq), float(max_norm), _p(overflow), _stream()), "mh_adam_step")
 
 
-def adam_step_rows(p, m, v, g, row_live, row_touched, rows, D, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0):
+def adam_step_rows(p, m, v, g, row_live, row_touched, rows, D, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0, overflow=None):
     """mh_adam_step_rows: Adam over a [rows][D] table, rows with no gradient history skipped (row_live |= row_touched)."""
     for nm, t in (("p", p), ("m", m), ("v", v), ("g", g), ("hyper", hyper)):
         _chk(t, F32, nm)
@@ -557,7 +557,7 @@ def adam_step_rows(p, m, v, g, row_live, row_touched, rows, D, hyper, decoupled=
     if not (row_live.is_cuda and row_live.dtype == torch.uint8 and row_live.numel() >= rows):
         raise TypeError("row_live must be a device uint8 tensor with one byte per row")
     check(_lib.load().mh_adam_step_rows(_p(p), _p(m), _p(v), _p(g), _p(row_live), _p(row_touched), rows, D, _p(hyper), int(decoupled),
-                                        _p(gnorm_sq), float(max_norm), _stream()), "mh_adam_step_rows")
+                                        _p(gnorm_sq), float(max_norm), _p(overflow), _stream()), "mh_adam_step_rows")
 
 
 def cast_f32_bf16(src, dst):

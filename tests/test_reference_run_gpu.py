@@ -211,10 +211,7 @@ def _kevin_setup(pkg, E, z, tmp_path):
     tc = pkg.TextConfig(vocab_size=tok_ar.vocab_size, hidden=768, layers=cfg["text_layers"], heads=12, intermediate=3072, max_position=512)
     cc = pkg.TextConfig(vocab_size=tok_en.vocab_size, hidden=768, layers=cfg["caption_layers"], heads=12, intermediate=3072, max_position=512)
     ic = pkg.ImageConfig(image_size=v["image_size"], patch=v["patch"], hidden=v["hidden"], layers=v["layers"], heads=v["heads"], intermediate=v["intermediate"])
-    # the reference's fp32 branch cannot overflow; its eval-mode steps (batches 3-4, see below) carry gradients ~20-100x larger than the
-    # train-mode ones (BatchNorm on running statistics), which the default 8192x fp16 gradient-stream scale does not leave room for
-    model = pkg.KevinMultimodalClassifier("concatenation", text=tc, image=ic, caption=cc, proj=cfg["proj"], compute_dtype="fp16",
-                                          grad_stream_scale=64.0)
+    model = pkg.KevinMultimodalClassifier("concatenation", text=tc, image=ic, caption=cc, proj=cfg["proj"], compute_dtype="fp16")
     state = E.kevin_state(tok_ar.vocab_size, tok_en.vocab_size, cfg)
     pfx = "image_model.image_model."
     ref_sd = {k: t for k, t in state.items() if not k.startswith(pfx)}
@@ -248,6 +245,11 @@ def test_kevin_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, t
     assert [sum(p.numel() for p in g["params"]) for g in groups] == [int(z["group_sizes"][0]) + unused, int(z["group_sizes"][1]) + stub,
                                                                      int(z["group_sizes"][2])]
     optimizer = pkg.Adam(groups, max_grad_norm=10.0)                      # fp32 branch: clip at 10.0 (:729-730)
+    # The reference's fp32 branch cannot overflow.  Its eval-mode steps (batches 3-4, see below) carry gradients ~20-100x larger than
+    # the train-mode ones (BatchNorm on running statistics), more than the default 8192x fp16 gradient-stream scale leaves room for:
+    # a GradScaler started at 2^-7 (64x in total) keeps every step finite, so that the trajectory can be compared step for step.  (Left
+    # at its default the scaler skips step 3 and halves itself, as torch.cuda.amp.GradScaler would in the reference's fp16 branch.)
+    scaler = pkg.GradScaler(init_scale=2.0 ** -7, growth_interval=1000)
     scheduler = pkg.get_linear_schedule_with_warmup(optimizer, num_warmup_steps=2, num_training_steps=8)
     criterion = pkg.SigmoidFocalLoss()
     fwd = []
@@ -290,8 +292,9 @@ def test_kevin_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, t
     assert max(abs(float(a[2]) - float(b[2])) for a, b in zip(prow0[1:], rrow0[1:])) < 2 * perr0 + 1e-6
     # ---- one epoch of train() with the reference's mid-epoch checks
     kv.best_macro_f1 = 0.0
-    train_loss, acc = kv.train(model, loader, criterion, optimizer, scheduler, device, 0, None, test_df=loader, val_df=loader, evaluate_kwargs=ekw,
+    train_loss, acc = kv.train(model, loader, criterion, optimizer, scheduler, device, 0, scaler, test_df=loader, val_df=loader, evaluate_kwargs=ekw,
                                log_every=0)
+    assert scaler.get_scale() == 2.0 ** -7
     # forward calls: batch 1, batch 2, [check: test x4, test x4, (evaluate x4)], batch 3, batch 4, [check ...]
     n_eval_calls = int(z["mid_epoch_evaluate_calls"])
     order = [0, 1]
