@@ -47,7 +47,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the secondary lines (other storage type, all-ones masks, dense text rows)")
+                    help="skip the secondary lines (other storage type, all-ones masks, dense text rows, unguarded / clipped / dropout "
+                         "variants, configs 5 and 2)")
+    ap.add_argument("--batches", type=int, default=8,
+                    help="distinct synthetic batches resident in HBM, loaded in turn (one device-to-device copy per step inside the timed "
+                         "region): other token ids, other ragged masks every step, as a DataLoader would hand over; 1 = replay one batch")
+    ap.add_argument("--unguarded", action="store_true", help="A/B: fp16 without overflow protection (skip_nonfinite=False, no loss scaler)")
+    ap.add_argument("--clip", type=float, default=0.0, help="A/B: max_grad_norm (the Trainer / Kevin variants clip at 1.0)")
+    ap.add_argument("--reference-dropout", action="store_true", help="A/B: BERT 0.1 / 0.1 + head Dropout(0.3), as the reference trains")
     ap.add_argument("--tiny", action="store_true", help="tiny model (debug only; not a bench line)")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="A/B: weight-gradient GEMMs on the main stream")
     ap.add_argument("--no-overlap-opt", action="store_true", help="A/B: whole Adam update after the backward")
@@ -135,29 +142,59 @@ def cpu_baseline(batch, seq, tiny, warm=3, timed=5, config=3):
                       f"(min {times[0]:.2f}, max {times[-1]:.2f}) on {threads} threads"}
 
 
-def timed_variant(pkg, args, device, dtype=None, full_masks=None, dense_text=None):
+def opt_kwargs(args, unguarded=None, clip=None):
+    kw = {}
+    if (args.unguarded if unguarded is None else unguarded):
+        kw["skip_nonfinite"] = False
+    c = args.clip if clip is None else clip
+    if c and c > 0:
+        kw["max_grad_norm"] = float(c)
+    return kw
+
+
+def make_batches(cfg, args, device, rank=0, full_masks=None, n=None):
+    fm = args.full_masks if full_masks is None else full_masks
+    return [synthetic_batch(cfg, args.batch, args.seq, seed=1234 + rank + 7919 * k, device=device, full_masks=fm)
+            for k in range(max(1, args.batches if n is None else n))]
+
+
+def run_steps(step, batches, n, start=0):
+    out = None
+    for i in range(n):
+        step.load_batch(*batches[(start + i) % len(batches)])
+        out = step.step()
+    return out
+
+
+def timed_variant(pkg, args, device, dtype=None, full_masks=None, dense_text=None, unguarded=None, clip=None, reference_dropout=None,
+                  config=None, n_batches=None):
     """One more single-GPU measurement of the same step under a different switch: returns (memes/s, ms/step)."""
-    cfg = make_config(pkg, args)
+    import copy
+    a = copy.copy(args)
+    if config is not None:
+        a.config = config
+        a.seq = 256 if config == 5 else 128
+    cfg = make_config(pkg, a)
     cfg.compute_dtype = dtype or args.dtype
     cfg.pack_text = not (args.dense_text if dense_text is None else dense_text)
+    if (args.reference_dropout if reference_dropout is None else reference_dropout):
+        cfg.with_reference_dropout()
     model = pkg.MultimodalClassifier.from_config(cfg, device=device, seed=0)
     model.train()
-    opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)
-    step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph,
+    opt = pkg.Adam(model.parameters(), lr=2e-5, model=model, **opt_kwargs(args, unguarded, clip))
+    step = pkg.GraphedStep(model, opt, a.batch, a.seq, use_graph=not args.no_graph,
                            overlap_wgrad=not args.no_overlap_wgrad, overlap_optimizer=not args.no_overlap_opt)
-    step.load_batch(*synthetic_batch(cfg, args.batch, args.seq, seed=1234, device=device,
-                                     full_masks=args.full_masks if full_masks is None else full_masks))
-    for _ in range(max(args.warmup, 1)):
-        step.step()
+    batches = make_batches(cfg, a, device, full_masks=full_masks, n=n_batches)
+    run_steps(step, batches, max(args.warmup, 1))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step.step()
+    run_steps(step, batches, args.steps, start=max(args.warmup, 1))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    del step, opt, model
+    step.close()
+    del step, opt, model, batches
     torch.cuda.empty_cache()
-    return args.batch * args.steps / dt, dt / args.steps * 1e3
+    return a.batch * args.steps / dt, dt / args.steps * 1e3
 
 
 def bench_config2(args):
@@ -169,32 +206,48 @@ def bench_config2(args):
     model = pkg.ResNetClassifier(num_labels=2, compute_dtype=args.dtype).to(device)
     pkg.flatten_parameters(model)
     model.train()
-    opt = pkg.Adam(model.parameters(), lr=2e-5)
+    # fp16 activations: the all-or-nothing overflow check (global norm, then the update) -- skip_nonfinite=True
+    opt = pkg.Adam(model.parameters(), lr=2e-5, skip_nonfinite=(args.dtype == "fp16" and not args.unguarded))
     g = torch.Generator().manual_seed(1234)
-    image = torch.randn((args.batch, 3, 224, 224), generator=g).to(device)
-    labels = (torch.rand((args.batch,), generator=g) < 0.28).long().to(device)
+    nb = max(1, args.batches)
+    images = [torch.randn((args.batch, 3, 224, 224), generator=g).to(device) for _ in range(nb)]
+    labelss = [(torch.rand((args.batch,), generator=g) < 0.28).long().to(device) for _ in range(nb)]
+    image, labels = images[0].clone(), labelss[0].clone()          # the graph's static input buffers
     loss_buf = torch.zeros((), device=device)
+    turn = [0]
 
-    def one_step():
+    def launches():                 # everything of a step that is a device launch (capturable)
         opt.zero_grad()
         loss, _ = model(pixel_values=image, labels=labels)
         loss.backward()
-        opt.step()
+        opt.launch()
         loss_buf.copy_(loss.detach())
 
+    def one_step():
+        k = turn[0] % nb
+        turn[0] += 1
+        image.copy_(images[k], non_blocking=True)
+        labels.copy_(labelss[k], non_blocking=True)
+        opt._step += 1              # the per-step scalars (step count, bias corrections, lr) are written OUTSIDE the graph,
+        opt._write_hyper()          # as GraphedStep does: captured inside they would freeze at their capture-time values
+        (graph.replay if graph is not None else launches)()
+
+    graph = None
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(2):
-            one_step()
+        opt.zero_grad()
+        loss0, _ = model(pixel_values=image, labels=labels)
+        loss0.backward()
+        opt.step()                  # binds the optimizer to the flat buffers (eager)
+        one_step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = None
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            one_step()
-    run = graph.replay if graph is not None else one_step
+            launches()
+    run = one_step
     for _ in range(max(args.warmup, 1)):
         run()
     torch.cuda.synchronize()
@@ -210,14 +263,17 @@ def bench_config2(args):
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"Subtask-2B fine-tune step: torchvision-topology ResNet-50 (25.6 M parameters), 3x224x224, batch {args.batch}, "
-                                  "fwd+CE+bwd+Adam, train-mode BatchNorm, random-init weights; convolutions = MFMA GEMM over explicit NHWC im2col",
+                                  "fwd+CE+bwd+Adam, train-mode BatchNorm, random-init weights; convolutions = MFMA GEMM over explicit NHWC im2col; "
+                                  f"{nb} resident batches in turn",
                       "global_batch": args.batch, "image": "3x224x224", "parallelism": "dp1",
                       "launch": "eager" if args.no_graph else "hipGraph", "final_loss": round(float(loss_buf), 5),
                       "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
            "roofline": {"bound": "mfma", "kernel": "whole step (conv GEMMs + im2col / BatchNorm passes)",
                         "achieved": round(flop_per_image * value / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flop_per_image * value / (MFMA_PEAK_TFLOPS * 1e12), 4), "traffic": None}}
-    print(json.dumps(out), flush=True)
+    del graph, opt, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -225,7 +281,8 @@ def main():
     if args.config == 2:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-        return bench_config2(args)
+        print(json.dumps(bench_config2(args)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -258,6 +315,8 @@ def main():
     cfg = make_config(pkg, args)
     cfg.compute_dtype = args.dtype
     cfg.pack_text = not args.dense_text
+    if args.reference_dropout:
+        cfg.with_reference_dropout()
     model = pkg.MultimodalClassifier.from_config(cfg, device=device, seed=0)
     model.train()
     reducer = None
@@ -265,26 +324,23 @@ def main():
         ddp.broadcast_parameters(model.flat_params)
         model.mark_weights_changed()
         reducer = ddp.GradientReducer(model.flat_grads, compress=None if args.ddp_compress == "none" else args.ddp_compress)
-    opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)
+    opt = pkg.Adam(model.parameters(), lr=2e-5, model=model, **opt_kwargs(args))
     step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer,
                            overlap_wgrad=not args.no_overlap_wgrad, overlap_optimizer=not args.no_overlap_opt, ddp_mode=args.ddp_mode)
     if reducer is not None:
         end = ddp.check_bucket_cover(step.plan.bucket_after, model.layout.n_total)
         assert end == model.layout.spec["bert.embeddings.token_type_embeddings.weight"].offset, end
-    batch = synthetic_batch(cfg, args.batch, args.seq, seed=1234 + rank, device=device, full_masks=args.full_masks)
-    step.load_batch(*batch)
+    batches = make_batches(cfg, args, device, rank=rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):       # >= 1: the first call captures the graph(s)
-        step.step()
+    run_steps(step, batches, max(args.warmup, 1))       # >= 1: the first call captures the graph(s)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step.step()
+    loss, _ = run_steps(step, batches, args.steps, start=max(args.warmup, 1))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -357,6 +413,15 @@ def main():
                                                                  if step.ddp_stream else "hipGraph per backward segment + RCCL all-reduce")),
                        "kernel_launches_per_step": plan.n_launches, "final_loss": round(final_loss, 5),
                        "masks": "all ones" if args.full_masks else "ragged, valid length ~ U{8..seq} (SURVEY 8d)",
+                       "batches": f"{len(batches)} distinct synthetic batches resident in HBM, loaded in turn (one device-to-device copy of "
+                                  "ids / mask / pixels / labels per step, inside the timed region)",
+                       "overflow_protection": ("none (skip_nonfinite=False)" if opt.skip_nonfinite is False else
+                                               ("all-or-nothing: global gradient norm before any update" if not step.opt_in_bwd and reducer is None else
+                                                "guarded optimizer-in-backward updates") +
+                                               (f" + dynamic loss scale on the device (GradScaler rule; scale now {step.scaler.get_scale():g} x "
+                                                f"{cfg.stream_scale:g})" if step.scaler is not None else "")),
+                       "dropout": "BERT 0.1 / 0.1, head 0.3 (reference)" if args.reference_dropout else "0 (BASELINE.md section 3)",
+                       "clip": args.clip if args.clip > 0 else None,
                        "optimizer": f"Adam lr 2e-5, dense semantics over all {model.layout.n_total / 1e6:.1f} M parameters every step (word-embedding rows "
                                     "that never received a gradient are the identity under Adam and are skipped: bit-identical)",
                        "text_rows": (f"padding-free: {live_rows} of {max_rows} token rows live on rank 0 (attention_mask != 0), "
@@ -381,14 +446,27 @@ def main():
         }
         if world == 1 and not args.force_ddp and not args.no_extras and not args.tiny and args.config == 3:
             # secondary lines, same K / W, same batch: the other 16-bit storage type (fp16 meets north_star's 1e-3 on the
-            # logits, see "parity"), SURVEY 8d's all-ones masks, and the reference's dense text rows
-            del step, opt, model, plan
+            # logits, see "parity"), SURVEY 8d's all-ones masks, the reference's dense text rows; fp16 WITHOUT overflow protection
+            # (round 2's headline mode), the Trainer / Kevin clip at 1.0 (needs the global norm: no optimizer-in-backward), the
+            # reference's dropout probabilities, ONE replayed batch (round 2's methodology); then BASELINE configs 5 and 2
+            step.close()
+            del step, opt, model, plan, batches
             torch.cuda.empty_cache()
             other = "fp16" if args.dtype == "bf16" else "bf16"
-            for key, kw in ((other, dict(dtype=other)), ("full_masks", dict(full_masks=True)),
-                            ("dense_text", dict(dense_text=True))):
+            for key, kw in ((other, dict(dtype=other)), ("full_masks", dict(full_masks=True)), ("dense_text", dict(dense_text=True)),
+                            ("fp16_unguarded", dict(unguarded=True)), ("clip1", dict(clip=1.0)),
+                            ("reference_dropout", dict(reference_dropout=True)), ("single_batch", dict(n_batches=1))):
                 v, ms = timed_variant(pkg, args, device, **kw)
                 out[f"value_{key}"], out[f"ms_per_step_{key}"] = round(v, 2), round(ms, 3)
+            v5, ms5 = timed_variant(pkg, args, device, config=5)
+            out["value_config5"], out["ms_per_step_config5"] = round(v5, 2), round(ms5, 3)
+            out["roofline_config5"] = {"bound": "mfma", "kernel": "whole step", "achieved": round(FLOP_PER_MEME[5] * v5 / 1e12, 1),
+                                       "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(FLOP_PER_MEME[5] * v5 / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                                       "traffic": None, "workload": "BASELINE configs[4]: CLIP ViT-L/14@336 (577 tokens) + BERT-large, seq 256, batch 32, "
+                                                                    "fwd+CE+bwd+Adam, 762 M parameters; per-kernel figures: bench.py --config 5"}
+            c2 = bench_config2(args)
+            out["value_config2"], out["ms_per_step_config2"], out["unit_config2"] = c2["value"], c2["ms_per_step"], c2["unit"]
+            out["roofline_config2"] = dict(c2["roofline"], workload=c2["config"]["workload"])
         if not args.no_cpu_baseline and world == 1:
             if args.config == 5:      # 1.6 TFLOP per meme: a batch of 32 would take the host cores an hour
                 out["cpu_baseline"] = cpu_baseline(1, args.seq, args.tiny, warm=1, timed=2, config=5)

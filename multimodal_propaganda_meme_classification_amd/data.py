@@ -302,7 +302,14 @@ class DeviceImagePipeline:
         for p_ in parts:
             starts.append(pos)
             pos = (pos + p_.size + 63) // 64 * 64
-        host = self._pin("arena", pos)
+        # two pinned arenas used in turn, each guarded by an event: the asynchronous copy of batch k may still be reading its arena
+        # while batch k + 1 is being packed
+        self._turn = 1 - getattr(self, "_turn", 1)
+        akey = f"arena{self._turn}"
+        prev = self._pinned.get(akey + ".event")
+        if prev is not None:
+            prev.synchronize()
+        host = self._pin(akey, pos)
         hv = host.numpy()
         for a, o in zip(arrs, offs):
             hv[o:o + a.size] = a.reshape(-1)
@@ -310,6 +317,9 @@ class DeviceImagePipeline:
             hv[st:st + p_.size] = p_.reshape(-1)
         dev = torch.empty(pos, dtype=torch.uint8, device=self.device)
         dev.copy_(host[:pos], non_blocking=True)                     # the ONE host-to-device copy of the batch
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pinned[akey + ".event"] = ev
         base = dev.data_ptr()
         ptr = lambda i: base + starts[i]
         tmp = torch.empty((B, max_h, S, 3), dtype=torch.uint8, device=self.device)

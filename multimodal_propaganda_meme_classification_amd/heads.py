@@ -178,7 +178,9 @@ class OrganizersMultimodalClassifier(_Composite):
                  seed: int = 0):
         super().__init__()
         from .resnet import ResNet50
-        tc = text or TextConfig(vocab_size=119547, hidden=768, layers=6, heads=12, intermediate=3072, max_position=512, type_vocab=0)
+        # default = distilbert-base-multilingual-cased as its checkpoint configures it (dropout 0.1, attention_dropout 0.1)
+        tc = text or TextConfig(vocab_size=119547, hidden=768, layers=6, heads=12, intermediate=3072, max_position=512, type_vocab=0,
+                                hidden_dropout=0.1, attention_dropout=0.1)
         self.bert = TextEncoder(tc, pool="last", compute_dtype=compute_dtype, seed=seed, naming="distilbert")
         self.bert_drop = nn.Dropout(0.3)
         self.bert_fc = nn.Linear(tc.hidden, 512)
@@ -280,8 +282,9 @@ class KevinMultimodalClassifier(_Composite):
         # three-input forward (:677) cannot call (TypeError on the first batch), so only the two that run are offered
         if fusion_method not in ("concatenation", "mca"):
             raise ValueError(f"Unsupported fusion method: {fusion_method}")
-        tc, ic = text or TextConfig(), image or ImageConfig()
-        cc = caption or TextConfig(vocab_size=30522)
+        # defaults = the checkpoints' own dropout (0.1 / 0.1); explicit configs say what they want
+        tc, ic = text or TextConfig(hidden_dropout=0.1, attention_dropout=0.1), image or ImageConfig()
+        cc = caption or TextConfig(vocab_size=30522, hidden_dropout=0.1, attention_dropout=0.1)
         self.fusion_method = fusion_method
         self.towers = MultimodalClassifier.from_config(ModelConfig(text=tc, image=ic, compute_dtype=compute_dtype,
                                                                    grad_stream_scale=grad_stream_scale), seed=seed)

@@ -267,7 +267,10 @@ class MultimodalClassifier(nn.Module):
     def __init__(self, num_classes: int = 2, config: Optional[ModelConfig] = None, device="cpu", seed: int = 0,
                  init: bool = True):
         super().__init__()
-        cfg = config if config is not None else ModelConfig(num_classes=num_classes)
+        # no config given = the reference's module as a user constructs it (Multimodal_example_task2C.txt:152-170): Dropout(0.3) on the
+        # text features, the BERT checkpoint's 0.1 / 0.1; an explicit ModelConfig says what it wants (the dataclass defaults are
+        # p = 0: the parity / measurement setting of BASELINE.md section 3)
+        cfg = config if config is not None else ModelConfig(num_classes=num_classes).with_reference_dropout()
         if config is None:
             cfg.num_classes = num_classes
         cfg.validate()
@@ -410,12 +413,19 @@ class MultimodalClassifier(nn.Module):
         if not getattr(plan, "dropout_on", False):
             return
         if self._rng_ring is None:
-            self._rng_ring = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(32)]
+            self._rng_ring = torch.zeros((32, 4), dtype=torch.int32).pin_memory()
+            self._rng_events = [None] * 32
         self._rng_step += 1
-        host = self._rng_ring[self._rng_step % 32]
+        slot = self._rng_step % 32
+        if self._rng_events[slot] is not None:        # the copy issued from this slot 32 steps ago must have run before it is rewritten
+            self._rng_events[slot].synchronize()
+        host = self._rng_ring[slot]
         lo, hi = self._rng_seed & 0x7FFFFFFF, (self._rng_seed >> 31) & 0x7FFFFFFF
         host.copy_(torch.tensor([lo, hi, self._rng_step & 0x7FFFFFFF, 0], dtype=torch.int32))
         plan.buf["rng"].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._rng_events[slot] = ev
 
     def _prepare(self, text, image, mask, labels=None, features=False) -> Plan:
         eng = self._get_engine()
@@ -775,7 +785,11 @@ class Adam(torch.optim.Optimizer):
 
     def _write_hyper(self):
         t = self._step
-        host = self._flat["ring"][t % 32]
+        slot = t % 32
+        evs = self._flat.setdefault("ring_events", [None] * 32)
+        if evs[slot] is not None:         # a host that runs > 32 steps ahead of the device would rewrite a slot whose copy is still pending
+            evs[slot].synchronize()
+        host = self._flat["ring"][slot]
         first = not (self._accounted and self._hyper_init)
         if first and self._accounted and t > 1:          # re-initialisation mid-run (a scaler attached, a checkpoint loaded)
             self._host_skipped = int(self._flat["skip_state"][0])
@@ -791,8 +805,11 @@ class Adam(torch.optim.Optimizer):
             else:           # bias corrections and grad_scale / loss scale were written on the device by the last step's accounting
                 self._flat["hyper"][gi][:5].copy_(host[gi][:5], non_blocking=True)
         self._hyper_init = True
-        self._flat["step_ring"][t % 32][0] = t
-        self._flat["step_dev"].copy_(self._flat["step_ring"][t % 32], non_blocking=True)
+        self._flat["step_ring"][slot][0] = t
+        self._flat["step_dev"].copy_(self._flat["step_ring"][slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        evs[slot] = ev
 
     _host_skipped = 0          # skipped steps known to the host when the device scalars are (re)initialised (load_state_dict)
 

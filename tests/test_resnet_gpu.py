@@ -324,3 +324,58 @@ def test_organizers_exact_model_distilbert_plus_resnet50(pkg):
         opt.step()
         losses.append(float(loss))
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+def test_resnet50_full_size_batch32_config2(pkg):
+    """BASELINE.json configs[1] at its real size: ResNet-50 (3, 4, 6, 3), 224 x 224, batch 32, through the Trainer-protocol module
+    and the fused Adam -- the loss falls over 3 steps, two runs from the same seed are bit-identical (deterministic kernels: no
+    atomics in col2im / BatchNorm / split-K sums), every BatchNorm running statistic is finite and has moved, and -- train-mode
+    BatchNorm normalises over the replica's own batch -- the gradient of the whole batch is NOT the sum of its two halves' gradients
+    (the reason data-parallel replicas of config 2 are per-replica BatchNorm, SURVEY 8e caveat (i))."""
+    def run(seed=0, batch=32, steps=3, half=None):
+        torch.manual_seed(seed)
+        model = pkg.ResNetClassifier(num_labels=2, compute_dtype="fp16").cuda()
+        assert sum(p.numel() for p in model.parameters()) == 25_557_032 - 2048 * 1000 - 1000 + 2048 * 2 + 2      # resnet50 with a 2-way fc
+        pkg.flatten_parameters(model)
+        model.train()
+        g = torch.Generator().manual_seed(11)
+        image = torch.randn((32, 3, 224, 224), generator=g)
+        labels = (torch.rand((32,), generator=g) < 0.5).long()
+        image = image + labels.float().view(-1, 1, 1, 1) * 0.5          # a learnable cue
+        if half is not None:
+            image, labels = image[half * 16:(half + 1) * 16], labels[half * 16:(half + 1) * 16]
+        image, labels = image.cuda(), labels.cuda()
+        opt = pkg.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss, logits = model(pixel_values=image, labels=labels)
+            loss.backward()
+            if steps == 1:
+                return model, float(loss), model._memehip_flat[1].clone()
+            opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return model, losses, model._memehip_flat[0].clone()
+
+    m1, l1, p1 = run()
+    m2, l2, p2 = run()
+    print("[ResNet-50 224x224 batch 32] losses over 3 fused-Adam steps:", [round(x, 5) for x in l1])
+    assert np.isfinite(l1).all() and l1[-1] < l1[0]
+    assert l1 == l2 and torch.equal(p1, p2)                               # run-to-run bit-identical
+    sd = m1.state_dict()
+    moved = 0
+    for k, v in sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert bool(torch.isfinite(v).all()), k
+            moved += int(not torch.equal(v, torch.zeros_like(v) if k.endswith("mean") else torch.ones_like(v)))
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 3, k
+    assert moved == 2 * 53
+    # per-replica BatchNorm: d(mean loss over 32) != (d(first 16) + d(last 16)) / 2
+    _, _, g_all = run(steps=1)
+    _, _, g_a = run(steps=1, half=0)
+    _, _, g_b = run(steps=1, half=1)
+    rel = float((g_all - 0.5 * (g_a + g_b)).norm() / g_all.norm())
+    print(f"[ResNet-50] ||grad(batch 32) - mean of the two half-batch grads|| / ||grad(batch 32)|| = {rel:.3f} (train-mode BatchNorm: not additive)")
+    assert rel > 0.05
