@@ -112,6 +112,9 @@ int mh_gemm_ksplit_for(int K, int want);
  * two groups of four waves (64x64 per wave), accumulators merged in the epilogue (both measured slower or equal: DESIGN.md 5.1).
  * Default 4 (or env MEMEHIP_GEMM_VARIANT at first launch). */
 int mh_gemm_set_variant(int variant);
+/* profiling knob: device buffer of 4 x uint64 per workgroup of the largest launch; the default kernel records 100-MHz stamps per
+ * workgroup {entry, first K stage landed, main loop done, epilogue stores issued}; NULL = off (tools/gemm_timeline.py) */
+int mh_gemm_set_trace(void* device_buffer);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (D % 8 == 0, D <= 4096 forward, <= 2048 backward), one wavefront per row.

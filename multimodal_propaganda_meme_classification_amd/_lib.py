@@ -106,6 +106,7 @@ class MhHeadGrads(C.Structure):
 # name -> argtypes; every function returns int (MhStatus) unless listed in _RESTYPES
 _PROTOS = {
     "mh_gemm_bf16_grouped": [C.POINTER(MhGemmProblem), c_int, c_int, c_int, c_void_p],
+    "mh_gemm_set_trace": [c_void_p],
     "mh_gemm_set_variant": [c_int],
     "mh_gemm_ksplit_for": [c_int, c_int],
     "mh_layernorm_fwd": [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p],

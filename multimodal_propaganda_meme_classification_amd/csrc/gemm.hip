@@ -34,8 +34,12 @@ struct GemmGroup {
     int total_tiles;
     int group_m;      // L2 blocking of the tile order: GROUP_M row panels are swept column by column (0/1: n-fastest)
     int pad_;
+    unsigned long long* trace;   // debug (mh_gemm_set_trace): per workgroup 4 x 100-MHz stamps {entry, first stage landed, main loop done, stores issued}
     DevProblem d[MH_GEMM_MAX_GROUP];
 };
+MH_DEV void trace_stamp(const GemmGroup& g, int k) {
+    if (g.trace && threadIdx.x == 0) g.trace[(size_t)blockIdx.x * 4 + k] = wall_clock64();
+}
 
 // local tile index -> (row tile, column tile).  n-fastest order makes the ~64 tiles an XCD runs at once span
 // 3-4 row panels x ALL column tiles: every K step touches the whole of B (3.5-4.7 MB at N = 2304 / 3072, K = 768),
@@ -313,6 +317,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- which tile ----------------------------------------------------------------------------
+    trace_stamp(g, 0);
     const int nwg = g.total_tiles;
     int t;
     {
@@ -450,6 +455,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
         dma_tile<LA, 16 / NW>(ra, P.lda, m0, kbeg, wave, lane, smem);
         dma_tile<LB, 16 / NW>(rb, P.ldb, n0, kbeg, wave, lane, smem + BM * BK * 2);
         __syncthreads();
+        trace_stamp(g, 1);
         for (int kt = 0; kt < nk; ++kt) {
             char* cur = smem + (kt & 1) * STAGE_BYTES;
             char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
+    trace_stamp(g, 2);
     if (KSW && (LA == 1) && (P.rowsum != nullptr) && (tn == 0)) {      // (uniform per workgroup) second K group's row sums -> LDS
         float* rs = (float*)smem;                                      // [128] (the main loop ended with a barrier)
         if (do_rowsum && kgrp == 1 && (lane & 15) == 0) {
@@ -563,6 +570,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     __syncthreads();
 
     epilogue_rows<BM, NW * 64, DROP, PREF>(P, cs, m0, n0, tid, M, &pf);
+    trace_stamp(g, 3);
 }
 
 // one 1-KiB LDS-DMA piece of a 16-KiB panel ([128 rows][64 k] or [64 k][128 rows]), swizzle on the source
@@ -1165,6 +1173,299 @@ __global__ __launch_bounds__(512, 4) void gemm_wide_kernel(const GemmGroup g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Variant 9 -- PERSISTENT workgroups, epilogue straight from the accumulator registers (K-contiguous A only: forward and dgrad).
+//
+// Same tile (128x128x64), same eight waves of 64x32, same two LDS-DMA stages and one barrier per K step as variant 4, but:
+//  * at most 512 workgroups (two per CU) are launched and each walks its XCD's run of tiles (tile j, j + slots, ...), so a
+//    multi-round launch pays the workgroup turnover -- exit, dispatch, descriptor set-up, first-stage fill -- once instead of
+//    once per tile: the first K stage of the NEXT tile is issued (LDS-DMA) before the current tile's epilogue starts;
+//  * the MFMA operands are swapped (weights in the A slot): the accumulator of a 16x16 block is D'[n][m], so lane l holds FOUR
+//    CONSECUTIVE OUTPUT COLUMNS n = 4 (l >> 4) + r of ONE output row m = l & 15.  Bias / GELU / gelu' / residual / dropout and the
+//    16-bit conversion run on those registers and go out as 8-byte stores (16-byte for f32 outputs): no f32 staging tile, no LDS
+//    round trip, no barrier in the epilogue -- which is what leaves the LDS free for the next tile's first stage.
+// Every output element is the same k-ordered MFMA dot product as in variant 4 (the operand swap transposes the block, not the
+// summation), so the results are bit-identical to it.  No communication between workgroups: nothing here depends on residency.
+// MEASURED (round 3, tools/gemm_ab.py 4 9, same process, config-3 shapes): 2-9 % SLOWER than variant 4 on the multi-round launches
+// and on the single-round ones alike -- with the epilogue all at the end of a tile (+2 us: 8-byte stores that touch 16 rows x 32 B
+// per wave-instruction instead of whole 256-B row segments) and with it spread over the next tile's first eight K steps (the
+// in-loop VALU / store work costs the K steps more than the hidden epilogue returns).  tools/gemm_timeline.py shows why turnover
+// is not the lever: the workgroups of a launch do run in lockstep rounds (fill 1.6 us, 12 K steps 10.4 us, epilogue 3.2 us), but
+// staggering the two workgroups of a CU by half a tile changes nothing either -- a workgroup's K step (0.87 us = ~1800 clocks for
+// 2 x 256 MFMA clocks per SIMD) is set by its own barrier -> LDS-DMA -> fragment-read -> MFMA chain with both the LDS array and
+// the matrix pipe near half load, not by what its partner on the CU is doing.  Kept as variant 9 for A/B; not the default.
+// one 16x16 block (i, j) of the transposed accumulator: lane l owns output row m = l & 15 and the four columns n = 4 (l >> 4) + r.
+// `res` / `mul`: the block's 16-bit epilogue operands, loaded earlier by epi_block_prefetch.
+struct EpiOps {
+    i32x2 res, mul;
+};
+MH_DEV EpiOps epi_block_prefetch(const MhGemmProblem& P, int gm, int gn, int M) {
+    EpiOps e;
+    e.res = i32x2{0, 0};
+    e.mul = i32x2{0, 0};
+    const size_t o = (size_t)min(gm, M - 1) * P.ldc + min(gn, P.N - 4);
+    if (P.residual) e.res = *(const i32x2*)((const h16*)P.residual + o);
+    if (P.mul) e.mul = *(const i32x2*)((const h16*)P.mul + o);
+    return e;
+}
+template <bool DROP>
+MH_DEV void epi_block(const MhGemmProblem& P, const f32x4& a, const EpiOps& ops, int gm, int gn, int M) {
+    const int N = P.N;
+    if (gm >= M || gn >= N) return;
+    const int flags = P.flags;
+    const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
+    float v[4];
+    {
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (P.bias) bias = *(const f32x4*)(P.bias + gn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a[e] * alpha + bias[e];
+    }
+    const size_t o = (size_t)gm * P.ldc + gn;
+    if (DROP) {
+        const DropCtx drop = mh_drop_ctx(P.drop_rng, P.drop_p, P.drop_stream);
+        if (drop.on) {
+            const uint64_t dr = P.drop_rows ? (uint64_t)P.drop_rows[gm] : (uint64_t)gm;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mh_drop_mul(drop, dr * (uint64_t)N + (uint64_t)(gn + e));
+        }
+    }
+    if ((flags & MH_GEMM_GELU) && (flags & MH_GEMM_DERIV_AUX) && P.aux) {
+        Pack4 u;
+        if (flags & MH_GEMM_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sg = qgelu_sig(v[e]);
+                u.e[e] = mh_f2bf(sg * (1.0f + 1.702f * v[e] * (1.0f - sg)));
+                v[e] *= sg;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const GeluParts gp = gelu_parts(v[e]);
+                u.e[e] = mh_f2bf(gp.cdf + v[e] * gp.pdf);
+                v[e] *= gp.cdf;
+            }
+        }
+        *(i32x2*)((h16*)P.aux + o) = u.v;
+    } else {
+        if (P.aux) {
+            Pack4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u.e[e] = mh_f2bf(v[e]);
+            *(i32x2*)((h16*)P.aux + o) = u.v;
+        }
+        if (flags & MH_GEMM_GELU) {
+            if (flags & MH_GEMM_QUICK_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = qgelu_f(v[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+            }
+        }
+    }
+    if (P.mul) {
+        Pack4 u;
+        u.v = ops.mul;
+        if (flags & MH_GEMM_DERIV_AUX) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mh_bf2f(u.e[e]);
+        } else if (flags & MH_GEMM_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= dqgelu_f(mh_bf2f(u.e[e]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(mh_bf2f(u.e[e]));
+        }
+    }
+    if (P.residual) {
+        Pack4 u;
+        u.v = ops.res;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += mh_bf2f(u.e[e]);
+    }
+    if (flags & MH_GEMM_OUT_F32) {
+        float* c = (float*)P.C + o;
+        f32x4 w = f32x4{v[0], v[1], v[2], v[3]};
+        if (flags & MH_GEMM_ACCUM) w += *(const f32x4*)c;
+        *(f32x4*)c = w;
+    } else {
+        Pack4 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u.e[e] = mh_f2bf(v[e]);
+        *(i32x2*)((h16*)P.C + o) = u.v;
+    }
+}
+
+template <int LB, bool DROP>
+__global__ __launch_bounds__(512, 4) void gemm_persist_kernel(const GemmGroup g) {
+    constexpr int NW = 8, NWN = 4, NI = 4, NJ = 2, NBLK = NI * NJ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / NWN) * (NI * 16), wn0 = (wave % NWN) * (NJ * 16);
+    const int mi = lane & 15, g4 = (lane >> 4) * 4;
+    // this workgroup's run of tiles: XCD label x = b & 7 owns a contiguous run (as in variant 4); slot j = b >> 3 of the XCD's
+    // `slots` resident workgroups takes tiles j, j + slots, ... of it, so the tiles in flight on an XCD stay neighbours
+    const int nwg = g.total_tiles;
+    const int b = blockIdx.x, x = b & 7, slots = (int)(gridDim.x >> 3);
+    const int q = nwg >> 3, r = nwg & 7;
+    const int run_start = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q);
+    const int run_len = q + (x < r ? 1 : 0);
+
+    struct Tile {
+        int pi, m0, n0, M, nk;
+        bool valid;
+    };
+    auto decode = [&](int idx) {
+        Tile T;
+        T.valid = idx < run_len;
+        T.pi = 0; T.m0 = 0; T.n0 = 0; T.M = 0; T.nk = 0;
+        if (!T.valid) return T;
+        const int t = run_start + idx;
+        int pi = 0;
+#pragma unroll
+        for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
+            if (i < g.n && t >= g.d[i].tile_start) pi = i;
+        int tm, tn;
+        tile_coords(g.d[pi], g.group_m, t - g.d[pi].tile_start, tm, tn);
+        const MhGemmProblem& P = g.d[pi].p;
+        T.pi = pi;
+        T.m0 = tm * BM;
+        T.n0 = tn * BN;
+        T.M = P.M;
+        if (P.rows_dev) T.M = min(T.M, *P.rows_dev);      // packed token rows: the live row count is only known on the device
+        T.nk = P.K / BK;
+        return T;
+    };
+    auto next_tile = [&](int& idx) {          // first tile with live rows at or after position idx of the run
+        Tile T = decode(idx);
+        while (T.valid && T.m0 >= T.M) {
+            idx += slots;
+            T = decode(idx);
+        }
+        return T;
+    };
+    auto stage0 = [&](const Tile& T) {
+        const MhGemmProblem& P = g.d[T.pi].p;
+        const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, (uint32_t)((T.M - 1) * P.lda + P.K) * 2u);
+        const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, (LB == 0) ? (uint32_t)((P.N - 1) * P.ldb + P.K) * 2u
+                                                                 : (uint32_t)((P.K - 1) * P.ldb + P.N) * 2u);
+        dma_tile<0, 16 / NW>(ra, P.lda, T.m0, 0, wave, lane, smem);
+        dma_tile<LB, 16 / NW>(rb, P.ldb, T.n0, 0, wave, lane, smem + BM * BK * 2);
+    };
+
+    int idx = b >> 3;
+    Tile cur = next_tile(idx);
+    if (!cur.valid) return;
+    stage0(cur);
+    // the PREVIOUS tile's accumulators: its epilogue is spread over the first K steps of the current tile (one 16x16 block per
+    // step, its 16-bit operands fetched a step ahead), so the stores of a round trickle out under the MFMAs of the next one instead
+    // of every workgroup bursting them at the same moment while the matrix pipes idle
+    f32x4 prev[NI][NJ];
+    Tile pt;
+    pt.valid = false;
+    pt.pi = 0; pt.m0 = 0; pt.n0 = 0; pt.M = 0; pt.nk = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    while (true) {
+        const MhGemmProblem& P = g.d[cur.pi].p;
+        const MhGemmProblem& PP = g.d[pt.pi].p;
+        const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, (uint32_t)((cur.M - 1) * P.lda + P.K) * 2u);
+        const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, (LB == 0) ? (uint32_t)((P.N - 1) * P.ldb + P.K) * 2u
+                                                                 : (uint32_t)((P.K - 1) * P.ldb + P.N) * 2u);
+        f32x4 acc[NI][NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int pgm0 = pt.m0 + wm0 + mi, pgn0 = pt.n0 + wn0 + g4;
+        EpiOps eo = EpiOps{i32x2{0, 0}, i32x2{0, 0}};
+        if (pt.valid) eo = epi_block_prefetch(PP, pgm0, pgn0, pt.M);
+        __syncthreads();          // stage 0 of this tile has landed (and every wave is done with the previous tile's LDS reads)
+        const int nk = cur.nk;
+        auto kstep = [&](int kt, auto&& between) {
+            char* st = smem + (kt & 1) * STAGE_BYTES;
+            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            if (kt + 1 < nk) {
+                dma_tile<0, 16 / NW>(ra, P.lda, cur.m0, (kt + 1) * BK, wave, lane, nxt);
+                dma_tile<LB, 16 / NW>(rb, P.ldb, cur.n0, (kt + 1) * BK, wave, lane, nxt + BM * BK * 2);
+            }
+            // the previous tile's epilogue block goes HERE, in front of the MFMAs: its stores are issued ~0.8 us before the barrier's
+            // vmcnt(0) (behind the MFMAs they would make every K step wait for a store round trip)
+            between();
+            const char* la = st;
+            const char* lb = st + BM * BK * 2;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                h16x8 fa[NI], fb[NJ];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fa[i] = read_frag<0>(la, wm0 + i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = MH_MFMA_16x16x32(fb[j], fa[i], acc[i][j], 0, 0, 0);      // weights in the A slot: D'[n][m]
+            }
+        };
+        // first NBLK K steps: one block of the previous tile's epilogue inside each step
+        int kt = 0;
+#pragma unroll
+        for (int u = 0; u < NBLK; ++u) {
+            const int i = u / NJ, j = u % NJ;
+            if (kt < nk) {
+                kstep(kt, [&]() {
+                    if (pt.valid) {
+                        epi_block<DROP>(PP, prev[i][j], eo, pgm0 + i * 16, pgn0 + j * 16, pt.M);
+                        if (u + 1 < NBLK) eo = epi_block_prefetch(PP, pgm0 + ((u + 1) / NJ) * 16, pgn0 + ((u + 1) % NJ) * 16, pt.M);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                __syncthreads();
+                ++kt;
+            } else if (pt.valid) {      // a contraction shorter than NBLK steps: the rest of the previous epilogue, unhidden
+                eo = epi_block_prefetch(PP, pgm0 + i * 16, pgn0 + j * 16, pt.M);
+                epi_block<DROP>(PP, prev[i][j], eo, pgm0 + i * 16, pgn0 + j * 16, pt.M);
+            }
+        }
+        for (; kt < nk; ++kt) {
+            kstep(kt, []() {});
+            __syncthreads();
+        }
+        // the LDS is free: start the next tile's first stage; this tile's accumulators become `prev`
+        idx += slots;
+        const Tile nxt_tile = next_tile(idx);
+        if (nxt_tile.valid) stage0(nxt_tile);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) prev[i][j] = acc[i][j];
+        pt = cur;
+        if (!nxt_tile.valid) break;
+        cur = nxt_tile;
+    }
+    // the last tile of this workgroup: nothing left to hide its epilogue behind
+    {
+        const MhGemmProblem& PP = g.d[pt.pi].p;
+        const int pgm0 = pt.m0 + wm0 + mi, pgn0 = pt.n0 + wn0 + g4;
+        EpiOps eo[NI][NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) eo[i][j] = epi_block_prefetch(PP, pgm0 + i * 16, pgn0 + j * 16, pt.M);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) epi_block<DROP>(PP, prev[i][j], eo[i][j], pgm0 + i * 16, pgn0 + j * 16, pt.M);
+    }
+}
+
+unsigned long long* g_trace = nullptr;      // mh_gemm_set_trace
 int g_variant = -1;  // -1: read MEMEHIP_GEMM_VARIANT once; 0 = register staging, 1 = LDS-DMA 4 waves, 2 = 256x128 ring,
                      // 3 = ping-pong ring, 4 = LDS-DMA 8 waves (default), 5 = LDS-DMA 16 waves
 
@@ -1301,8 +1602,35 @@ int launch_wide(const GemmGroup& g, hipStream_t s) {
     if (LB == 0 && any_drop) return launch_wide2<LB, true>(g, s);
     return launch_wide2<LB, false>(g, s);
 }
+template <int LB, bool DROP>
+int launch_persist2(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_persist_kernel<LB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    // two resident workgroups per CU (64 KiB of LDS and <= 128 VGPRs each): 512 slots, a multiple of 8 either way
+    const int grid = g.total_tiles >= 512 ? 512 : (g.total_tiles + 7) / 8 * 8;
+    hipLaunchKernelGGL((gemm_persist_kernel<LB, DROP>), dim3(grid), dim3(512), LDS_BYTES, s, g);
+    return mh_launch_status();
+}
+template <int LB>
+int launch_persist(const GemmGroup& g, hipStream_t s) {
+    bool any_drop = false;
+    for (int i = 0; i < g.n; ++i) any_drop |= (g.d[i].p.drop_rng != nullptr && g.d[i].p.drop_p > 0.f);
+    if (LB == 0 && any_drop) return launch_persist2<LB, true>(g, s);
+    return launch_persist2<LB, false>(g, s);
+}
 template <int LA, int LB>
 int launch(const GemmGroup& g, hipStream_t s) {
+    if (g_variant == 9) {          // persistent, register epilogue: K-contiguous A without split-K; everything else = variant 4
+        bool plain = (LA == 0);
+        for (int i = 0; i < g.n; ++i) plain = plain && g.d[i].kchunk == 0 && g.d[i].p.rowsum == nullptr && (g.d[i].p.N % 4) == 0;
+        if (plain) {
+            if constexpr (LA == 0) return launch_persist<LB>(g, s);
+        }
+        return launch_nw<LA, LB, 8>(g, s);
+    }
     if (g_variant == 8) return launch_ksw<LA, LB>(g, s);
     if (g_variant == 7) return launch_db<LA, LB>(g, s);
     if (g_variant == 6) return launch_s4<LA, LB>(g, s);
@@ -1322,7 +1650,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     if (g_variant < 0) {
         const char* e = getenv("MEMEHIP_GEMM_VARIANT");
         g_variant = e ? atoi(e) : 4;
-        if (g_variant < 0 || g_variant > 8) g_variant = 4;
+        if (g_variant < 0 || g_variant > 9) g_variant = 4;
     }
     const int tile_m = (g_variant == 2 || g_variant == 3) ? R_BM : BM;
     // the wide (128x256) kernel: only the default variant, only K-contiguous A, every N a multiple of 256, and only
@@ -1367,7 +1695,7 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         g.d[i].kchunk = 0;
         int splits = 1;
         if (p.ksplit > 1) {       // split-K: f32 output slabs [ksplit][M][ldc], default kernel variant only, no fused epilogue
-            if ((g_variant != 4 && g_variant != 7 && g_variant != 8) || wide || !(p.flags & MH_GEMM_OUT_F32) || (p.flags & (MH_GEMM_ACCUM | MH_GEMM_GELU)) || p.bias ||
+            if ((g_variant != 4 && g_variant != 7 && g_variant != 8 && g_variant != 9) || wide || !(p.flags & MH_GEMM_OUT_F32) || (p.flags & (MH_GEMM_ACCUM | MH_GEMM_GELU)) || p.bias ||
                 p.residual || p.aux || p.mul || p.rowsum || p.rows_dev || p.drop_rng)
                 return MH_EINVAL;
             const int kc = ((p.K + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
@@ -1385,6 +1713,8 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         if (group_m < 0 || group_m > 64) group_m = 8;
     }
     g.group_m = group_m;
+    g.pad_ = 0;
+    g.trace = g_trace;
     hipStream_t s = (hipStream_t)stream;
     if (wide) return b_kmajor ? launch_wide<1>(g, s) : launch_wide<0>(g, s);
     if (!a_kmajor && !b_kmajor) return launch<0, 0>(g, s);
@@ -1401,9 +1731,16 @@ extern "C" int mh_gemm_ksplit_for(int K, int want) {
     return 1;
 }
 
+// profiling knob: with a device buffer of 4 x 8 bytes per workgroup of the largest launch, the default kernel (variant 4) records
+// 100-MHz stamps per workgroup {entry, first K stage landed, main loop done, epilogue stores issued}; NULL switches it off
+extern "C" int mh_gemm_set_trace(void* device_buffer) {
+    g_trace = (unsigned long long*)device_buffer;
+    return MH_OK;
+}
+
 // experiment knob (A/B in one process): 0 = register-staged tiles, 1 = LDS-DMA staged tiles
 extern "C" int mh_gemm_set_variant(int v) {
-    if (v < 0 || v > 8) return MH_EINVAL;
+    if (v < 0 || v > 9) return MH_EINVAL;
     g_variant = v;
     return MH_OK;
 }

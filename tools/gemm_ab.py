@@ -6,7 +6,7 @@ from multimodal_propaganda_meme_classification_amd import ops, _lib
 
 dev = torch.device("cuda")
 BF16 = torch.bfloat16
-Tt, Ti, D, I = 4096, 6304, 768, 3072
+Tt, Ti, D, I = int(os.environ.get("TT", "4096")), 6304, 768, 3072
 
 
 def rnd(*s):
@@ -42,30 +42,35 @@ def wgrad_group():
 cases = {"fwd qkv": fwd_group(3 * D, D), "fwd out": fwd_group(D, D), "fwd ffn1": fwd_group(I, D), "fwd ffn2": fwd_group(D, I),
          "dgrad ffn2": dgrad_group(D, I), "dgrad ffn1": dgrad_group(I, D), "dgrad out": dgrad_group(D, D), "dgrad qkv": dgrad_group(3 * D, D),
          "wgrad layer": wgrad_group()}
-if __name__ != "__main__":
-    raise SystemExit
-variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
-lib = _lib.load()
-res = {}
-for rnd_i in range(5):
+
+
+def run():
+    variants = [int(v) for v in (sys.argv[1:] or ["0", "1"])]
+    lib = _lib.load()
+    res = {}
+    for rnd_i in range(5):
+        for name, (ps, ak, bk, fl) in cases.items():
+            for v in variants:
+                lib.mh_gemm_set_variant(v)
+                for _ in range(2):
+                    ops.gemm_grouped(ps, ak, bk)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    ops.gemm_grouped(ps, ak, bk)
+                e1.record()
+                torch.cuda.synchronize()
+                res.setdefault((name, v), []).append(e0.elapsed_time(e1) / 10)
+    tot = {v: 0.0 for v in variants}
     for name, (ps, ak, bk, fl) in cases.items():
+        line = f"{name:12s}"
         for v in variants:
-            lib.mh_gemm_set_variant(v)
-            for _ in range(2):
-                ops.gemm_grouped(ps, ak, bk)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                ops.gemm_grouped(ps, ak, bk)
-            e1.record()
-            torch.cuda.synchronize()
-            res.setdefault((name, v), []).append(e0.elapsed_time(e1) / 10)
-tot = {v: 0.0 for v in variants}
-for name, (ps, ak, bk, fl) in cases.items():
-    line = f"{name:12s}"
-    for v in variants:
-        ms = sorted(res[(name, v)])[len(res[(name, v)]) // 2]
-        tot[v] += ms * (1 if name.startswith("wgrad") else 1)
-        line += f"  v{v}: {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF"
-    print(line)
-print("sum per layer (ms):", {v: round(t, 3) for v, t in tot.items()}, " x12 layers =", {v: round(12 * t, 2) for v, t in tot.items()})
+            ms = sorted(res[(name, v)])[len(res[(name, v)]) // 2]
+            tot[v] += ms * (1 if name.startswith("wgrad") else 1)
+            line += f"  v{v}: {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF"
+        print(line)
+    print("sum per layer (ms):", {v: round(t, 3) for v, t in tot.items()}, " x12 layers =", {v: round(12 * t, 2) for v, t in tot.items()})
+
+
+if __name__ == "__main__":
+    run()
