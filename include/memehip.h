@@ -262,10 +262,14 @@ int mh_image_normalize_u8(const uint8_t* src, float* dst, int B, int H, int W, c
  *     xbounds / ybounds int32 [B][OW|OH][2]; xcoef / ycoef int32 [B][OW|OH][KX|KY]; tmp uint8 [B][max_h][OW][3];
  *     out uint8 [B][OH][OW][3].
  * mh_image_jitter_rotate_u8: ColorJitter (brightness / contrast / saturation / hue factors, per-image op order packed 2 bits
- *   per step: 0 brightness, 1 contrast, 2 saturation, 3 hue) with PIL's ImageEnhance arithmetic on uint8, then
- *   RandomRotation (nearest, about the centre, fill 0).  params: device array of {f32 brightness, contrast, saturation, hue,
- *   angle_rad; i32 order; 2 x i32 pad} per image; lsum: device u64 [B] workspace (L-image sums for the contrast mean).
- *   (Multimodal_example_task2C.py:222-235.)  The random factors are drawn on the host. */
+ *   per step: 0 brightness, 1 contrast, 2 saturation, 3 hue) with PIL's arithmetic on uint8 -- ImageEnhance = ImagingBlend in
+ *   float32 (product and sum rounded separately), the hue op = Pillow's 8-bit RGB -> HSV -> RGB round trip with the H band shifted
+ *   modulo 256 (torchvision adjust_hue on a PIL image) -- then RandomRotation = Image.rotate(angle, NEAREST, expand=False, fill 0)
+ *   walked in 16.16 fixed point as libImaging's affine_fixed does.  Bit-exact against PIL (tests).  params: device array of 16
+ *   32-bit words per image {f32 brightness, contrast, saturation; i32 hue (0 = no hue op, else 0x100 | uint8(hue_factor * 255));
+ *   i32 order; i32 rotate (0 = angle 0); i32 a[6] (the fixed-point inverse map, data.pil_rotate_fixed_coeffs); 4 x pad};
+ *   lsum: device u64 [B] workspace (L-image sums for the contrast mean).  (Multimodal_example_task2C.py:222-235.)  The random
+ *   factors are drawn on the host. */
 int mh_image_resample_u8(const uint8_t* arena, const int64_t* src_off, const int32_t* hw, const int32_t* xbounds,
                          const int32_t* xcoef, int KX, const int32_t* ybounds, const int32_t* ycoef, int KY, const uint8_t* flip,
                          uint8_t* tmp, uint8_t* out, int B, int max_h, int OH, int OW, mh_stream_t stream);

@@ -68,7 +68,13 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const uint8_t* __restri
 MH_DEV int luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
 // PIL Image.blend(im1, im2, alpha) on one band: truncating cast inside [0, 1], clipped outside
 MH_DEV int blend8(int a, int b, float alpha) {
-    const float t = (float)a + alpha * (float)(b - a);
+    // ImagingBlend: float temp = in1 + alpha * (in2 - in1): a product rounded to float, then a sum rounded to float.  The build's
+    // -ffp-contract=fast lets the BACKEND fuse the two into one FMA (one rounding; neither HIP's __fmul_rn / __fadd_rn nor
+    // `#pragma clang fp contract(off)` stop that), which is off by one grey level on ~1 % of the pixels at factors like 1.1: the
+    // product goes through an empty asm statement, which the fusion cannot see through.
+    float prod = alpha * (float)(b - a);
+    asm volatile("" : "+v"(prod));
+    const float t = (float)a + prod;
     if (alpha >= 0.f && alpha <= 1.f) return (int)t;
     return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
 }
@@ -92,40 +98,55 @@ __global__ __launch_bounds__(256) void luma_sum_kernel(const uint8_t* __restrict
 // PIL takes the contrast op's grey level from the mean of the L image AS IT ENTERS that op, so the work runs in two phases:
 // phase 0 applies the ops in front of contrast, mh_image_luma_sum_u8 reduces the result, phase 1 applies contrast, the ops
 // behind it and the rotation (inverse mapping: output pixel -> source pixel; the colour ops are pointwise).
-struct JitterParams { float brightness, contrast, saturation, hue, angle; int order; int pad0_, pad1_; };
+struct JitterParams {
+    float brightness, contrast, saturation;
+    int hue_shift;        // 0 = no hue op; else 0x100 | uint8(hue_factor * 255), what torchvision adds to the H band with wrap-around
+    int order;            // permutation of the four ops, 2 bits each
+    int rotate;           // 0: angle == 0 (PIL returns a copy)
+    int a[6];             // Image.rotate's inverse affine map in 16.16 fixed point (libImaging/Geometry.c affine_fixed)
+    int pad_[4];
+};
 
-MH_DEV void apply_hue(int& r, int& g, int& b, float hue) {
-    // float HSV round trip (PIL uses an integer HSV image: same formula, 8-bit hue quantisation reproduced)
-    const float rf = r / 255.f, gf = g / 255.f, bf = b / 255.f;
-    const float mx = fmaxf(rf, fmaxf(gf, bf)), mn = fminf(rf, fminf(gf, bf));
-    const float d = mx - mn;
-    float hq = 0.f;
-    if (d > 0.f) {
-        if (mx == rf) hq = fmodf((gf - bf) / d, 6.f);
-        else if (mx == gf) hq = (bf - rf) / d + 2.f;
-        else hq = (rf - gf) / d + 4.f;
-        hq /= 6.f;
-        if (hq < 0.f) hq += 1.f;
+// adjust_hue on one pixel exactly as torchvision does it on a PIL image: RGB -> HSV (Pillow Convert.c rgb2hsv_row: 8-bit H, S, V),
+// H += shift (mod 256), HSV -> RGB (Convert.c hsv2rgb).  float where the C code has float, double where it has double; checked
+// against PIL over all 2^24 colours (tests/test_host_cpu.py pins the same arithmetic written in numpy, the GPU test the kernel).
+MH_DEV void apply_hue(int& r, int& g, int& b, int shift) {
+    const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+    int uh = 0, us = 0;
+    const int uv = maxc;
+    if (minc != maxc) {
+        const float cr = (float)(maxc - minc);
+        const float s = __fdiv_rn(cr, (float)maxc);
+        const float rc = __fdiv_rn((float)(maxc - r), cr), gc = __fdiv_rn((float)(maxc - g), cr), bc = __fdiv_rn((float)(maxc - b), cr);
+        float h;
+        if (r == maxc) h = __fsub_rn(bc, gc);
+        else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+        else h = (float)(4.0 + (double)gc - (double)rc);
+        h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+        uh = min(max((int)((double)h * 255.0), 0), 255);
+        us = min(max((int)((double)s * 255.0), 0), 255);
     }
-    const float s = mx > 0.f ? d / mx : 0.f;
-    int h8 = (int)(hq * 255.f) + (int)(hue * 255.f);        // uint8 wrap-around of the H band
-    h8 = ((h8 % 256) + 256) % 256;
-    const float hh = h8 / 255.f * 6.f;
-    const int i = (int)floorf(hh) % 6;
-    const float f = hh - floorf(hh);
-    const float p = mx * (1.f - s), q = mx * (1.f - s * f), t = mx * (1.f - s * (1.f - f));
-    float ro, go, bo;
-    switch (i) {
-        case 0: ro = mx; go = t; bo = p; break;
-        case 1: ro = q; go = mx; bo = p; break;
-        case 2: ro = p; go = mx; bo = t; break;
-        case 3: ro = p; go = q; bo = mx; break;
-        case 4: ro = t; go = p; bo = mx; break;
-        default: ro = mx; go = p; bo = q; break;
+    uh = (uh + shift) & 0xFF;
+    if (us == 0) {
+        r = g = b = uv;
+        return;
     }
-    r = (int)(ro * 255.f + 0.5f);
-    g = (int)(go * 255.f + 0.5f);
-    b = (int)(bo * 255.f + 0.5f);
+    const double hf = (double)(float)uh * 6.0 / 255.0;
+    const int i = (int)floor(hf);
+    const float f = (float)(hf - (double)(float)i);
+    const float fs = (float)((double)(float)us / 255.0);
+    const double vf = (double)(float)uv;
+    const int p = min(max((int)round(vf * (1.0 - (double)fs)), 0), 255);
+    const int q = min(max((int)round(vf * (1.0 - (double)fs * (double)f)), 0), 255);
+    const int t = min(max((int)round(vf * (1.0 - (double)fs * (1.0 - (double)f))), 0), 255);
+    switch (i % 6) {
+        case 0: r = uv; g = t; b = p; break;
+        case 1: r = q; g = uv; b = p; break;
+        case 2: r = p; g = uv; b = t; break;
+        case 3: r = p; g = q; b = uv; break;
+        case 4: r = t; g = p; b = uv; break;
+        default: r = uv; g = p; b = q; break;
+    }
 }
 
 __global__ __launch_bounds__(256) void jitter_rotate_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
@@ -141,12 +162,12 @@ __global__ __launch_bounds__(256) void jitter_rotate_kernel(const uint8_t* __res
         if (((P.order >> (2 * st)) & 3) == 1) cpos = st;
     int xs = xo, ys = yo;
     uint8_t* o = out + (((size_t)b * H + yo) * W + xo) * 3;
-    if (phase == 1) {   // inverse rotation about the image centre (torchvision F.rotate: nearest, expand = False, fill 0)
-        const float cx = (W - 1) * 0.5f, cy = (H - 1) * 0.5f;
-        const float ca = cosf(P.angle), sa = sinf(P.angle);
-        const float dx = xo - cx, dy = yo - cy;
-        xs = (int)floorf(ca * dx - sa * dy + cx + 0.5f);
-        ys = (int)floorf(sa * dx + ca * dy + cy + 0.5f);
+    if (phase == 1 && P.rotate) {   // torchvision F.rotate on a PIL image = Image.rotate(angle, NEAREST, expand=False, fillcolor=0):
+        // the inverse map in 16.16 fixed point, accumulated along x and y by integer adds (closed form here), truncated by >> 16
+        const long long xx = (long long)P.a[2] + (long long)yo * P.a[1] + (long long)xo * P.a[0];
+        const long long yy = (long long)P.a[5] + (long long)yo * P.a[4] + (long long)xo * P.a[3];
+        xs = (int)(xx >> 16);
+        ys = (int)(yy >> 16);
         if (xs < 0 || xs >= W || ys < 0 || ys >= H) {
             o[0] = o[1] = o[2] = 0;
             return;
@@ -165,8 +186,8 @@ __global__ __launch_bounds__(256) void jitter_rotate_kernel(const uint8_t* __res
         } else if (op == 2) {       // saturation: blend(grey image, img, f)
             const int l = luma(r, g, bl);
             r = blend8(l, r, P.saturation); g = blend8(l, g, P.saturation); bl = blend8(l, bl, P.saturation);
-        } else if (P.hue != 0.f) {  // hue
-            apply_hue(r, g, bl, P.hue);
+        } else if (P.hue_shift != 0) {  // hue op configured: bit 8 set, low byte = the shift (a shift of 0 still makes PIL's HSV round trip)
+            apply_hue(r, g, bl, P.hue_shift & 0xFF);
         }
     }
     o[0] = (uint8_t)r;

@@ -224,6 +224,56 @@ def resample_u8_reference(img: np.ndarray, bx, cx, by, cy) -> np.ndarray:
     return out
 
 
+def pil_rotate_fixed_coeffs(angle_deg: float, w: int, h: int):
+    """``Image.rotate(angle, NEAREST, expand=False)`` (what torchvision's F.rotate calls on a PIL image) as the six 16.16 fixed-point
+    coefficients libImaging/Geometry.c's affine_fixed walks: source x = (a2 + y a1 + x a0) >> 16, source y = (a5 + y a4 + x a3) >> 16.
+    Restated from PIL/Image.py rotate() + Geometry.c; pinned against PIL by tests/test_host_cpu.py.  None: angle % 360 == 0 (a copy)."""
+    import math
+    angle = angle_deg % 360.0
+    if angle == 0.0:
+        return None
+    a = -math.radians(angle)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    cx, cy = w / 2.0, h / 2.0
+    m[2] = m[0] * (-cx) + m[1] * (-cy) + m[2] + cx
+    m[5] = m[3] * (-cx) + m[4] * (-cy) + m[5] + cy
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+    return [fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]), fix(m[5] + m[3] * 0.5 + m[4] * 0.5)]
+
+
+def hue_shift_u8_reference(rgb: np.ndarray, hue_factor: float) -> np.ndarray:
+    """numpy statement of what the jitter kernel's hue op computes = torchvision adjust_hue on a PIL image: Pillow's 8-bit RGB -> HSV
+    (Convert.c rgb2hsv_row), H += uint8(hue_factor * 255) with wrap-around, HSV -> RGB (hsv2rgb).  Tests only."""
+    r, g, b = (rgb[..., k].astype(np.int32) for k in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(np.float32)
+    safe = np.where(cr == 0, np.float32(1), cr)
+    s = cr / np.where(maxc == 0, 1, maxc).astype(np.float32)
+    rc, gc, bc = ((maxc - c).astype(np.float32) / safe for c in (r, g, b))
+    h = np.where(r == maxc, (bc - gc).astype(np.float32),
+                 np.where(g == maxc, (2.0 + rc.astype(np.float64) - bc.astype(np.float64)).astype(np.float32),
+                          (4.0 + gc.astype(np.float64) - rc.astype(np.float64)).astype(np.float32)))
+    h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+    uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    us = np.clip((s.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    grey = minc == maxc
+    uh, us = np.where(grey, 0, uh), np.where(grey, 0, us)
+    uh = (uh + (int(hue_factor * 255) & 0xFF)) & 0xFF
+    hf = uh.astype(np.float32).astype(np.float64) * 6.0 / 255.0
+    i = np.floor(hf).astype(np.int32)
+    f = (hf - i.astype(np.float32).astype(np.float64)).astype(np.float32).astype(np.float64)
+    fs = (us.astype(np.float32).astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)
+    vf = maxc.astype(np.float64)
+    rnd = lambda x: np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5))          # C round(): halves away from zero
+    p = np.clip(rnd(vf * (1.0 - fs)), 0, 255).astype(np.int32)
+    q = np.clip(rnd(vf * (1.0 - fs * f)), 0, 255).astype(np.int32)
+    t = np.clip(rnd(vf * (1.0 - fs * (1.0 - f))), 0, 255).astype(np.int32)
+    m = i % 6
+    v = maxc
+    out = np.stack([np.choose(m, [v, q, p, p, t, v]), np.choose(m, [t, v, v, q, p, p]), np.choose(m, [p, p, t, v, v, q])], -1)
+    return np.where((us == 0)[..., None], np.stack([v, v, v], -1), out).astype(np.uint8)
+
+
 class DeviceImagePipeline:
     """The reference's image transforms on the device.  ``__call__(images)`` takes the batch's decoded images (uint8
     [h, w, 3] arrays or PIL images, any sizes), packs them into one pinned host arena, issues ONE asynchronous H2D copy and
@@ -260,7 +310,10 @@ class DeviceImagePipeline:
         left, top, _, _ = center_crop_box(nw, nh, S)
         return pil_resample_coeffs(w, nw, left, S), pil_resample_coeffs(h, nh, top, S)
 
-    def __call__(self, images) -> torch.Tensor:
+    def __call__(self, images, params: Optional[dict] = None) -> torch.Tensor:
+        """``params`` (tests / reproducing a given draw): dict(flip=[B] bool, factors=[B, 4] (brightness, contrast, saturation, hue),
+        order=[B][4] permutation of 0..3 (0 brightness, 1 contrast, 2 saturation, 3 hue), angle=[B] degrees) used instead of the
+        generator's draws."""
         from . import _lib, ops
         if self.device.type != "cuda":
             raise _lib.MemehipError("DeviceImagePipeline runs on the HIP device only (no CPU fallback)")
@@ -281,22 +334,33 @@ class DeviceImagePipeline:
             xb[b], yb[b] = bx, by
             xc[b, :, :cx.shape[1]], yc[b, :, :cy.shape[1]] = cx, cy
         flips = np.zeros(B, np.uint8)
-        jit = np.zeros((B, 8), np.float32)
+        jit = np.zeros((B, 16), np.int32)          # JitterParams of csrc/imagepipe.hip: 16 words per image
         if self.augment:
-            g = self.gen
-            flips = (torch.rand(B, generator=g) < 0.5).to(torch.uint8).numpy()
             jb, jc, js, jh = self.jitter
-            u = torch.rand((B, 5), generator=g).numpy()
-            jit[:, 0] = 1 - jb + 2 * jb * u[:, 0]
-            jit[:, 1] = 1 - jc + 2 * jc * u[:, 1]
-            jit[:, 2] = 1 - js + 2 * js * u[:, 2]
-            jit[:, 3] = -jh + 2 * jh * u[:, 3]
-            jit[:, 4] = np.deg2rad(-self.degrees + 2 * self.degrees * u[:, 4])
-            order = np.zeros(B, np.int32)
+            if params is not None:
+                flips = np.asarray(params["flip"], dtype=np.uint8)
+                fac = np.asarray(params["factors"], dtype=np.float64)
+                orders = [list(o) for o in params["order"]]
+                angles = [float(a) for a in params["angle"]]
+            else:
+                g = self.gen
+                flips = (torch.rand(B, generator=g) < 0.5).to(torch.uint8).numpy()
+                u = torch.rand((B, 5), generator=g).numpy().astype(np.float64)
+                fac = np.stack([1 - jb + 2 * jb * u[:, 0], 1 - jc + 2 * jc * u[:, 1], 1 - js + 2 * js * u[:, 2], -jh + 2 * jh * u[:, 3]], 1)
+                angles = list(-self.degrees + 2 * self.degrees * u[:, 4])
+                orders = [torch.randperm(4, generator=g).tolist() for _ in range(B)]
+            jf = jit.view(np.float32)
             for b in range(B):
-                perm = torch.randperm(4, generator=g).tolist()
-                order[b] = sum(int(op) << (2 * st) for st, op in enumerate(perm))
-            jit.view(np.int32)[:, 5] = order
+                jf[b, 0], jf[b, 1], jf[b, 2] = fac[b, 0], fac[b, 1], fac[b, 2]
+                # torchvision skips an op whose range is 0 (ColorJitter(hue=0) -> hue=None); a configured hue op makes PIL's HSV round
+                # trip even when the drawn shift is 0
+                jit[b, 3] = (0x100 | (int(fac[b, 3] * 255) & 0xFF)) if jh > 0 else 0
+                jit[b, 4] = sum(int(op) << (2 * st) for st, op in enumerate(orders[b]))
+                co = pil_rotate_fixed_coeffs(angles[b], S, S)
+                jit[b, 5] = 0 if co is None else 1
+                if co is not None:
+                    jit[b, 6:12] = co
+            self.last_params = dict(flip=flips.copy(), factors=fac.copy(), order=orders, angle=list(angles))
         parts = meta + [x.view(np.uint8).reshape(-1) for x in (xb, xc, yb, yc)] + [flips, jit.view(np.uint8).reshape(-1)]
         starts, pos = [], (total + 63) // 64 * 64
         for p_ in parts:

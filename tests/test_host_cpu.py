@@ -263,3 +263,37 @@ def test_kevin_dataset_keys_and_collate_on_the_host():
     batch = kv.kevin_collate([ds[0], ds[2]])
     assert batch["text"].shape == (2, 12) and batch["label"].tolist() == [0, 0] and batch["id"] == ["a", "c"]
     assert isinstance(batch["image"], list) and len(batch["image"]) == 2
+
+
+def test_hue_and_rotation_restatements_are_bit_exact_against_pil():
+    """The two augmentations round 2 left pinned to nothing: torchvision's adjust_hue on a PIL image (Pillow's 8-bit HSV round trip
+    with a wrapped H shift) and F.rotate = Image.rotate(angle, NEAREST, expand=False, fillcolor=0) (16.16 fixed-point affine walk).
+    data.hue_shift_u8_reference is the numpy statement of the kernel's hue arithmetic, data.pil_rotate_fixed_coeffs what the host
+    hands the rotation kernel; both must reproduce PIL bit for bit (the GPU test then pins the kernels to the same PIL calls)."""
+    from PIL import Image
+    from oracle import ref_env as E
+    from multimodal_propaganda_meme_classification_amd.data import hue_shift_u8_reference, pil_rotate_fixed_coeffs
+    rng = np.random.default_rng(4)
+    # a 1024 x 1024 image: random colours + every grey + saturated primaries
+    rgb = rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    rgb[0, :256] = np.arange(256, dtype=np.uint8)[:, None]
+    rgb[1, :6] = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255]], dtype=np.uint8)
+    img = Image.fromarray(rgb)
+    for hf in (0.0, 0.0713, -0.0831, 0.1, -0.1, 0.5, -0.5, 0.0039):
+        assert np.array_equal(hue_shift_u8_reference(rgb, hf), np.asarray(E.adjust_hue_pil(img, hf))), hf
+
+    def rotate(a, co):
+        h, w = a.shape[:2]
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.int64)
+        xin, yin = (co[2] + ys * co[1] + xs * co[0]) >> 16, (co[5] + ys * co[4] + xs * co[3]) >> 16
+        ok = (xin >= 0) & (xin < w) & (yin >= 0) & (yin < h)
+        out = np.zeros_like(a)
+        out[ok] = a[yin[ok], xin[ok]]
+        return out
+
+    for (h, w) in ((224, 224), (64, 96), (97, 131)):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        im = Image.fromarray(a)
+        for ang in (3.7, -14.99, 11.25, 0.31, -7.0, 15.0, -15.0, 45.0, 123.4):
+            assert np.array_equal(rotate(a, pil_rotate_fixed_coeffs(ang, w, h)), np.asarray(E.rotate_pil(im, ang))), (h, w, ang)
+    assert pil_rotate_fixed_coeffs(0.0, 10, 10) is None and pil_rotate_fixed_coeffs(360.0, 10, 10) is None
