@@ -60,12 +60,13 @@ def parse():
     ap.add_argument("--no-overlap-opt", action="store_true", help="A/B: whole Adam update after the backward")
     ap.add_argument("--force-ddp", action="store_true",
                     help="debug: run the data-parallel code path (segmented graphs, RCCL all-reduce) on a 1-rank group")
-    ap.add_argument("--ddp-mode", choices=("stream", "segments"), default=None,
+    ap.add_argument("--ddp-mode", choices=("stream", "segments", "graph"), default=None,
                     help="data-parallel schedule (default: MEMEHIP_DDP_MODE or 'segments'): one hipGraph per backward segment, or forward "
                          "graph + stream-ordered eager backward with the all-reduces behind a fence stream")
-    ap.add_argument("--ddp-compress", choices=("none", "bf16"), default="none",
-                    help="N > 1: wire format of the gradient exchange: fp32 all-reduce (default) or bf16 with fp32 accumulation on "
-                         "receipt (all-to-all + all-gather, half the bytes)")
+    ap.add_argument("--ddp-compress", choices=("auto", "none", "bf16"), default="auto",
+                    help="wire format of the gradient exchange: fp32 all-reduce, or bf16 with fp32 accumulation on receipt (all-to-all + "
+                         "all-gather, half the bytes).  auto = bf16 when more than one rank exchanges gradients (xGMI's per-link rate is what "
+                         "a ring is bound by), fp32 on a 1-rank group (nothing crosses a link, the casts would only cost)")
     ap.add_argument("--dense-text", action="store_true",
                     help="A/B: compute every padded text position like the reference does (default: padding-free text tower)")
     ap.add_argument("--full-masks", action="store_true", help="all-ones attention masks (SURVEY 8d's second input variant)")
@@ -323,7 +324,8 @@ def main():
     if world > 1 or args.force_ddp:
         ddp.broadcast_parameters(model.flat_params)
         model.mark_weights_changed()
-        reducer = ddp.GradientReducer(model.flat_grads, compress=None if args.ddp_compress == "none" else args.ddp_compress)
+        compress = ("bf16" if world > 1 else None) if args.ddp_compress == "auto" else (None if args.ddp_compress == "none" else args.ddp_compress)
+        reducer = ddp.GradientReducer(model.flat_grads, compress=compress)
     opt = pkg.Adam(model.parameters(), lr=2e-5, model=model, **opt_kwargs(args))
     step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer,
                            overlap_wgrad=not args.no_overlap_wgrad, overlap_optimizer=not args.no_overlap_opt, ddp_mode=args.ddp_mode)
@@ -409,7 +411,9 @@ def main():
                        "image": f"3x{cfg.image.image_size}x{cfg.image.image_size}",
                        "params": model.layout.n_total, "parallelism": f"dp{world}",
                        "launch": "eager" if args.no_graph else ("hipGraph" if reducer is None else
-                                                                ("forward hipGraph + stream-ordered backward launches, RCCL all-reduce per completed gradient slice"
+                                                                ("ONE hipGraph for the whole step, the RCCL all-reduce of every completed gradient slice captured in it"
+                                                                 if step.ddp_graph else
+                                                                 "forward hipGraph + stream-ordered backward launches, RCCL all-reduce per completed gradient slice"
                                                                  if step.ddp_stream else "hipGraph per backward segment + RCCL all-reduce")),
                        "kernel_launches_per_step": plan.n_launches, "final_loss": round(final_loss, 5),
                        "masks": "all ones" if args.full_masks else "ragged, valid length ~ U{8..seq} (SURVEY 8d)",

@@ -1169,9 +1169,13 @@ class GraphedStep:
             optimizer.grad_scale = reducer.grad_scale
         self.graphs = None
         ddp_mode = ddp_mode or os.environ.get("MEMEHIP_DDP_MODE", "segments")
-        if ddp_mode not in ("stream", "segments"):
-            raise ValueError(f"ddp_mode must be 'stream' or 'segments', got {ddp_mode!r}")
-        self.ddp_stream = reducer is not None and ddp_mode == "stream"
+        if ddp_mode not in ("stream", "segments", "graph"):
+            raise ValueError(f"ddp_mode must be 'stream', 'segments' or 'graph', got {ddp_mode!r}")
+        # "graph": the "stream" schedule -- two-stream backward, every completed gradient slice all-reduced behind a fence stream, its
+        # Adam slice behind the all-reduce -- captured WHOLE, collectives included, into ONE hipGraph (RCCL's launches are capturable;
+        # torch's process group records them as nodes on its own stream, forked from and joined to the capture stream by events)
+        self.ddp_graph = reducer is not None and ddp_mode == "graph"
+        self.ddp_stream = reducer is not None and ddp_mode in ("stream", "graph")
         # weight-gradient GEMMs run on a second stream beside the LayerNorm / attention / dgrad chain
         # (a high-priority side stream was measured: 16.1 vs 9.79 ms for config 3, 92.0 vs 81.2 ms for config 5 -- as with the
         #  high-priority main stream of round 1, any non-default stream priority inside the graph loses badly on this stack)
@@ -1403,6 +1407,11 @@ class GraphedStep:
         else:
             if self.graphs is None:
                 self._capture()
+            if self.ddp_graph:        # everything, the collectives included, is one graph
+                self.graphs[0][0].replay()
+                self.reducer.reduced_elems += self._per_replay[0]
+                self.reducer.wire_bytes += self._per_replay[1]
+                return self.plan.buf["loss"], self.plan.buf["ncorrect"]
             if self.ddp_stream:       # forward graph, then the backward + optimizer as stream-ordered eager launches
                 self.graphs[0][0].replay()
                 stream = torch.cuda.current_stream().cuda_stream
@@ -1461,7 +1470,21 @@ class GraphedStep:
         #  rows the warm-up wrote)
         pieces = self._pieces()
         graphs = []
-        if self.ddp_stream:
+        if self.ddp_graph:
+            e0, w0 = self.reducer.reduced_elems, self.reducer.wire_bytes
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (the process group's watchdog thread queries events)
+                stream = torch.cuda.current_stream().cuda_stream
+                for name, fn, rng in pieces:
+                    if name == "opt":
+                        self.reducer.wait()
+                    fn(stream)
+                if self.ddp_side is not None:
+                    torch.cuda.current_stream().wait_stream(self.ddp_side)
+            graphs.append((g, "step", None))
+            self._per_replay = (self.reducer.reduced_elems - e0, self.reducer.wire_bytes - w0)      # the host-side counters of one step
+            self.reducer.reduced_elems, self.reducer.wire_bytes = e0, w0
+        elif self.ddp_stream:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 pieces[0][1](torch.cuda.current_stream().cuda_stream)

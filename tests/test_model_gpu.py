@@ -273,7 +273,7 @@ def rccl_world1():
 
 
 @pytest.mark.parametrize("clip", [1.0, None])
-@pytest.mark.parametrize("ddp_mode", ["stream", "segments"])
+@pytest.mark.parametrize("ddp_mode", ["stream", "segments", "graph"])
 def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode, rccl_world1):
     """The N > 1 code path on a 1-rank RCCL group, both schedules -- "stream": forward graph + eagerly launched two-stream
     backward with the all-reduce of every completed gradient slice behind a fence stream; "segments": one hipGraph per
@@ -305,7 +305,9 @@ def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode, rccl_world1):
         assert float(l1) == float(l2)
         assert torch.equal(m1.flat_params, m2.flat_params)
     assert red.reduced_elems == 3 * end
-    if ddp_mode == "stream":
+    if ddp_mode == "graph":
+        assert len(g2.graphs) == 1 and g2.graphs[0][1] == "step"       # the whole step incl. the RCCL launches is ONE graph
+    elif ddp_mode == "stream":
         assert len(g2.graphs) == 1       # the forward; the backward is stream-ordered eager launches
     else:
         assert 4 <= len(g2.graphs) <= len(g2.plan.bwd) + 3   # fwd, opt, gather marker + segments (paired)
