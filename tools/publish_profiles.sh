@@ -1,0 +1,14 @@
+#!/bin/bash
+# Turn one tools/collect_profiles.sh collection (gpurun_out/<tag>/) into the tracked summaries profiles/<prefix>_*.
+#   usage: tools/publish_profiles.sh <tag> <prefix>      e.g.  tools/publish_profiles.sh r3s r03
+set -e
+T=gpurun_out/$1
+P=profiles/$2
+cp $T/stats/run/*/*_kernel_stats.csv ${P}_bench_steps5_kernel_stats.csv
+cp $T/stats_seq/run/*/*_kernel_stats.csv ${P}_bench_steps5_sequential_kernel_stats.csv
+python tools/pmc_to_summary_csv.py $T/fetch/run FETCH_SIZE ${P}_pmc_fetch_size_summary.csv
+python tools/pmc_to_summary_csv.py $T/write/run WRITE_SIZE ${P}_pmc_write_size_summary.csv
+python tools/traffic_from_pmc.py $T/fetch/run $T/write/run ${P}_traffic.json
+python tools/sq_summary.py $T/sq/run ${P}_sq_counters_summary.csv
+tail -1 $T/bench_default.log > ${P}_bench_line.json
+ls -la ${P}_*
