@@ -264,12 +264,12 @@ def bench_config2(args):
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"Subtask-2B fine-tune step: torchvision-topology ResNet-50 (25.6 M parameters), 3x224x224, batch {args.batch}, "
-                                  "fwd+CE+bwd+Adam, train-mode BatchNorm, random-init weights; convolutions = MFMA GEMM over explicit NHWC im2col; "
+                                  "fwd+CE+bwd+Adam, train-mode BatchNorm, random-init weights; convolutions = implicit MFMA GEMM on NHWC (no im2col panel), BatchNorm statistics from the conv epilogue; "
                                   f"{nb} resident batches in turn",
                       "global_batch": args.batch, "image": "3x224x224", "parallelism": "dp1",
                       "launch": "eager" if args.no_graph else "hipGraph", "final_loss": round(float(loss_buf), 5),
                       "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3)},
-           "roofline": {"bound": "mfma", "kernel": "whole step (conv GEMMs + im2col / BatchNorm passes)",
+           "roofline": {"bound": "mfma", "kernel": "whole step (implicit conv GEMMs + BatchNorm passes)",
                         "achieved": round(flop_per_image * value / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flop_per_image * value / (MFMA_PEAK_TFLOPS * 1e12), 4), "traffic": None}}
     del graph, opt, model

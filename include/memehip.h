@@ -502,6 +502,30 @@ int mh_bn2d_apply(const void* x, const float* mean, const float* rstd, const flo
 int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean, const float* save_rstd,
                 void* dx, void* dres, float* dgamma, float* dbeta, float* workspace, int M, int C, int flags /* MH_BN_* */,
                 float scale, mh_stream_t stream);
+/* ---- implicit GEMM (convgemm.hip): the same convolutions with NO im2col panel in HBM.  The panel exists only as addresses:
+ * every 16-byte LDS-DMA chunk of the MFMA tile's operand is fetched from (pixel, tap, 8 channels) of the NHWC tensor, taps in
+ * the padding read as zeros through the buffer bounds.  Weights are the packed [Cout][ldk] of mh_conv_weight_pack.
+ *   mh_conv_fwd   y[B*Ho*Wo][Cout] = conv(x[B][H][W][C]); any KH x KW / stride / pad, C % 8 == 0 (C % 64 == 0 and
+ *                 ldk == KH*KW*C take the wave-uniform tap walk).  bn_part (or NULL): f32 [2][Cout][ceil(B*Ho*Wo / 128)] -- per
+ *                 128-row tile the column sums of y and y^2 (of the 16-bit values as stored), the layout mh_bn2d_fwd_parts reads:
+ *                 train-mode BatchNorm2d (Multimodal_example_task2C.txt:164 resnet50) then needs no statistics pass.
+ *   mh_conv_dgrad dx[B*H*W][C] = the input gradient from dy[B*Ho*Wo][Cout]; stride 1, KH == KW, Cout % 64 == 0 (a strided
+ *                 convolution keeps the explicit dgrad GEMM + mh_col2im_nhwc).
+ *   mh_conv_wgrad slabs[ksplit][Cout][ldk] (f32) = alpha * dy^T im2col(x), the contraction over B*Ho*Wo pixels cut into
+ *                 `ksplit` chunks (mh_gemm_ksplit_for(B*Ho*Wo, want)); mh_conv_wgrad_finish_batched sums the slabs.
+ * Limits: every tensor < 2 GiB, B*H*W and B*Ho*Wo < 2^24. */
+typedef struct MhConvGeom {
+    int32_t B, H, W, C;            /* input NHWC (C = channels of the activation matrix, a multiple of 8) */
+    int32_t KH, KW, stride, pad;
+    int32_t Cout, ldk;             /* filters; row pitch of the packed weights (multiple of 64, >= KH*KW*C) */
+} MhConvGeom;
+int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_part, const MhConvGeom* g, mh_stream_t stream);
+int mh_conv_dgrad(const void* dy, const void* wk, void* dx, const MhConvGeom* g, mh_stream_t stream);
+int mh_conv_wgrad(const void* dy, const void* x, float* slabs, int ksplit, float alpha, const MhConvGeom* g, mh_stream_t stream);
+/* mh_bn2d_fwd in training mode from statistics partials part[2][C][nblk] produced elsewhere (mh_conv_fwd): finish + apply */
+int mh_bn2d_fwd_parts(const void* x, const float* part, int nblk, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, const void* residual, void* y, float* save_mean, float* save_rstd, int M, int C, float eps,
+                      float momentum, int relu, mh_stream_t stream);
 int mh_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad, mh_stream_t stream);
 int mh_maxpool_bwd(const void* dy, const uint8_t* arg, void* dx, int B, int H, int W, int C, int K, int stride, int pad,
                    mh_stream_t stream);

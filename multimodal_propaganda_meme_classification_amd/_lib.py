@@ -50,6 +50,10 @@ class MhConvWgradJob(C.Structure):
                [("scale", C.c_float), ("block_start", C.c_int32)]
 
 
+class MhConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "KH", "KW", "stride", "pad", "Cout", "ldk")]
+
+
 MH_CONV_MAX_JOBS = 64
 MH_BN_RELU, MH_BN_ACCUM_PARAM_GRADS = 1, 2
 
@@ -168,6 +172,10 @@ _PROTOS = {
     "mh_conv_weight_unpack": [c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p],
     "mh_conv_weight_pack_batched": [C.POINTER(MhConvPackJob), c_int, c_void_p],
     "mh_conv_wgrad_finish_batched": [C.POINTER(MhConvWgradJob), c_int, c_void_p],
+    "mh_conv_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
+    "mh_conv_dgrad": [c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
+    "mh_conv_wgrad": [c_void_p, c_void_p, c_void_p, c_int, c_float, C.POINTER(MhConvGeom), c_void_p],
+    "mh_bn2d_fwd_parts": [c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_int, c_void_p],
     "mh_bn2d_workspace_elems": [c_int, c_int],
     "mh_bn2d_fwd": [c_void_p] * 10 + [c_int, c_int, c_float, c_float, c_int, c_int, c_void_p],
     "mh_bn2d_apply": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p],

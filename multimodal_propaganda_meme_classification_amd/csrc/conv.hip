@@ -547,6 +547,18 @@ extern "C" int mh_bn2d_fwd(const void* x, const float* gamma, const float* beta,
                        beta, (const h16*)residual, (h16*)y, (size_t)M, C, relu);
     return mh_launch_status();
 }
+extern "C" int mh_bn2d_fwd_parts(const void* x, const float* part, int nblk, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, const void* residual, void* y, float* save_mean,
+                                 float* save_rstd, int M, int C, float eps, float momentum, int relu, mh_stream_t stream) {
+    if (!x || !part || !gamma || !beta || !y || !save_mean || !save_rstd) return MH_EINVAL;
+    if (M < 1 || C < 8 || (C % 8) || nblk < 1) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn2d_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, nblk, M, C, eps, momentum, save_mean, save_rstd,
+                       running_mean, running_var);
+    hipLaunchKernelGGL(bn2d_apply_kernel, dim3(grid1((size_t)M * (C / 8))), dim3(256), 0, s, (const h16*)x, save_mean, save_rstd, gamma,
+                       beta, (const h16*)residual, (h16*)y, (size_t)M, C, relu);
+    return mh_launch_status();
+}
 extern "C" int mh_bn2d_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                              const void* residual, void* y, int M, int C, int relu, mh_stream_t stream) {
     if (!x || !mean || !rstd || !gamma || !beta || !y) return MH_EINVAL;

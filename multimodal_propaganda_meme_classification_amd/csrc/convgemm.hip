@@ -1,0 +1,429 @@
+// Implicit-GEMM convolution on the MFMA tile of gemm.hip (gfx950): forward, input gradient and weight gradient of an NHWC
+// 16-bit convolution WITHOUT an im2col panel in HBM (torchvision ResNet-50 as wired at Multimodal_example_task2C.txt:164,183;
+// the 3x3 panels were 9x the activation bytes, the 7x7 stem panel 360 MB per step).  See include/memehip.h ("implicit GEMM").
+//
+// Same 128x128x64 tile, 8 waves of 64x32, two LDS stages filled by LDS-DMA (buffer_load ... lds), one barrier per K tile as
+// gemm_kernel<.,.,1,8>.  The im2col matrix exists only as ADDRESSES: the per-lane source offset of every 16-byte LDS-DMA
+// chunk (8 consecutive channels of one filter tap of one pixel) is computed from (pixel, tap); taps that fall into the
+// padding get an offset beyond the buffer's num_records, which the buffer load turns into zeros.
+//   forward : Y[(b,ho,wo)][co] = sum_{tap,ci} X[b][ho*s-p+kh][wo*s-p+kw][ci] * Wk[co][(tap,ci)]     A implicit, B = Wk (K-contiguous)
+//   dgrad   : dX[(b,h,w)][ci]  = sum_{tap',co} dY[b][h-p'+kh'][w-p'+kw'][co] * Wk[co][(flip(tap'),ci)]   (stride 1, p' = KH-1-p)
+//             A implicit over dY, B = the tap's [Cout][Cin] slice of Wk read K-strided
+//   wgrad   : dWk[co][(tap,ci)] = sum_{(b,ho,wo)} dY[(b,ho,wo)][co] * X[b][ho*s-p+kh][wo*s-p+kw][ci]  A = dY (K-strided), B implicit
+//             (K-strided), split-K into f32 slabs summed in fixed order by mh_conv_wgrad_finish_batched
+// Forward epilogue: besides the 16-bit store, per-tile column sums of y and y^2 (of the ROUNDED values, i.e. of what BatchNorm
+// will read) -> part[2][Cout][tiles_m]: train-mode BatchNorm2d needs no statistics pass over the activation.
+#include "common.h"
+#include "gemm_tile.h"
+#include <stdlib.h>
+
+namespace {
+using namespace mh_tile;
+
+constexpr int NW = 8, NWM = 2, NWN = 4, NI = 4, NJ = 2;      // waves: 2 along M x 4 along N, 64x32 each (gemm.hip variant 4)
+constexpr int RED_BYTES = 4 * 2 * 128 * 4;                   // BatchNorm column partials of the four 32-row quarters of a tile
+constexpr int CONV_LDS = LDS_BYTES + RED_BYTES;
+constexpr uint32_t OOB = 0x80000000u;                        // >= num_records of every operand (sizes are checked < 2 GiB)
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+
+struct ConvArgs {
+    const h16* src;      // tensor behind the implicit operand: [B][H][W][C]
+    const h16* reg;      // the regular operand: packed weights [Cout][ldk] (fwd, dgrad) or dy [Mpix][Cout] (wgrad)
+    void* out;           // fwd: y [M][ldc] 16-bit; dgrad: dx [M][ldc] 16-bit; wgrad: f32 slabs [nsplit][M][ldc]
+    float* part;         // fwd: BatchNorm partials [2][N][tiles_m] or NULL
+    uint32_t src_bytes, reg_bytes;
+    int H, W, C;         // the implicit operand's tensor (per image)
+    int KH, KW, stride, pad;      // window walk: source pixel = (po*stride - pad + kh, qo*stride - pad + kw)
+    int Ho, Wo, Mpix;    // pixel grid the window is anchored on; Mpix = B*Ho*Wo
+    int M, N, K;         // GEMM dims (K = contraction)
+    int ldreg, ldc;
+    int Cw;              // dgrad: channels of one tap inside a packed weight row
+    int tiles_m, tiles_n, total_tiles, group_m;
+    int kchunk, nsplit;
+    float alpha;
+    float inv_wo, inv_howo;
+};
+
+// m -> (image, row, column) of the anchored pixel grid.  m < 2^24 (checked on the host): the float quotient is off by at
+// most one, fixed up exactly.
+MH_DEV void pix_decomp(const ConvArgs& a, int m, int& b, int& po, int& qo) {
+    const int hw = a.Ho * a.Wo;
+    b = (int)((float)m * a.inv_howo);
+    int r = m - b * hw;
+    if (r < 0) { --b; r += hw; }
+    else if (r >= hw) { ++b; r -= hw; }
+    po = (int)((float)r * a.inv_wo);
+    qo = r - po * a.Wo;
+    if (qo < 0) { --po; qo += a.Wo; }
+    else if (qo >= a.Wo) { ++po; qo -= a.Wo; }
+}
+
+// UNI: C % 64 == 0 and K == taps * C, so a 64-deep K tile lies inside ONE tap and the tap walk is wave-uniform (scalar).
+template <int MODE, bool UNI>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int LA = (MODE == MODE_WGRAD) ? 1 : 0;
+    constexpr int LB = (MODE == MODE_FWD) ? 0 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    int t;
+    {
+        const int nwg = a.total_tiles;
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, x = b & 7;       // blocks b, b+8, ... share an XCD (and its L2): contiguous tile runs
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    int ks = 0;
+    if (MODE == MODE_WGRAD) {
+        const int per = a.tiles_m * a.tiles_n;
+        ks = t / per;
+        t -= ks * per;
+    }
+    int tm, tn;
+    if (a.group_m <= 1) {
+        tm = t / a.tiles_n;
+        tn = t - tm * a.tiles_n;
+    } else {
+        const int per_group = a.group_m * a.tiles_n;
+        const int g = t / per_group;
+        const int r = t - g * per_group;
+        const int rows = min(a.group_m, a.tiles_m - g * a.group_m);
+        tn = r / rows;
+        tm = g * a.group_m + (r - tn * rows);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = (MODE == MODE_WGRAD) ? ks * a.kchunk : 0;
+    const int kend = (MODE == MODE_WGRAD) ? min(a.K, kbeg + a.kchunk) : a.K;
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / NWN) * (NI * 16), wn0 = (wave % NWN) * (NJ * 16);
+    const __amdgpu_buffer_rsrc_t rs = mh_rsrc(a.src, a.src_bytes);
+    const __amdgpu_buffer_rsrc_t rr = mh_rsrc(a.reg, a.reg_bytes);
+    const int taps = a.KH * a.KW;
+
+    // ---- per-lane constants of the implicit operand (two 1-KiB LDS-DMA pieces per wave and K tile) ----------------------
+    int p_base[2], p_ih[2], p_iw[2], p_aux[2];
+    if (MODE != MODE_WGRAD) {
+        // A tile [128 pixels][64 k]: piece = 8 rows x 8 chunks; the lane's row (pixel) is fixed, the tap walks with the K tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave * 2 + i;
+            const int row = piece * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            const int m = m0 + row;
+            p_aux[i] = c * 8;
+            p_base[i] = 0;
+            p_ih[i] = -(1 << 20);         // rows past M: every tap out of range -> zeros
+            p_iw[i] = 0;
+            if (m < a.M) {
+                int b, po, qo;
+                pix_decomp(a, m, b, po, qo);
+                const int ih0 = po * a.stride - a.pad, iw0 = qo * a.stride - a.pad;
+                p_ih[i] = ih0;
+                p_iw[i] = iw0;
+                p_base[i] = ((b * a.H + ih0) * a.W + iw0) * a.C + (UNI ? c * 8 : 0);
+            }
+        }
+    } else {
+        // B tile [64 pixels][128 k-columns]: piece = 4 pixel rows x 16 chunks; the lane's column chunk (tap, channels) is
+        // fixed, the pixel walks with the K tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave * 2 + i;
+            const int kr = piece * 4 + (lane >> 4);
+            const int pos = lane & 15;
+            const int c = (((pos >> 1) ^ swz_kstrided(kr)) << 1) | (pos & 1);
+            const int n = n0 + c * 8;
+            p_aux[i] = kr;
+            p_ih[i] = -(1 << 20);
+            p_iw[i] = 0;
+            p_base[i] = 0;
+            if (n < taps * a.C) {
+                const int tap = n / a.C, cin = n - tap * a.C;
+                const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                p_ih[i] = kh - a.pad;
+                p_iw[i] = kw - a.pad;
+                p_base[i] = (p_ih[i] * a.W + p_iw[i]) * a.C + cin;
+            }
+        }
+    }
+
+    // wave-uniform tap walk of the K tiles (fwd / dgrad; K starts at 0)
+    int u_kh = 0, u_kw = 0, u_c0 = 0;
+    auto issue = [&](int kt, char* st) {
+        char* la = st;
+        char* lb = st + BM * BK * 2;
+        const int k0 = kbeg + kt * BK;
+        if (MODE == MODE_WGRAD) {
+            dma_tile<1, 2>(rr, a.ldreg, m0, k0, wave, lane, la);          // dY [pixel][cout], K-strided
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int piece = wave * 2 + i;
+                const int m = k0 + p_aux[i];
+                uint32_t off = OOB;
+                if (m < kend) {
+                    int b, po, qo;
+                    pix_decomp(a, m, b, po, qo);
+                    const int hh = po * a.stride, ww = qo * a.stride;
+                    const int ih = hh + p_ih[i], iw = ww + p_iw[i];
+                    if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                        off = (uint32_t)(((b * a.H + hh) * a.W + ww) * a.C + p_base[i]) * 2u;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lb + piece * 1024), 16, off, 0, 0, 0);
+            }
+            return;
+        }
+        // regular B first (it needs the tap BEFORE the walk advances)
+        if (MODE == MODE_FWD) {
+            dma_tile<0, 2>(rr, a.ldreg, n0, k0, wave, lane, lb);          // Wk [cout][(tap,ci)], K-contiguous
+        } else {
+            const int wtap = taps - 1 - (u_kh * a.KW + u_kw);              // the weight tap behind window tap (kh', kw')
+            dma_tile<1, 2>(rr, a.ldreg, wtap * a.Cw + n0, u_c0, wave, lane, lb);   // rows co = u_c0.., columns = the tap's ci
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave * 2 + i;
+            uint32_t off = OOB;
+            if (UNI) {
+                const int ih = p_ih[i] + u_kh, iw = p_iw[i] + u_kw;
+                if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                    off = (uint32_t)(p_base[i] + (u_kh * a.W + u_kw) * a.C + u_c0) * 2u;
+            } else {
+                const int k = k0 + p_aux[i];
+                const int tap = k / a.C, cin = k - tap * a.C;
+                const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                const int ih = p_ih[i] + kh, iw = p_iw[i] + kw;
+                if (tap < taps && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                    off = (uint32_t)(p_base[i] + (kh * a.W + kw) * a.C + cin) * 2u;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, la + piece * 1024), 16, off, 0, 0, 0);
+        }
+        if (UNI) {
+            u_c0 += BK;
+            if (u_c0 >= a.C) {
+                u_c0 = 0;
+                if (++u_kw == a.KW) { u_kw = 0; ++u_kh; }
+            }
+        }
+    };
+
+    f32x4 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) issue(0, smem);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * STAGE_BYTES;
+        char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        if (kt + 1 < nk) issue(kt + 1, nxt);
+        const char* la = cur;
+        const char* lb = cur + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h16x8 fa[NI], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fa[i] = read_frag<LA>(la, wm0 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = MH_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> f32 staging tile -> 16-byte stores ---------------------------------------------------
+    float* cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                cs[cs_index(wm0 + i * 16 + (lane >> 4) * 4 + r, wn0 + j * 16 + (lane & 15))] = acc[i][j][r];
+    __syncthreads();
+    const float alpha = a.alpha;
+    if (MODE == MODE_WGRAD) {
+        float* slab = (float*)a.out + (size_t)ks * (size_t)a.M * (size_t)a.ldc;
+#pragma unroll
+        for (int it = 0; it < BM * 16 / (NW * 64); ++it) {
+            const int q = it * NW * 64 + tid;
+            const int row = q >> 4, cc = q & 15;
+            const int gm = m0 + row, gn = n0 + cc * 8;
+            if (gm >= a.M || gn >= a.N) continue;
+            const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
+            const f32x4 x1 = *(const f32x4*)(cs + cs_index(row, cc * 8 + 4));
+            float* c = slab + (size_t)gm * a.ldc + gn;
+            *(f32x4*)c = x0 * alpha;
+            *(f32x4*)(c + 4) = x1 * alpha;
+        }
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < BM * 16 / (NW * 64); ++it) {
+        const int q = it * NW * 64 + tid;
+        const int row = q >> 4, cc = q & 15;
+        const int gm = m0 + row, gn = n0 + cc * 8;
+        if (gm >= a.M || gn >= a.N) continue;
+        const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
+        const f32x4 x1 = *(const f32x4*)(cs + cs_index(row, cc * 8 + 4));
+        Pack8 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { u.e[e] = mh_f2bf(x0[e] * alpha); u.e[4 + e] = mh_f2bf(x1[e] * alpha); }
+        *(i32x4*)((h16*)a.out + (size_t)gm * a.ldc + gn) = u.v;
+    }
+    if (MODE == MODE_FWD && a.part) {
+        // column sums over the tile's rows (rows past M hold zeros), of the values as stored: four row quarters in
+        // parallel, summed in quarter order -> one partial per (tile row, channel), fixed order everywhere
+        float* red = (float*)(smem + LDS_BYTES);
+        const int col = tid & 127, qtr = tid >> 7;
+        float s = 0.f, ss = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+            const float v = mh_bf2f(mh_f2bf(cs[cs_index(qtr * 32 + r, col)] * alpha));
+            s += v;
+            ss += v * v;
+        }
+        red[(qtr * 2 + 0) * 128 + col] = s;
+        red[(qtr * 2 + 1) * 128 + col] = ss;
+        __syncthreads();
+        if (tid < 256) {
+            const int which = tid >> 7, c = tid & 127;
+            const float v = ((red[(0 * 2 + which) * 128 + c] + red[(1 * 2 + which) * 128 + c]) + red[(2 * 2 + which) * 128 + c]) +
+                            red[(3 * 2 + which) * 128 + c];
+            const int gn = n0 + c;
+            if (gn < a.N) a.part[((size_t)which * a.N + gn) * a.tiles_m + tm] = v;
+        }
+    }
+}
+
+template <int MODE, bool UNI>
+int conv_launch(const ConvArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<MODE, UNI>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, UNI>), dim3(a.total_tiles), dim3(NW * 64), CONV_LDS, s, a);
+    return mh_launch_status();
+}
+
+int geom_check(const MhConvGeom* g, int& Ho, int& Wo) {
+    if (!g) return MH_EINVAL;
+    if (g->B < 1 || g->H < 1 || g->W < 1 || g->C < 8 || (g->C % 8) || g->KH < 1 || g->KW < 1 || g->stride < 1 || g->pad < 0 ||
+        g->Cout < 8 || (g->Cout % 8) || g->ldk < g->KH * g->KW * g->C || (g->ldk % BK))
+        return MH_ESHAPE;
+    Ho = (g->H + 2 * g->pad - g->KH) / g->stride + 1;
+    Wo = (g->W + 2 * g->pad - g->KW) / g->stride + 1;
+    if (Ho < 1 || Wo < 1) return MH_ESHAPE;
+    // 32-bit byte offsets below 2 GiB (the out-of-range sentinel sits above them); pixel counts exact in a float
+    if ((size_t)g->B * g->H * g->W * g->C * 2 >= 0x80000000ull || (size_t)g->B * Ho * Wo * g->Cout * 2 >= 0x80000000ull ||
+        (size_t)g->Cout * g->ldk * 2 >= 0x80000000ull || (size_t)g->B * g->H * g->W >= (1u << 24) || (size_t)g->B * Ho * Wo >= (1u << 24))
+        return MH_ESHAPE;
+    return MH_OK;
+}
+
+int group_m_setting() {
+    static int group_m = -1;
+    if (group_m < 0) {
+        const char* e = getenv("MEMEHIP_GEMM_GROUP_M");
+        group_m = e ? atoi(e) : 8;
+        if (group_m < 0 || group_m > 64) group_m = 8;
+    }
+    return group_m;
+}
+
+}  // namespace
+
+extern "C" int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_part, const MhConvGeom* g, mh_stream_t stream) {
+    int Ho, Wo;
+    const int st = geom_check(g, Ho, Wo);
+    if (st != MH_OK) return st;
+    if (!x || !wk || !y) return MH_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)wk | (uintptr_t)y) & 15) return MH_EINVAL;
+    ConvArgs a = {};
+    a.src = (const h16*)x;
+    a.reg = (const h16*)wk;
+    a.out = y;
+    a.part = bn_part;
+    a.src_bytes = (uint32_t)((size_t)g->B * g->H * g->W * g->C * 2);
+    a.reg_bytes = (uint32_t)((size_t)g->Cout * g->ldk * 2);
+    a.H = g->H; a.W = g->W; a.C = g->C;
+    a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
+    a.Ho = Ho; a.Wo = Wo; a.Mpix = g->B * Ho * Wo;
+    a.M = a.Mpix; a.N = g->Cout; a.K = g->ldk;
+    a.ldreg = g->ldk; a.ldc = g->Cout; a.Cw = g->C;
+    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
+    a.total_tiles = a.tiles_m * a.tiles_n;
+    a.group_m = group_m_setting();
+    a.kchunk = 0; a.nsplit = 1;
+    a.alpha = 1.f;
+    a.inv_wo = 1.0f / (float)Wo; a.inv_howo = 1.0f / (float)(Ho * Wo);
+    const bool uni = (g->C % BK) == 0 && g->ldk == g->KH * g->KW * g->C;
+    return uni ? conv_launch<MODE_FWD, true>(a, (hipStream_t)stream) : conv_launch<MODE_FWD, false>(a, (hipStream_t)stream);
+}
+
+extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, const MhConvGeom* g, mh_stream_t stream) {
+    int Ho, Wo;
+    const int st = geom_check(g, Ho, Wo);
+    if (st != MH_OK) return st;
+    if (!dy || !wk || !dx) return MH_EINVAL;
+    if (((uintptr_t)dy | (uintptr_t)wk | (uintptr_t)dx) & 15) return MH_EINVAL;
+    // stride 1 (a strided convolution's input gradient has parity classes with different tap sets: the explicit path serves
+    // it), window inside the padding, a K tile inside one tap of dY
+    if (g->stride != 1 || g->KH != g->KW || g->pad > g->KH - 1 || (g->Cout % BK)) return MH_ESHAPE;
+    ConvArgs a = {};
+    a.src = (const h16*)dy;
+    a.reg = (const h16*)wk;
+    a.out = dx;
+    a.part = nullptr;
+    a.src_bytes = (uint32_t)((size_t)g->B * Ho * Wo * g->Cout * 2);
+    a.reg_bytes = (uint32_t)((size_t)g->Cout * g->ldk * 2);
+    a.H = Ho; a.W = Wo; a.C = g->Cout;
+    a.KH = g->KH; a.KW = g->KW; a.stride = 1; a.pad = g->KH - 1 - g->pad;
+    a.Ho = g->H; a.Wo = g->W; a.Mpix = g->B * g->H * g->W;
+    a.M = a.Mpix; a.N = g->C; a.K = g->KH * g->KW * g->Cout;
+    a.ldreg = g->ldk; a.ldc = g->C; a.Cw = g->C;
+    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
+    a.total_tiles = a.tiles_m * a.tiles_n;
+    a.group_m = group_m_setting();
+    a.kchunk = 0; a.nsplit = 1;
+    a.alpha = 1.f;
+    a.inv_wo = 1.0f / (float)a.Wo; a.inv_howo = 1.0f / (float)(a.Ho * a.Wo);
+    return conv_launch<MODE_DGRAD, true>(a, (hipStream_t)stream);
+}
+
+extern "C" int mh_conv_wgrad(const void* dy, const void* x, float* slabs, int ksplit, float alpha, const MhConvGeom* g,
+                             mh_stream_t stream) {
+    int Ho, Wo;
+    const int st = geom_check(g, Ho, Wo);
+    if (st != MH_OK) return st;
+    if (!dy || !x || !slabs || ksplit < 1) return MH_EINVAL;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)slabs) & 15) return MH_EINVAL;
+    ConvArgs a = {};
+    a.src = (const h16*)x;
+    a.reg = (const h16*)dy;
+    a.out = slabs;
+    a.part = nullptr;
+    a.src_bytes = (uint32_t)((size_t)g->B * g->H * g->W * g->C * 2);
+    a.reg_bytes = (uint32_t)((size_t)g->B * Ho * Wo * g->Cout * 2);
+    a.H = g->H; a.W = g->W; a.C = g->C;
+    a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.pad = g->pad;
+    a.Ho = Ho; a.Wo = Wo; a.Mpix = g->B * Ho * Wo;
+    a.M = g->Cout; a.N = g->KH * g->KW * g->C; a.K = a.Mpix;
+    a.ldreg = g->Cout; a.ldc = g->ldk; a.Cw = g->C;
+    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
+    const int kc = ((a.K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+    if ((a.K + kc - 1) / kc != ksplit) return MH_ESHAPE;          // an empty split: use mh_gemm_ksplit_for(B*Ho*Wo, want)
+    a.kchunk = kc; a.nsplit = ksplit;
+    a.total_tiles = a.tiles_m * a.tiles_n * ksplit;
+    a.group_m = group_m_setting();
+    a.alpha = alpha == 0.f ? 1.f : alpha;
+    a.inv_wo = 1.0f / (float)Wo; a.inv_howo = 1.0f / (float)(Ho * Wo);
+    return conv_launch<MODE_WGRAD, false>(a, (hipStream_t)stream);
+}

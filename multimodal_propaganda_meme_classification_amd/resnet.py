@@ -5,11 +5,14 @@
 ``layer3.4.conv2.weight``, ``layer2.0.downsample.0.weight``, ``fc.bias`` ...): the ``nn.Conv2d / nn.BatchNorm2d / nn.Linear``
 submodules only HOLD the parameters and running statistics; the arithmetic runs in libmemehip:
 
-* activations NHWC 16-bit (a [B*H*W][C] matrix); every convolution is ``mh_gemm_bf16_grouped`` -- directly for 1x1/stride 1,
-  over ``mh_im2col_nhwc`` otherwise; weights are re-packed to ``[Cout][(kh,kw,c)]`` 16-bit every forward (150 MB of traffic);
-* train-mode BatchNorm2d with per-replica batch statistics (the reference uses plain BN) fused with the residual
-  add and the ReLU (``mh_bn2d_fwd / mh_bn2d_bwd``), max pool, global average pool, the 2048 -> 1000 classifier in exact f32;
-* the backward is one opaque autograd node (dgrad GEMM + ``mh_col2im_nhwc``, wgrad GEMM, BatchNorm backward);
+* activations NHWC 16-bit (a [B*H*W][C] matrix); every convolution is an IMPLICIT GEMM on the MFMA tile (``mh_conv_fwd``:
+  the im2col matrix exists only as LDS-DMA source addresses, nothing is materialised); weights are re-packed to
+  ``[Cout][(kh,kw,c)]`` 16-bit every forward (150 MB of traffic);
+* train-mode BatchNorm2d with per-replica batch statistics (the reference uses plain BN): the statistics come from
+  the convolution epilogue's per-tile column sums (``mh_bn2d_fwd_parts``: no pass over the activation), the normalisation is
+  fused with the residual add and the ReLU; max pool, global average pool, the 2048 -> 1000 classifier in exact f32;
+* the backward is one opaque autograd node (``mh_conv_wgrad``, ``mh_conv_dgrad`` -- the six strided convolutions keep the
+  dgrad GEMM + ``mh_col2im_nhwc`` --, BatchNorm backward);
 * the 16-bit gradient stream carries ``grad_stream_scale`` (8192 for fp16), removed where parameter gradients are produced.
 
 ``ResNetClassifier`` is the Subtask-2B surface (ResNet_example_task2B.py:206-221): ``model(pixel_values=..., labels=...)``
@@ -62,25 +65,41 @@ class _Conv:
     def out_hw(self, H, W):
         return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
 
-    def forward(self, lib, x, B, H, W, T16, wk):
-        """x: [B*H*W, cp] 16-bit, wk: the packed weight [cout, ldk] -> (y [B*Ho*Wo, cout] 16-bit, saved A matrix, wk, Ho, Wo)"""
+    def geom(self, B, H, W):
+        g = _lib.MhConvGeom()
+        g.B, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.Cout, g.ldk = B, H, W, self.cp, self.kh, self.kw, self.stride, self.pad, self.cout, self.ldk
+        return g
+
+    def forward(self, lib, x, B, H, W, T16, wk, want_stats=True):
+        """x: [B*H*W, cp] 16-bit, wk: the packed weight [cout, ldk] -> (y [B*Ho*Wo, cout] 16-bit, BatchNorm partials
+        [2][cout][ceil(M/128)] or None, Ho, Wo).  Implicit GEMM (mh_conv_fwd): no im2col panel; the epilogue leaves the
+        per-tile column sums BatchNorm needs."""
         Ho, Wo = self.out_hw(H, W)
         M = B * Ho * Wo
-        if self.direct:
-            A = x
-        else:
-            A = torch.empty((M, self.ldk), dtype=T16, device=x.device)
-            check(lib.mh_im2col_nhwc(x.data_ptr(), A.data_ptr(), B, H, W, self.cp, self.kh, self.kw, self.stride, self.pad, self.ldk,
-                                     _stream()), "mh_im2col_nhwc")
         y = torch.empty((M, self.cout), dtype=T16, device=x.device)
-        ops.gemm_grouped([ops.Gemm(A, wk, y, M, self.cout, self.ldk, self.ldk, self.ldk, self.cout)], False, False)
-        return y, A, wk, Ho, Wo
+        part = torch.empty((2, self.cout, (M + 127) // 128), dtype=F32, device=x.device) if want_stats else None
+        check(lib.mh_conv_fwd(x.data_ptr(), wk.data_ptr(), y.data_ptr(), None if part is None else part.data_ptr(), self.geom(B, H, W),
+                              _stream()), "mh_conv_fwd")
+        return y, part, Ho, Wo
 
-    def backward(self, lib, dy, A, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True, side=None):
+    def _wgrad(self, lib, dy, x, B, H, W, Ho, Wo, gscale):
+        M = B * Ho * Wo
+        tiles = ((self.cout + 127) // 128) * ((self.kh * self.kw * self.cp + 127) // 128)
+        target = int(os.environ.get("MEMEHIP_WGRAD_TILES", 512))
+        want = max(1, min(64, -(-target // tiles), M // 256))
+        sp = max(1, lib.mh_gemm_ksplit_for(int(M), int(want)))
+        slabs = torch.empty((sp, self.cout, self.ldk), dtype=F32, device=dy.device)
+        check(lib.mh_conv_wgrad(dy.data_ptr(), x.data_ptr(), slabs.data_ptr(), sp, 1.0 / gscale, self.geom(B, H, W), _stream()),
+              "mh_conv_wgrad")
+        return slabs, sp
+
+    def backward(self, lib, dy, x, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True, side=None):
         """dy [M, cout] 16-bit -> dx [B*H*W, cp] 16-bit (or None); the weight gradient's split-K slabs are queued in `wjobs`
         (summed, un-packed and added to .grad for all convolutions at once at the end of the backward).  With `side`, the
-        weight-gradient GEMM -- which nothing later in the backward chain reads -- runs on that stream beside the input-gradient
-        GEMM / col2im / BatchNorm chain of the layers below (the operands are kept alive in `wjobs` until the streams join)."""
+        weight-gradient kernel -- which nothing later in the backward chain reads -- runs on that stream beside the input-gradient
+        chain of the layers below (the operands are kept alive in `wjobs` until the streams join).
+        Weight gradient: implicit GEMM over x (mh_conv_wgrad).  Input gradient: stride 1 -> mh_conv_dgrad (1x1: the plain GEMM,
+        which is the same thing); strided -> dgrad GEMM into a per-tap panel + mh_col2im_nhwc (3 + 3 layers of ResNet-50)."""
         M = B * Ho * Wo
         dev = dy.device
         if side is not None:
@@ -88,17 +107,22 @@ class _Conv:
             ev.record(torch.cuda.current_stream())
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                slabs, sp = ops.wgrad_slabs(dy, A, self.cout, self.ldk, M, self.cout, self.ldk, alpha=1.0 / gscale)
+                slabs, sp = self._wgrad(lib, dy, x, B, H, W, Ho, Wo, gscale)
         else:
-            slabs, sp = ops.wgrad_slabs(dy, A, self.cout, self.ldk, M, self.cout, self.ldk, alpha=1.0 / gscale)
-        wjobs.append((self, slabs, sp, dy, A))
+            slabs, sp = self._wgrad(lib, dy, x, B, H, W, Ho, Wo, gscale)
+        wjobs.append((self, slabs, sp, dy, x))
         if not need_dx:
             return None
+        if self.direct:
+            dx = torch.empty((M, self.cp), dtype=dy.dtype, device=dev)
+            ops.gemm_grouped([ops.Gemm(dy, wk, dx, M, self.ldk, self.cout, self.cout, self.ldk, self.ldk)], False, True)
+            return dx
+        dx = torch.empty((B * H * W, self.cp), dtype=dy.dtype, device=dev)
+        if self.stride == 1 and self.kh == self.kw and self.cout % 64 == 0:
+            check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), self.geom(B, H, W), _stream()), "mh_conv_dgrad")
+            return dx
         dA = torch.empty((M, self.ldk), dtype=dy.dtype, device=dev)
         ops.gemm_grouped([ops.Gemm(dy, wk, dA, M, self.ldk, self.cout, self.cout, self.ldk, self.ldk)], False, True)
-        if self.direct:
-            return dA
-        dx = torch.empty((B * H * W, self.cp), dtype=dy.dtype, device=dev)
         check(lib.mh_col2im_nhwc(dA.data_ptr(), dx.data_ptr(), B, H, W, self.cp, self.kh, self.kw, self.stride, self.pad, self.ldk,
                                  _stream()), "mh_col2im_nhwc")
         return dx
@@ -112,10 +136,16 @@ class _BN:
     def _ws(self, M, dev):
         return torch.empty(int(_lib.load().mh_bn2d_workspace_elems(M, self.C)), dtype=F32, device=dev)
 
-    def forward(self, lib, x, M, residual, relu, training):
+    def forward(self, lib, x, M, residual, relu, training, part=None):
         m = self.mod
         y = torch.empty_like(x)
         sm, sr = torch.empty(self.C, dtype=F32, device=x.device), torch.empty(self.C, dtype=F32, device=x.device)
+        if training and part is not None:      # batch statistics from the convolution epilogue's per-tile sums: no pass over x
+            check(lib.mh_bn2d_fwd_parts(x.data_ptr(), part.data_ptr(), part.shape[2], m.weight.data_ptr(), m.bias.data_ptr(),
+                                        m.running_mean.data_ptr(), m.running_var.data_ptr(), None if residual is None else residual.data_ptr(),
+                                        y.data_ptr(), sm.data_ptr(), sr.data_ptr(), M, self.C, float(m.eps),
+                                        float(m.momentum if m.momentum is not None else 0.1), int(relu), _stream()), "mh_bn2d_fwd_parts")
+            return y, sm, sr
         ws = self._ws(M, x.device)
         check(lib.mh_bn2d_fwd(x.data_ptr(), m.weight.data_ptr(), m.bias.data_ptr(), m.running_mean.data_ptr(), m.running_var.data_ptr(),
                               None if residual is None else residual.data_ptr(), y.data_ptr(), sm.data_ptr(), sr.data_ptr(),
@@ -230,10 +260,11 @@ class ResNet50(nn.Module):
 
         def conv_bn(conv_mod, bn_mod, xin, h, w, residual=None, relu=True, cin_pad=None):
             cv, bn = _Conv(conv_mod, cin_pad), _BN(bn_mod)
-            z, A, wk, ho, wo = cv.forward(lib, xin, B, h, w, T16, packed[id(conv_mod)])
+            wk = packed[id(conv_mod)]
+            z, part, ho, wo = cv.forward(lib, xin, B, h, w, T16, wk, want_stats=training)
             M = B * ho * wo
-            y, sm, sr = bn.forward(lib, z, M, residual, relu, training)
-            tape["ops"].append(("conv_bn", cv, bn, A, wk, z, y, sm, sr, h, w, ho, wo, relu, residual is not None))
+            y, sm, sr = bn.forward(lib, z, M, residual, relu, training, part)
+            tape["ops"].append(("conv_bn", cv, bn, xin, wk, z, y, sm, sr, h, w, ho, wo, relu, residual is not None))
             return y, ho, wo
 
         y, h, w = conv_bn(self.conv1, self.bn1, x, H, W, cin_pad=8)

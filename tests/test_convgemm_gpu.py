@@ -1,0 +1,185 @@
+"""Implicit-GEMM convolution (csrc/convgemm.hip) on the MI355X through the C ABI: forward, input gradient and weight gradient
+of the ResNet-50 convolutions (Multimodal_example_task2C.txt:164,183: models.resnet50) with no im2col panel.
+
+Oracle: torch's fp32 conv2d on the CPU.  On small integers every product and partial sum is exactly representable in the 16-bit
+operands and the f32 accumulators, so the comparison is BIT-EXACT up to the one rounding of the 16-bit store (the bar for index work:
+which pixel, which tap, which channel goes where); the BatchNorm partial sums of the forward epilogue are compared the same way."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+F16, BF16, F32 = torch.float16, torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import multimodal_propaganda_meme_classification_amd as m
+    return m
+
+
+def _nhwc(x, T16):
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).to(T16).cuda().contiguous()
+
+
+def _nchw(m, B, H, W):
+    return m.float().cpu().view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def _geom(pkg, B, H, W, C, k, s, p, Cout, ldk):
+    g = pkg._lib.MhConvGeom()
+    g.B, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.Cout, g.ldk = B, H, W, C, k, k, s, p, Cout, ldk
+    return g
+
+
+def _pack(pkg, lib, w, Cp, ldk, T16):
+    Cout, Cin, k, _ = w.shape
+    wd = w.cuda().contiguous()
+    wk = torch.empty((Cout, ldk), dtype=T16, device="cuda")
+    pkg._lib.check(lib.mh_conv_weight_pack(wd.data_ptr(), wk.data_ptr(), Cout, Cin, k, k, Cp, ldk, torch.cuda.current_stream().cuda_stream), "pack")
+    return wk
+
+
+# (B, Cin, H, W, Cout, k, stride, pad): uniform-tap walk (Cin % 64 == 0) and the generic one (the stem's 8 padded channels,
+# 24 channels), ragged M (rows past the last full tile), Cout below / above one column tile, 1x1 strided (downsample)
+CASES = [
+    (2, 64, 9, 7, 64, 3, 1, 1),
+    (3, 128, 10, 10, 192, 3, 1, 1),
+    (2, 64, 12, 11, 128, 3, 2, 1),
+    (2, 256, 8, 8, 64, 1, 2, 0),
+    (2, 64, 6, 6, 256, 1, 1, 0),
+    (2, 8, 20, 18, 64, 7, 2, 3),
+    (1, 24, 7, 9, 16, 3, 1, 1),
+    (5, 64, 14, 14, 64, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("T16", [F16, BF16])
+def test_implicit_conv_forward_and_bn_partials_are_exact_on_integers(pkg, T16):
+    lib = pkg._lib.load("fp16" if T16 == F16 else "bf16")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(11)
+    for (B, C, H, W, Cout, k, s, p) in CASES:
+        x = torch.randint(-1, 2, (B, C, H, W), generator=g).float()
+        w = torch.randint(-2, 3, (Cout, C, k, k), generator=g).float()
+        ref = F.conv2d(x, w, stride=s, padding=p).to(T16).float()       # integer sums are exact in f32; the store rounds once
+        Ho, Wo = ref.shape[2], ref.shape[3]
+        M = B * Ho * Wo
+        ldk = (k * k * C + 63) // 64 * 64
+        xd, wk = _nhwc(x, T16), _pack(pkg, lib, w, C, ldk, T16)
+        y = torch.full((M, Cout), 7.0, dtype=T16, device="cuda")
+        nblk = (M + 127) // 128
+        part = torch.full((2, Cout, nblk), -1.0, dtype=F32, device="cuda")
+        geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
+        pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y.data_ptr(), part.data_ptr(), geom, st), "mh_conv_fwd")
+        assert torch.equal(_nchw(y, B, Ho, Wo), ref), (B, C, H, W, Cout, k, s, p)
+        rows = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+        pad_rows = torch.zeros((nblk * 128, Cout))
+        pad_rows[:M] = rows
+        blocks = pad_rows.view(nblk, 128, Cout)
+        assert torch.equal(part[0].cpu(), blocks.sum(1).t().contiguous())
+        assert torch.equal(part[1].cpu(), (blocks * blocks).sum(1).t().contiguous())
+        # without the statistics request the output is the same
+        y2 = torch.empty_like(y)
+        pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y2.data_ptr(), None, geom, st), "mh_conv_fwd")
+        assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("T16", [F16, BF16])
+def test_implicit_conv_input_gradient_is_exact_on_integers(pkg, T16):
+    lib = pkg._lib.load("fp16" if T16 == F16 else "bf16")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(12)
+    for (B, C, H, W, Cout, k, s, p) in CASES:
+        if s != 1 or Cout % 64:
+            geom = _geom(pkg, B, H, W, C, k, s, p, Cout, (k * k * C + 63) // 64 * 64)
+            d = torch.zeros(16, dtype=T16, device="cuda")
+            assert lib.mh_conv_dgrad(d.data_ptr(), d.data_ptr(), d.data_ptr(), geom, st) == 2       # MH_ESHAPE: the explicit path serves it
+            continue
+        x = torch.zeros((B, C, H, W), requires_grad=True)
+        w = torch.randint(-2, 3, (Cout, C, k, k), generator=g).float()
+        yr = F.conv2d(x, w, stride=s, padding=p)
+        Ho, Wo = yr.shape[2], yr.shape[3]
+        dy = torch.randint(-2, 3, yr.shape, generator=g).float()
+        yr.backward(dy)
+        ldk = (k * k * C + 63) // 64 * 64
+        wk = _pack(pkg, lib, w, C, ldk, T16)
+        dyd = _nhwc(dy, T16)
+        dx = torch.full((B * H * W, C), 7.0, dtype=T16, device="cuda")
+        geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
+        pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), geom, st), "mh_conv_dgrad")
+        assert torch.equal(_nchw(dx, B, H, W), x.grad.to(T16).float()), (B, C, H, W, Cout, k, s, p)
+
+
+@pytest.mark.parametrize("T16", [F16, BF16])
+def test_implicit_conv_weight_gradient_is_exact_on_integers(pkg, T16):
+    lib = pkg._lib.load("fp16" if T16 == F16 else "bf16")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(13)
+    for (B, C, H, W, Cout, k, s, p) in CASES:
+        x = torch.randint(-2, 3, (B, C, H, W), generator=g).float()
+        w = torch.zeros((Cout, C, k, k), requires_grad=True)
+        yr = F.conv2d(x, w, stride=s, padding=p)
+        Ho, Wo = yr.shape[2], yr.shape[3]
+        dy = torch.randint(-1, 2, yr.shape, generator=g).float()
+        yr.backward(dy)
+        M = B * Ho * Wo
+        ldk = (k * k * C + 63) // 64 * 64
+        xd, dyd = _nhwc(x, T16), _nhwc(dy, T16)
+        geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
+        for want in (1, 3):
+            sp = max(1, lib.mh_gemm_ksplit_for(M, want))
+            slabs = torch.full((sp, Cout, ldk), 5.0, dtype=F32, device="cuda")
+            pkg._lib.check(lib.mh_conv_wgrad(dyd.data_ptr(), xd.data_ptr(), slabs.data_ptr(), sp, 0.5, geom, st), "mh_conv_wgrad")
+            gk = slabs.sum(0)[:, :k * k * C].cpu().view(Cout, k * k, C)          # [co][tap][ci]
+            got = gk.permute(0, 2, 1).reshape(Cout, C, k, k)
+            assert torch.equal(got, 0.5 * w.grad), (B, C, H, W, Cout, k, s, p, sp)
+        # an impossible split is refused
+        assert lib.mh_conv_wgrad(dyd.data_ptr(), xd.data_ptr(), slabs.data_ptr(), 10 ** 6, 1.0, geom, st) == 2
+
+
+def test_implicit_conv_equals_the_explicit_im2col_path_bit_for_bit(pkg):
+    """Same tile, same K order (tap-major, then channel): on random 16-bit data the implicit kernel and the im2col + grouped-GEMM
+    path must agree in every bit, forward and weight gradient."""
+    lib = pkg._lib.load("fp16")
+    st = torch.cuda.current_stream().cuda_stream
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(14)
+    B, C, H, W, Cout, k, s, p = 4, 128, 28, 28, 128, 3, 1, 1
+    x = torch.randn((B, C, H, W), generator=g)
+    w = torch.randn((Cout, C, k, k), generator=g) * 0.05
+    Ho, Wo = H, W
+    M, ldk = B * Ho * Wo, k * k * C
+    xd, wk = _nhwc(x, F16), _pack(pkg, lib, w, C, ldk, F16)
+    col = torch.empty((M, ldk), dtype=F16, device="cuda")
+    pkg._lib.check(lib.mh_im2col_nhwc(xd.data_ptr(), col.data_ptr(), B, H, W, C, k, k, s, p, ldk, st), "im2col")
+    y_ref = torch.empty((M, Cout), dtype=F16, device="cuda")
+    ops.gemm_grouped([ops.Gemm(col, wk, y_ref, M, Cout, ldk, ldk, ldk, Cout)], False, False)
+    y = torch.empty_like(y_ref)
+    geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
+    pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y.data_ptr(), None, geom, st), "mh_conv_fwd")
+    assert torch.equal(y, y_ref)
+    # against the fp32 oracle the error is the 16-bit rounding of the operands and of the result
+    ref = F.conv2d(x.to(F16).float(), w.to(F16).float(), stride=s, padding=p)
+    assert float((_nchw(y, B, Ho, Wo) - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    dy = torch.randn((M, Cout), generator=g).to(F16).cuda()
+    slabs_ref, sp = ops.wgrad_slabs(dy, col, Cout, ldk, M, Cout, ldk, alpha=1.0)
+    slabs = torch.empty_like(slabs_ref)
+    pkg._lib.check(lib.mh_conv_wgrad(dy.data_ptr(), xd.data_ptr(), slabs.data_ptr(), sp, 1.0, geom, st), "mh_conv_wgrad")
+    assert torch.equal(slabs, slabs_ref)
+    # dgrad: implicit vs GEMM + col2im.  The explicit path rounds each tap's product to 16 bits before col2im sums the taps; the
+    # implicit one accumulates all taps in f32 -- it is the more accurate of the two, compare both with the fp32 oracle
+    dcol = torch.empty((M, ldk), dtype=F16, device="cuda")
+    ops.gemm_grouped([ops.Gemm(dy, wk, dcol, M, ldk, Cout, Cout, ldk, ldk)], False, True)
+    dx_ref = torch.empty((B * H * W, C), dtype=F16, device="cuda")
+    pkg._lib.check(lib.mh_col2im_nhwc(dcol.data_ptr(), dx_ref.data_ptr(), B, H, W, C, k, k, s, p, ldk, st), "col2im")
+    dx = torch.empty_like(dx_ref)
+    pkg._lib.check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), geom, st), "mh_conv_dgrad")
+    xr = x.to(F16).float().requires_grad_(True)
+    F.conv2d(xr, w.to(F16).float(), stride=s, padding=p).backward(_nchw(dy, B, Ho, Wo))
+    scale = float(xr.grad.abs().max())
+    e_imp = float((_nchw(dx, B, H, W) - xr.grad).abs().max())
+    e_exp = float((_nchw(dx_ref, B, H, W) - xr.grad).abs().max())
+    assert e_imp < 1.5e-3 * scale and e_imp <= e_exp * 1.05
