@@ -499,9 +499,11 @@ int mh_bn2d_fwd(const void* x, const float* gamma, const float* beta, float* run
                 int relu, mh_stream_t stream);
 int mh_bn2d_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, const void* residual,
                   void* y, int M, int C, int relu, mh_stream_t stream);
-int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean, const float* save_rstd,
-                void* dx, void* dres, float* dgamma, float* dbeta, float* workspace, int M, int C, int flags /* MH_BN_* */,
-                float scale, mh_stream_t stream);
+/* y: the forward output (the ReLU mask is y > 0), or NULL with MH_BN_RELU when the forward had NO residual: the mask is then
+ * recomputed from x as the forward computed y (16-bit rounding of (x - mean) rstd gamma + beta > 0), one tensor less to read */
+int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
+                const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* workspace, int M, int C,
+                int flags /* MH_BN_* */, float scale, mh_stream_t stream);
 /* ---- implicit GEMM (convgemm.hip): the same convolutions with NO im2col panel in HBM.  The panel exists only as addresses:
  * every 16-byte LDS-DMA chunk of the MFMA tile's operand is fetched from (pixel, tap, 8 channels) of the NHWC tensor, taps in
  * the padding read as zeros through the buffer bounds.  Weights are the packed [Cout][ldk] of mh_conv_weight_pack.

@@ -179,7 +179,7 @@ _PROTOS = {
     "mh_bn2d_workspace_elems": [c_int, c_int],
     "mh_bn2d_fwd": [c_void_p] * 10 + [c_int, c_int, c_float, c_float, c_int, c_int, c_void_p],
     "mh_bn2d_apply": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p],
-    "mh_bn2d_bwd": [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p],
+    "mh_bn2d_bwd": [c_void_p] * 12 + [c_int, c_int, c_int, c_float, c_void_p],
     "mh_maxpool_fwd": [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     "mh_maxpool_bwd": [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     "mh_avgpool_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

@@ -104,12 +104,55 @@ struct PackJobs {
     int pad_;
     MhConvPackJob j[MH_CONV_MAX_JOBS];
 };
+// k x k filters with Cin % 64 == 0 take the TRANSPOSING path: a wave owns one (filter, 64 input channels) unit -- 64 * taps
+// contiguous floats of the torch layout, read coalesced, turned [ci][tap] -> [tap][ci] through LDS and written as 16-byte
+// chunks (the element-per-thread form read with a stride of `taps` floats: 312 us per ResNet-50 step, most of it 3x3 filters)
+constexpr int CONV_T_MAX_TAPS = 16;
+MH_DEV bool conv_job_transposes(int Cin, int Cp, int taps, int ldk) {
+    return taps > 1 && taps <= CONV_T_MAX_TAPS && (Cin % 64) == 0 && Cp == Cin && ldk == taps * Cin;
+}
+// 1x1 filters whose packed row IS the torch row (Cp == Cin == ldk): a flat cast / sum, 8 (pack) or 4 (finish) elements per thread
+MH_DEV bool conv_job_flat(int Cin, int Cp, int taps, int ldk) { return taps == 1 && Cp == Cin && ldk == Cin && (Cin % 8) == 0; }
+static int conv_job_blocks(int Cout, int Cin, int Cp, int taps, int ldk, size_t elems, int per_thread) {
+    if (taps > 1 && taps <= CONV_T_MAX_TAPS && (Cin % 64) == 0 && Cp == Cin && ldk == taps * Cin) return (Cout * (Cin / 64) + 3) / 4;
+    if (taps == 1 && Cp == Cin && ldk == Cin && (Cin % 8) == 0) return grid1(elems / per_thread);
+    return grid1(elems);
+}
 __global__ __launch_bounds__(256) void weight_pack_batched_kernel(const PackJobs J) {
+    __shared__ float tr[4][64 * CONV_T_MAX_TAPS];
     int ji = 0;
     for (int i = 1; i < J.n; ++i)
         if ((int)blockIdx.x >= J.j[i].block_start) ji = i;
     const MhConvPackJob& q = J.j[ji];
+    const int taps = q.KH * q.KW;
+    if (conv_job_transposes(q.Cin, q.Cp, taps, q.ldk)) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int unit = (int)(blockIdx.x - q.block_start) * 4 + wave, cgrp = q.Cin / 64;
+        const bool live = unit < q.Cout * cgrp;
+        const int co = live ? unit / cgrp : 0, c0 = live ? (unit - co * cgrp) * 64 : 0;
+        const float* src = q.w + ((size_t)co * q.Cin + c0) * taps;
+        for (int i = lane; i < 64 * taps && live; i += 64) tr[wave][i] = src[i];      // [ci][tap]
+        __syncthreads();
+        h16* dst = (h16*)q.out + (size_t)co * q.ldk + c0;
+        for (int u = lane; u < taps * 8 && live; u += 64) {
+            const int tap = u >> 3, ch = u & 7;
+            Pack8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.e[e] = mh_f2bf(tr[wave][(ch * 8 + e) * taps + tap]);
+            *(i32x4*)(dst + (size_t)tap * q.Cp + ch * 8) = o.v;
+        }
+        return;
+    }
     const uint32_t idx = (uint32_t)(blockIdx.x - q.block_start) * 256u + threadIdx.x;      // (a job has < 2^31 elements: checked on the host)
+    if (conv_job_flat(q.Cin, q.Cp, taps, q.ldk)) {
+        if (idx >= (uint32_t)q.Cout * (uint32_t)q.ldk / 8u) return;
+        const f32x4 a = *(const f32x4*)(q.w + (size_t)idx * 8), b = *(const f32x4*)(q.w + (size_t)idx * 8 + 4);
+        Pack8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o.e[e] = mh_f2bf(a[e]); o.e[4 + e] = mh_f2bf(b[e]); }
+        *(i32x4*)((h16*)q.out + (size_t)idx * 8) = o.v;
+        return;
+    }
     if (idx >= (uint32_t)q.Cout * (uint32_t)q.ldk) return;
     const uint32_t co = idx / (uint32_t)q.ldk, k = idx - co * (uint32_t)q.ldk;
     float v = 0.f;
@@ -127,18 +170,59 @@ struct FinishJobs {
     MhConvWgradJob j[MH_CONV_MAX_JOBS];
 };
 __global__ __launch_bounds__(256) void wgrad_finish_batched_kernel(const FinishJobs J) {
+    __shared__ float tr[4][64 * CONV_T_MAX_TAPS];
     int ji = 0;
     for (int i = 1; i < J.n; ++i)
         if ((int)blockIdx.x >= J.j[i].block_start) ji = i;
     const MhConvWgradJob& q = J.j[ji];
-    // threads walk the SLAB order (co, tap, ci): the nsplit reads are coalesced, the one write per element is strided by KH*KW
     const uint32_t taps = (uint32_t)(q.KH * q.KW), per_co = taps * (uint32_t)q.Cin;
+    const size_t slab = (size_t)q.Cout * q.ldk;
+    if (conv_job_transposes(q.Cin, q.Cp, (int)taps, q.ldk)) {
+        // a wave per (filter, 64 input channels): the slab rows [tap][64 ci] are read coalesced and summed in slab order, the
+        // result goes [tap][ci] -> [ci][tap] through LDS and leaves as one contiguous run of the torch layout
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int unit = (int)(blockIdx.x - q.block_start) * 4 + wave, cgrp = q.Cin / 64;
+        const bool live = unit < q.Cout * cgrp;
+        const int co = live ? unit / cgrp : 0, c0 = live ? (unit - co * cgrp) * 64 : 0;
+        if (live) {     // every tap's load of a slab in flight together (a tap at a time was one 256-B load in flight per wave)
+            float acc[CONV_T_MAX_TAPS];
+#pragma unroll
+            for (int tap = 0; tap < CONV_T_MAX_TAPS; ++tap) acc[tap] = 0.f;
+            const float* src = q.slabs + (size_t)co * q.ldk + c0 + lane;
+            for (int sidx = 0; sidx < q.nsplit; ++sidx, src += slab) {
+#pragma unroll
+                for (int tap = 0; tap < CONV_T_MAX_TAPS; ++tap)
+                    if (tap < (int)taps) acc[tap] += src[(size_t)tap * q.Cp];
+            }
+#pragma unroll
+            for (int tap = 0; tap < CONV_T_MAX_TAPS; ++tap)
+                if (tap < (int)taps) tr[wave][lane * taps + tap] = acc[tap] * q.scale;
+        }
+        __syncthreads();
+        float* dst = q.g + ((size_t)co * q.Cin + c0) * taps;
+        for (uint32_t i = lane; i < 64 * taps && live; i += 64) {
+            float v = tr[wave][i];
+            if (q.accumulate) v += dst[i];
+            dst[i] = v;
+        }
+        return;
+    }
+    // threads walk the SLAB order (co, tap, ci): the nsplit reads are coalesced, the one write per element is strided by KH*KW
     const uint32_t idx = (uint32_t)(blockIdx.x - q.block_start) * 256u + threadIdx.x;
+    if (conv_job_flat(q.Cin, q.Cp, (int)taps, q.ldk)) {
+        if (idx >= (uint32_t)q.Cout * per_co / 4u) return;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int sidx = 0; sidx < q.nsplit; ++sidx) acc += *(const f32x4*)(q.slabs + (size_t)sidx * slab + (size_t)idx * 4);
+        acc *= q.scale;
+        f32x4* dst = (f32x4*)(q.g + (size_t)idx * 4);
+        if (q.accumulate) acc += *dst;
+        *dst = acc;
+        return;
+    }
     if (idx >= (uint32_t)q.Cout * per_co) return;
     const uint32_t co = idx / per_co, r = idx - co * per_co;
     const uint32_t tap = r / (uint32_t)q.Cin, ci = r - tap * (uint32_t)q.Cin;
     const size_t src = (size_t)co * q.ldk + (size_t)tap * q.Cp + ci;
-    const size_t slab = (size_t)q.Cout * q.ldk;
     float acc = 0.f;
     for (int sidx = 0; sidx < q.nsplit; ++sidx) acc += q.slabs[(size_t)sidx * slab + src];
     acc *= q.scale;
@@ -262,9 +346,17 @@ __global__ __launch_bounds__(256) void bn2d_apply_kernel(const h16* __restrict__
     *(i32x4*)(y + idx * 8) = o.v;
 }
 // backward stats: dy' = dy * (y > 0 if relu); part[b][0][c] = sum dy', part[b][1][c] = sum dy' xhat
+MH_DEV void load8(const float* __restrict__ p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+// relu with y == NULL: the mask is RECOMPUTED from x -- y = relu(bn(x)) was positive exactly when the 16-bit rounding of
+// (x - mean) rstd gamma + beta is (the forward's own expression; no residual in that case) -- one tensor less to read
 __global__ __launch_bounds__(256) void bn2d_bwd_stats_kernel(const h16* __restrict__ dy, const h16* __restrict__ x,
                                                              const h16* __restrict__ y, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, float* __restrict__ part, int M,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ part, int M,
                                                              int C, int relu, int rpb) {
     const int c8 = C / 8, c8w = min(c8, 256), nty = 256 / c8w;
     const int tx = threadIdx.x % c8w, ty = threadIdx.x / c8w;
@@ -273,21 +365,25 @@ __global__ __launch_bounds__(256) void bn2d_bwd_stats_kernel(const h16* __restri
     const int r0 = blk * rpb, r1 = min(M, r0 + rpb);
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (t < c8 && ty < nty) {
-        float mu[8], rs[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { mu[e] = mean[t * 8 + e]; rs[e] = rstd[t * 8 + e]; }
+        const bool from_y = relu && y != nullptr, from_x = relu && y == nullptr;
+        float mu[8], rs[8], ga[8], be[8];
+        load8(mean + t * 8, mu);
+        load8(rstd + t * 8, rs);
+        if (from_x) { load8(gamma + t * 8, ga); load8(beta + t * 8, be); }
         for (int r = r0 + ty; r < r1; r += nty) {
             Pack8 d, xv, yv;
             d.v = *(const i32x4*)(dy + (size_t)r * C + t * 8);
             xv.v = *(const i32x4*)(x + (size_t)r * C + t * 8);
             yv.v = d.v;
-            if (relu) yv.v = *(const i32x4*)(y + (size_t)r * C + t * 8);
+            if (from_y) yv.v = *(const i32x4*)(y + (size_t)r * C + t * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float g = mh_bf2f(d.e[e]);
-                if (relu && !(mh_bf2f(yv.e[e]) > 0.f)) g = 0.f;
+                const float xh = (mh_bf2f(xv.e[e]) - mu[e]) * rs[e];
+                if (from_y && !(mh_bf2f(yv.e[e]) > 0.f)) g = 0.f;
+                if (from_x && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) g = 0.f;
                 s[e] += g;
-                q[e] += g * (mh_bf2f(xv.e[e]) - mu[e]) * rs[e];
+                q[e] += g * xh;
             }
         }
     }
@@ -316,23 +412,34 @@ __global__ __launch_bounds__(256) void bn2d_bwd_finish_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const h16* __restrict__ dy, const h16* __restrict__ x,
                                                              const h16* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ sums, h16* __restrict__ dx,
-                                                             h16* __restrict__ dres, size_t M, int C, int relu) {
+                                                             const float* __restrict__ beta, const float* __restrict__ sums,
+                                                             h16* __restrict__ dx, h16* __restrict__ dres, size_t M, int C, int relu) {
     const int c8 = C / 8;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= M * c8) return;
     const int c = (int)(idx % c8) * 8;
     const float invM = 1.0f / (float)M;
+    const bool from_y = relu && y != nullptr, from_x = relu && y == nullptr;
+    float mu[8], rs[8], ga[8], be[8], s0[8], s1[8];
+    load8(mean + c, mu);
+    load8(rstd + c, rs);
+    load8(gamma + c, ga);
+    load8(sums + c, s0);
+    load8(sums + C + c, s1);
+    if (from_x) load8(beta + c, be);
     Pack8 d, xv, yv, o, rr;
     d.v = *(const i32x4*)(dy + idx * 8);
     xv.v = *(const i32x4*)(x + idx * 8);
-    if (relu) yv.v = *(const i32x4*)(y + idx * 8);
+    yv.v = d.v;
+    if (from_y) yv.v = *(const i32x4*)(y + idx * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         float g = mh_bf2f(d.e[e]);
-        if (relu && !(mh_bf2f(yv.e[e]) > 0.f)) g = 0.f;
-        const float xh = (mh_bf2f(xv.e[e]) - mean[c + e]) * rstd[c + e];
-        o.e[e] = mh_f2bf(gamma[c + e] * rstd[c + e] * (g - sums[c + e] * invM - xh * sums[C + c + e] * invM));
+        const float xf = mh_bf2f(xv.e[e]);
+        if (from_y && !(mh_bf2f(yv.e[e]) > 0.f)) g = 0.f;
+        if (from_x && !(mh_bf2f(mh_f2bf((xf - mu[e]) * rs[e] * ga[e] + be[e])) > 0.f)) g = 0.f;
+        const float xh = (xf - mu[e]) * rs[e];
+        o.e[e] = mh_f2bf(ga[e] * rs[e] * (g - s0[e] * invM - xh * s1[e] * invM));
         rr.e[e] = mh_f2bf(g);
     }
     *(i32x4*)(dx + idx * 8) = o.v;
@@ -495,7 +602,7 @@ extern "C" int mh_conv_weight_pack_batched(const MhConvPackJob* jobs, int n, mh_
         if (q.Cout < 1 || q.Cin < 1 || q.KH < 1 || q.KW < 1 || q.Cp < q.Cin || q.ldk < q.KH * q.KW * q.Cp) return MH_ESHAPE;
         if ((size_t)q.Cout * q.ldk >= 0x7fffffffULL) return MH_ESHAPE;
         q.block_start = (int)total;
-        total += grid1((size_t)q.Cout * q.ldk);
+        total += conv_job_blocks(q.Cout, q.Cin, q.Cp, q.KH * q.KW, q.ldk, (size_t)q.Cout * q.ldk, 8);
         J.j[i] = q;
     }
     if (total > 0x7fffffffL) return MH_ESHAPE;
@@ -514,7 +621,7 @@ extern "C" int mh_conv_wgrad_finish_batched(const MhConvWgradJob* jobs, int n, m
         if (q.Cout < 1 || q.Cin < 1 || q.KH < 1 || q.KW < 1 || q.Cp < q.Cin || q.ldk < q.KH * q.KW * q.Cp || q.nsplit < 1) return MH_ESHAPE;
         if ((size_t)q.Cout * q.Cin * q.KH * q.KW >= 0x7fffffffULL) return MH_ESHAPE;
         q.block_start = (int)total;
-        total += grid1((size_t)q.Cout * q.Cin * q.KH * q.KW);
+        total += conv_job_blocks(q.Cout, q.Cin, q.Cp, q.KH * q.KW, q.ldk, (size_t)q.Cout * q.Cin * q.KH * q.KW, 4);
         J.j[i] = q;
     }
     if (total > 0x7fffffffL) return MH_ESHAPE;
@@ -567,22 +674,22 @@ extern "C" int mh_bn2d_apply(const void* x, const float* mean, const float* rstd
                        gamma, beta, (const h16*)residual, (h16*)y, (size_t)M, C, relu);
     return mh_launch_status();
 }
-extern "C" int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+extern "C" int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
                            const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, float* workspace, int M, int C,
                            int flags, float scale, mh_stream_t stream) {
     const int relu = (flags & MH_BN_RELU) ? 1 : 0, accumulate = (flags & MH_BN_ACCUM_PARAM_GRADS) ? 1 : 0;
     if (!dy || !x || !gamma || !save_mean || !save_rstd || !dx || !workspace) return MH_EINVAL;
-    if (relu && !y) return MH_EINVAL;
+    if (relu && !y && !beta) return MH_EINVAL;      // the mask comes from y, or is recomputed from x (needs beta)
     if (M < 1 || C < 8 || (C % 8)) return MH_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int rpb = bn_rpb(M, C), nblk = (M + rpb - 1) / rpb;
     float* sums = workspace + (size_t)nblk * 2 * C;
     hipLaunchKernelGGL(bn2d_bwd_stats_kernel, dim3((C / 8 + 255) / 256, nblk), dim3(256), 0, s, (const h16*)dy, (const h16*)x,
-                       (const h16*)y, save_mean, save_rstd, workspace, M, C, relu, rpb);
+                       (const h16*)y, save_mean, save_rstd, gamma, beta, workspace, M, C, relu, rpb);
     hipLaunchKernelGGL(bn2d_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, nblk, C, scale, dgamma, dbeta, sums,
                        accumulate);
     hipLaunchKernelGGL(bn2d_bwd_apply_kernel, dim3(grid1((size_t)M * (C / 8))), dim3(256), 0, s, (const h16*)dy, (const h16*)x,
-                       (const h16*)y, save_mean, save_rstd, gamma, sums, (h16*)dx, (h16*)dres, (size_t)M, C, relu);
+                       (const h16*)y, save_mean, save_rstd, gamma, beta, sums, (h16*)dx, (h16*)dres, (size_t)M, C, relu);
     return mh_launch_status();
 }
 extern "C" int mh_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad,

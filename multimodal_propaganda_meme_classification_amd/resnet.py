@@ -85,7 +85,7 @@ class _Conv:
     def _wgrad(self, lib, dy, x, B, H, W, Ho, Wo, gscale):
         M = B * Ho * Wo
         tiles = ((self.cout + 127) // 128) * ((self.kh * self.kw * self.cp + 127) // 128)
-        target = int(os.environ.get("MEMEHIP_WGRAD_TILES", 512))
+        target = int(os.environ.get("MEMEHIP_WGRAD_TILES", 256))      # (512 / 384 / 256 / 192: 7.78 / 7.74 / 7.74 / 7.72 ms per step; 256 halves the slabs)
         want = max(1, min(64, -(-target // tiles), M // 256))
         sp = max(1, lib.mh_gemm_ksplit_for(int(M), int(want)))
         slabs = torch.empty((sp, self.cout, self.ldk), dtype=F32, device=dy.device)
@@ -165,7 +165,7 @@ class _BN:
             acc_g = False
         ws = self._ws(M, x.device)
         flags = (_lib.MH_BN_RELU if relu else 0) | (_lib.MH_BN_ACCUM_PARAM_GRADS if acc_g else 0)
-        check(lib.mh_bn2d_bwd(dy.data_ptr(), x.data_ptr(), None if y is None else y.data_ptr(), m.weight.data_ptr(), sm.data_ptr(),
+        check(lib.mh_bn2d_bwd(dy.data_ptr(), x.data_ptr(), None if y is None else y.data_ptr(), m.weight.data_ptr(), m.bias.data_ptr(), sm.data_ptr(),
                               sr.data_ptr(), dx.data_ptr(), None if dres is None else dres.data_ptr(), dg.data_ptr(), db.data_ptr(),
                               ws.data_ptr(), M, self.C, flags, 1.0 / gscale, _stream()), "mh_bn2d_bwd")
         return dx, dres
@@ -345,7 +345,8 @@ class ResNet50(nn.Module):
         def conv_bn_bwd(op, dy, want_dres, need_dx=True):
             _, cv, bn, A, wk, z, y, sm, sr, hh, ww, ho, wo, relu, has_res = op
             M = B * ho * wo
-            dz, dres = bn.backward(lib, dy, z, y if relu else None, sm, sr, M, relu, want_dres, self.gscale, grads)
+            # the ReLU mask: from y where a residual was added before the ReLU, recomputed from z otherwise (one tensor less to read)
+            dz, dres = bn.backward(lib, dy, z, y if (relu and has_res) else None, sm, sr, M, relu, want_dres, self.gscale, grads)
             dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx, side=side)
             return dxin, dres
 

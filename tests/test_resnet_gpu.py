@@ -100,9 +100,15 @@ def test_batchnorm2d_train_fwd_bwd_matches_torch(pkg):
         assert float((rmd.cpu() - rm).abs().max()) < 1e-5 and float((rvd.cpu() - rv).abs().max()) < 2e-5
         dxd, dresd = torch.empty_like(xd), torch.empty_like(xd)
         dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
-        pkg._lib.check(lib.mh_bn2d_bwd(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr(), gd.data_ptr(), sm.data_ptr(),
+        pkg._lib.check(lib.mh_bn2d_bwd(dyd.data_ptr(), xd.data_ptr(), yd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sm.data_ptr(),
                                        sr.data_ptr(), dxd.data_ptr(), dresd.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), M, C,
                                        int(relu), 1.0, st), "bn2d_bwd")
+        if relu and not res:      # the mask recomputed from x (y = NULL) is the mask read from y: identical results
+            dx2, dg2, db2 = torch.empty_like(xd), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+            pkg._lib.check(lib.mh_bn2d_bwd(dyd.data_ptr(), xd.data_ptr(), None, gd.data_ptr(), bd.data_ptr(), sm.data_ptr(),
+                                           sr.data_ptr(), dx2.data_ptr(), None, dg2.data_ptr(), db2.data_ptr(), ws.data_ptr(), M, C,
+                                           int(relu), 1.0, st), "bn2d_bwd")
+            assert torch.equal(dx2, dxd) and torch.equal(dg2, dg) and torch.equal(db2, db)
         scale = float(xr.grad.abs().max())
         assert float((_nchw(dxd, B, H, W) - xr.grad).abs().max()) < 6e-3 * scale + 1e-3
         assert float((dg.cpu() - gr.grad).abs().max()) < 5e-3 * float(gr.grad.abs().max()) + 1e-2
