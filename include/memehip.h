@@ -200,6 +200,10 @@ typedef struct MhAttnProblem {
 } MhAttnProblem;
 int mh_attn_fwd_grouped(const MhAttnProblem* problems /*host*/, int n, mh_stream_t stream);
 int mh_attn_bwd_grouped(const MhAttnProblem* problems /*host*/, int n, mh_stream_t stream);
+/* backward of 129..224-token heads without mask / dropout / packing (the ViT tower): 1 = ONE pass per head (five products per
+ * block pair, dQ summed across key blocks through LDS mailboxes in a fixed order), 2 = the same with the text tower's sweeps in
+ * the same launch when two problems are grouped (default; env MEMEHIP_ATTN_ONEPASS), 0 = the dQ sweep + dK/dV sweep */
+int mh_attn_set_onepass(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Padding-free text tower.  BertModel computes every padded position and then ignores it (the keys are masked,

@@ -122,6 +122,7 @@ _PROTOS = {
     "mh_attn_bwd": [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_attn_fwd_grouped": [C.POINTER(MhAttnProblem), c_int, c_void_p],
     "mh_attn_bwd_grouped": [C.POINTER(MhAttnProblem), c_int, c_void_p],
+    "mh_attn_set_onepass": [c_int],
     "mh_attn_fwd_packed": [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_attn_bwd_packed": [c_void_p] * 9 + [c_int, c_int, c_int, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_pack_plan": [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p],

@@ -788,6 +788,199 @@ __global__ __launch_bounds__(448) void attn_bwd_merged_dual_kernel(const AttnArg
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// backward in ONE pass for a head of 129..224 rows (ViT-B/16: 197 tokens = 7 blocks of 32), no mask / dropout / packing.
+// Five products per (query block, key block) pair instead of the seven of the dQ sweep + dK/dV sweep, one exponential per
+// score instead of two, every operand read from HBM once.
+//   * the head's Q and dO (row + transposed images) and K (transposed image) stay in LDS: 5 x 28 KiB; the registers already
+//     hold this kernel to one workgroup per CU, so the LDS is free to use;
+//   * wave w owns KEY block w (K, V fragments, dK and dV accumulators in registers) AND QUERY block w (dQ accumulator);
+//   * step j = 0..6: wave w takes query block (w + j) mod 7 -- all seven waves on different query blocks --: S = Q K^T,
+//     dP = dO V^T, P, dS; dV += dO^T P and dK += Q^T dS as in the dK/dV sweep; dS (16-bit, the very values dK consumed) goes
+//     to the query block owner's mailbox in LDS; after the barrier each wave adds K_src^T dS^T of the message it received
+//     (from key block (w - j) mod 7) to its dQ.  A query block's seven messages arrive in a fixed order, so dQ is summed in a
+//     fixed order: deterministic, no atomics.
+// delta = rowsum(dO o O) is computed while staging, in the dQ kernel's summation order (bit-identical), and published.
+// ----------------------------------------------------------------------------------------------
+constexpr int OP_NB = 7, OP_ROWS = OP_NB * 32, OP_IMG = OP_ROWS * 128;     // 224 rows, 28 KiB per image
+constexpr int OP_MB_PITCH = 72, OP_MB = 32 * OP_MB_PITCH;                    // mailbox [32 queries][32 keys] 16-bit, 72-B rows (conflict-free b64 reads)
+constexpr int OP_LDS = 5 * OP_IMG + OP_NB * OP_MB + 2 * OP_ROWS * 4;
+
+MH_DEV void attn_bwd_onepass_body(const AttnArgs& A, const int bh, char* smem) {
+    const h16* __restrict__ qkv = A.qkv;
+    const h16* __restrict__ outp = A.out;
+    const h16* __restrict__ dout = A.dout;
+    const float* __restrict__ lse = A.lse;
+    float* __restrict__ delta = A.delta;
+    h16* __restrict__ dqkv = A.dqkv;
+    const int S = A.S, H = A.H;
+    const int b = bh / H, hh = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const size_t pitch = (size_t)3 * H * HD;
+    const size_t r0 = (size_t)b * S;
+    const int Sb = S;
+    const h16* qb = qkv + r0 * pitch + hh * HD;
+    const h16* kb = qb + (size_t)H * HD;
+    const h16* vb = qb + (size_t)2 * H * HD;
+    const h16* dob = dout + r0 * H * HD + hh * HD;
+    const float c = 0.125f * LOG2E;
+
+    char* q_img = smem;
+    char* qt_img = smem + OP_IMG;
+    char* do_img = smem + 2 * OP_IMG;
+    char* dot_img = smem + 3 * OP_IMG;
+    char* kt_img = smem + 4 * OP_IMG;
+    char* mbox = smem + 5 * OP_IMG;
+    float* lse_t = (float*)(mbox + OP_NB * OP_MB);
+    float* dl_t = lse_t + OP_ROWS;
+
+    for (int q = tid; q < OP_ROWS * 8; q += 448) {
+        const int r = q >> 3, ch = q & 7;
+        i32x4 vq = {0, 0, 0, 0}, vd = {0, 0, 0, 0}, vk = {0, 0, 0, 0};
+        if (r < Sb) {
+            vq = *(const i32x4*)(qb + (size_t)r * pitch + ch * 8);
+            vd = *(const i32x4*)(dob + (size_t)r * H * HD + ch * 8);
+            vk = *(const i32x4*)(kb + (size_t)r * pitch + ch * 8);
+        }
+        *(i32x4*)(q_img + row_img_off(r, ch)) = vq;
+        *(i32x4*)(qt_img + tr_img_off(r, ch >> 1) + ((ch & 1) << 4)) = vq;
+        *(i32x4*)(do_img + row_img_off(r, ch)) = vd;
+        *(i32x4*)(dot_img + tr_img_off(r, ch >> 1) + ((ch & 1) << 4)) = vd;
+        *(i32x4*)(kt_img + tr_img_off(r, ch >> 1) + ((ch & 1) << 4)) = vk;
+    }
+    {   // two threads per query row (448 = 2 x 224): dims 16 s + 8 hf + j, s-major, then the two halves added -- the dQ kernel's order
+        const int i = tid >> 1, hf = tid & 1;
+        float dl = 0.f;
+        if (i < Sb) {
+            const h16* dr = dob + (size_t)i * H * HD + 8 * hf;
+            const h16* orow = outp + (r0 + i) * (size_t)H * HD + hh * HD + 8 * hf;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                Pack8 a, o;
+                a.v = *(const i32x4*)(dr + 16 * s4);
+                o.v = *(const i32x4*)(orow + 16 * s4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)a.h[j] * (float)o.h[j];
+            }
+        }
+        dl += __shfl_xor(dl, 1, 64);
+        if (hf == 0) {
+            dl_t[i] = dl;
+            // rows past S: lse = +big makes P = exp2(-big) = 0, so they add nothing
+            lse_t[i] = i < Sb ? lse[((size_t)b * H + hh) * S + i] * LOG2E : 1.0e30f;
+            if (i < Sb) delta[((size_t)b * H + hh) * S + i] = dl;
+        }
+    }
+    __syncthreads();
+
+    const int wk0 = wave * 32;
+    const bool mine = wk0 < Sb;                    // this wave's key / query block holds rows (uniform per wave)
+    h16x8 kf[4], vf[4];
+    load_rows_frag(kb, pitch, wk0, Sb, lane, kf);
+    load_rows_frag(vb, pitch, wk0, Sb, lane, vf);
+    const float kbias = (wk0 + (lane & 31)) < Sb ? 0.f : NEG_BIG;
+    f32x16 dk[2], dv[2], dq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { dk[i][g] = 0.f; dv[i][g] = 0.f; dq[i][g] = 0.f; }
+
+    for (int j = 0; j < OP_NB; ++j) {
+        int qblk = wave + j;
+        if (qblk >= OP_NB) qblk -= OP_NB;
+        const int q0 = qblk * 32;
+        if (mine && q0 < Sb) {
+            f32x16 st, dp;  // rows = queries (register), cols = keys (lane)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { st[g] = 0.f; dp[g] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = MH_MFMA_32x32x16(frag_rows(q_img, q0, s, lane), kf[s], st, 0, 0, 0);
+                dp = MH_MFMA_32x32x16(frag_rows(do_img, q0, s, lane), vf[s], dp, 0, 0, 0);
+            }
+            f32x16 pp;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *(const f32x4*)(lse_t + q0 + 8 * g4 + 4 * h);
+                const f32x4 d4 = *(const f32x4*)(dl_t + q0 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int g = 4 * g4 + e;
+                    const float pr = __builtin_amdgcn_exp2f(st[g] * c + kbias - l4[e]);
+                    pp[g] = pr;
+                    st[g] = pr * (dp[g] - d4[e]);   // dS (unscaled)
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const h16x8 pf = acc_frag(pp, s);
+                const h16x8 df = acc_frag(st, s);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = MH_MFMA_32x32x16(frag_tr(dot_img, q0, s, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = MH_MFMA_32x32x16(frag_tr(qt_img, q0, s, dt * 32, lane), df, dk[dt], 0, 0, 0);
+                }
+            }
+            // dS -> the query block owner's mailbox, [query][key] 16-bit (the same rounding acc_frag applied for dK)
+            char* mb = mbox + qblk * OP_MB + (lane & 31) * 2;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *(h16*)(mb + (8 * g4 + 4 * h + e) * OP_MB_PITCH) = (h16)st[4 * g4 + e];
+        }
+        __syncthreads();
+        int src = wave - j;
+        if (src < 0) src += OP_NB;
+        if (mine && src * 32 < Sb) {     // dQ^T += K_src^T dS^T: lane = query, registers j = keys 16 s + 8 (j >> 2) + 4 h + (j & 3)
+            const char* mb = mbox + wave * OP_MB + (lane & 31) * OP_MB_PITCH;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                union {
+                    struct { i32x2 lo, hi; } v;
+                    h16x8 f;
+                } u;
+                u.v.lo = *(const i32x2*)(mb + (16 * s + 4 * h) * 2);
+                u.v.hi = *(const i32x2*)(mb + (16 * s + 8 + 4 * h) * 2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = MH_MFMA_32x32x16(frag_tr(kt_img, src * 32, s, dt * 32, lane), u.f, dq[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();     // the mailboxes are free for the next step's messages
+    }
+    if (!mine) return;
+    store_rows_from_T(dqkv + r0 * pitch + hh * HD, pitch, wk0, Sb, lane, dq, 0.125f);
+    store_rows_from_T(dqkv + r0 * pitch + (size_t)H * HD + hh * HD, pitch, wk0, Sb, lane, dk, 0.125f);
+    store_rows_from_T(dqkv + r0 * pitch + (size_t)2 * H * HD + hh * HD, pitch, wk0, Sb, lane, dv, 1.0f);
+}
+
+__global__ __launch_bounds__(448) void attn_bwd_onepass_kernel(const AttnArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_bwd_onepass_body(A, blockIdx.x, smem);
+}
+// one launch for both towers: [one pass of A | dQ of B | dK,dV of B] (every workgroup is given the one-pass kernel's LDS)
+template <int RES_B, bool DROP_B>
+__global__ __launch_bounds__(448) void attn_bwd_onepass_dual_kernel(const AttnArgs A, const AttnArgs Bp, const int nA, const int nB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int y = blockIdx.y;
+    if (y < nA) {
+        attn_bwd_onepass_body(A, y, smem);
+    } else {
+        if (threadIdx.x >= 256) return;
+        if (y < nA + nB) attn_bwd_dq_body<4, RES_B, DROP_B>(Bp, 0, 1, y - nA, smem);
+        else attn_bwd_dkv_body<4, RES_B, DROP_B, true>(Bp, 0, 1, y - nA - nB, smem);
+    }
+}
+// The text heads' two sweeps (problem B of the dual launch) when problem A runs the one-pass kernel: roles [dQ | dK,dV]
+template <int RES_B, bool DROP_B>
+__global__ __launch_bounds__(256) void attn_bwd_merged_single_kernel(const AttnArgs Bp, const int nB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int y = blockIdx.y;
+    if (y < nB) attn_bwd_dq_body<4, RES_B, DROP_B>(Bp, 0, 1, y, smem);
+    else attn_bwd_dkv_body<4, RES_B, DROP_B, true>(Bp, 0, 1, y - nB, smem);
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------
 // resident when S <= 256 (NT_RES = 2 for S <= 128, else 4); the 32-row tiles of a head are dealt to
 // `split` workgroups of 4 waves (split chosen so that every wave has work and the grid fills 256 CUs)
@@ -832,6 +1025,16 @@ bool fwd_seven_waves() {
         v = e ? atoi(e) : 1;
     }
     return v != 0;
+}
+// one-pass backward for 129..224-token heads (default on); mh_attn_set_onepass(0) / MEMEHIP_ATTN_ONEPASS=0 restore the two sweeps
+int g_onepass = -1;
+bool onepass_on() {
+    if (g_onepass < 0) {
+        const char* e = getenv("MEMEHIP_ATTN_ONEPASS");
+        g_onepass = e ? atoi(e) : 2;      // 2 = both towers in ONE launch (attn_bwd_onepass_dual_kernel; default), 1 = two launches
+        // (same box, 60 steps, two repetitions, ms per step: two sweeps 9.98 / 10.00, one pass in two launches 9.95 / 9.99, in one launch 9.90 / 9.85)
+    }
+    return g_onepass != 0;
 }
 int split_for(int S) {
     const int tiles32 = (S + 31) / 32;
@@ -905,11 +1108,24 @@ void launch_fwd(const MhAttnProblem& p, hipStream_t s) {
     else ATTN_LAUNCH(attn_fwd_kernel, 4, 0, dim3((S + 127) / 128, BH), lds_fwd(0), a);
 }
 
+bool onepass_fits(const MhAttnProblem& p) {
+    return onepass_on() && p.S > 128 && p.S <= OP_ROWS && !p.key_mask && !p.cu && !has_drop(p);
+}
+void launch_onepass(const AttnArgs& a, int BH, hipStream_t s) {
+    static bool once = (set_lds(attn_bwd_onepass_kernel, OP_LDS), true);
+    (void)once;
+    hipLaunchKernelGGL(attn_bwd_onepass_kernel, dim3(BH), dim3(448), OP_LDS, s, a);
+}
+
 void launch_bwd(const MhAttnProblem& p, hipStream_t s) {
     const AttnArgs a = to_args(p);
     const bool dr = has_drop(p);
     const int S = p.S, BH = p.B * p.H;
     const int rmax = bwd_resident_max();
+    if (onepass_fits(p)) {
+        launch_onepass(a, BH, s);
+        return;
+    }
     if (S <= 128 && S <= rmax) {
         const dim3 grid(split_for(S), BH);
         ATTN_LAUNCH(attn_bwd_dq_kernel, 4, 2, grid, lds_dq(2), a);
@@ -991,7 +1207,32 @@ extern "C" int mh_attn_bwd_grouped(const MhAttnProblem* p, int n, mh_stream_t st
         const int nA = p[ia].B * p[ia].H, nB = p[ib].B * p[ib].H;
         const bool dr = has_drop(p[ib]);
         const int mode = bwd_merged_mode();
-        if (mode == 0) {
+        if (onepass_fits(p[ia])) {
+            // ViT heads: one pass, one workgroup per head; text heads: their two sweeps as the roles of one launch
+            constexpr int L = cmax(lds_dq(2), lds_dkv(2));
+            if (g_onepass == 2) {
+                if (dr) {
+                    static bool o7 = (set_lds(attn_bwd_onepass_dual_kernel<2, true>, OP_LDS), true);
+                    (void)o7;
+                    hipLaunchKernelGGL((attn_bwd_onepass_dual_kernel<2, true>), dim3(1, nA + 2 * nB), dim3(448), OP_LDS, s, A, Bp, nA, nB);
+                } else {
+                    static bool o8 = (set_lds(attn_bwd_onepass_dual_kernel<2, false>, OP_LDS), true);
+                    (void)o8;
+                    hipLaunchKernelGGL((attn_bwd_onepass_dual_kernel<2, false>), dim3(1, nA + 2 * nB), dim3(448), OP_LDS, s, A, Bp, nA, nB);
+                }
+                return mh_launch_status();
+            }
+            launch_onepass(A, nA, s);
+            if (dr) {
+                static bool o5 = (set_lds(attn_bwd_merged_single_kernel<2, true>, L), true);
+                (void)o5;
+                hipLaunchKernelGGL((attn_bwd_merged_single_kernel<2, true>), dim3(1, 2 * nB), dim3(256), L, s, Bp, nB);
+            } else {
+                static bool o6 = (set_lds(attn_bwd_merged_single_kernel<2, false>, L), true);
+                (void)o6;
+                hipLaunchKernelGGL((attn_bwd_merged_single_kernel<2, false>), dim3(1, 2 * nB), dim3(256), L, s, Bp, nB);
+            }
+        } else if (mode == 0) {
             const dim3 grid(1, nA + nB);
             ATTN_LAUNCH_DUAL(attn_bwd_dq_dual_kernel, cmax(lds_dq(0), lds_dq(2)), grid, A, Bp, nA);
             ATTN_LAUNCH_DUAL(attn_bwd_dkv_dual_kernel, cmax(lds_dkv(0), lds_dkv(2)), grid, A, Bp, nA);
@@ -1025,6 +1266,11 @@ extern "C" int mh_attn_bwd_grouped(const MhAttnProblem* p, int n, mh_stream_t st
         for (int i = 0; i < n; ++i) launch_bwd(p[i], s);
     }
     return mh_launch_status();
+}
+
+extern "C" int mh_attn_set_onepass(int on) {
+    g_onepass = on;
+    return MH_OK;
 }
 
 static MhAttnProblem one_problem(const void* qkv, const int64_t* key_mask, const void* out, float* lse, const void* dout,

@@ -80,8 +80,9 @@ struct LnFwdGroup {
 // grouped launch: workgroups [start[j], start[j+1]) normalise job j's rows, 8 rows per workgroup: every wave takes TWO
 // rows and has both rows' loads in flight before the first reduction (the kernel is a latency chain load -> reduce ->
 // reduce -> store; a second independent chain per wave hides half of it)
-constexpr int LN_FWD_ROWS_PER_WG = 8;
-template <int NCH>
+// RPW rows per wave (2 or 4), 4 waves per workgroup: with 4 rows a wave amortises its gamma / beta loads (6 KB of f32 per
+// wave against 1.5 KB per 16-bit row at D = 768) over twice the rows and has twice the bytes in flight
+template <int NCH, int RPW>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp, int D) {
     int j = 0;
     while (j + 1 < grp.n && (int)blockIdx.x >= grp.start[j + 1]) ++j;
@@ -96,22 +97,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp, int D
     const int rows = jb.rows_dev ? min(jb.rows, *jb.rows_dev) : jb.rows;
     const float eps = jb.eps;
     const int lane = threadIdx.x & 63;
-    const int row0 = ((int)blockIdx.x - grp.start[j]) * LN_FWD_ROWS_PER_WG + (threadIdx.x >> 6) * 2;
+    const int row0 = ((int)blockIdx.x - grp.start[j]) * (4 * RPW) + (threadIdx.x >> 6) * RPW;
     if (row0 >= rows) return;
-    const bool two = row0 + 1 < rows;
-    i32x4 raw0[NCH], raw1[NCH];
-    load_row_raw<NCH>(x + (size_t)row0 * D, D, lane, raw0);
-    load_row_raw<NCH>(x + (size_t)(two ? row0 + 1 : row0) * D, D, lane, raw1);
+    i32x4 raw[RPW][NCH];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) load_row_raw<NCH>(x + (size_t)min(row0 + r, rows - 1) * D, D, lane, raw[r]);
     float g[NCH][8], b[NCH][8];
     load_row_f32<NCH>(gamma, D, lane, g);
     load_row_f32<NCH>(beta, D, lane, b);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (r == 1 && !two) break;
+    for (int r = 0; r < RPW; ++r) {
         const int row = row0 + r;
+        if (row >= rows) break;
         float v[NCH][8];
-        if (r == 0) unpack_row<NCH>(raw0, v);
-        else unpack_row<NCH>(raw1, v);
+        unpack_row<NCH>(raw[r], v);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
@@ -265,16 +264,19 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LnBwdGroup grp, 
         for (int i = 0; i < NCH; ++i) {
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = pass == 0 ? dg[i][e] : db[i][e];
+            // (lane l's element e sits at l*8 + (e ^ ((l >> 2) & 7)): with the plain l*8 + e the 32 lanes of a ds_write_b32
+            //  group hit 4 banks -- 8-way conflicts, 23 % of this kernel's LDS cycles; the XOR spreads them over all 32)
+            for (int e = 0; e < 8; ++e) red[wave][lane * 8 + (e ^ ((lane >> 2) & 7))] = pass == 0 ? dg[i][e] : db[i][e];
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 8 / NWV; ++k) {
                 const int cidx = threadIdx.x + NWV * 64 * k;  // = l*8+e
                 const int col = (cidx >> 3) * 8 + 64 * 8 * i + (cidx & 7);
+                const int sidx = (cidx & ~7) | ((cidx & 7) ^ ((cidx >> 5) & 7));
                 if (col < D) {
                     float s = 0.f;
 #pragma unroll
-                    for (int w = 0; w < NWV; ++w) s += red[w][cidx];
+                    for (int w = 0; w < NWV; ++w) s += red[w][sidx];
                     (pass == 0 ? pg : pb)[col] = s;
                 }
             }
@@ -322,18 +324,24 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs j
 
 }  // namespace
 
-#define LN_DISPATCH(NAME, ...)                                          \
-    do {                                                                \
-        const int nch = (D / 8 + 63) / 64;                              \
-        if (nch <= 1) hipLaunchKernelGGL((NAME<1>), __VA_ARGS__);       \
-        else if (nch <= 2) hipLaunchKernelGGL((NAME<2>), __VA_ARGS__);  \
-        else if (nch <= 4) hipLaunchKernelGGL((NAME<4>), __VA_ARGS__);  \
-        else hipLaunchKernelGGL((NAME<8>), __VA_ARGS__);                \
+#define LN_FWD_GO(RPW_)                                                                                 \
+    do {                                                                                                \
+        const int nch = (D / 8 + 63) / 64;                                                              \
+        if (nch <= 1) hipLaunchKernelGGL((ln_fwd_kernel<1, RPW_>), dim3(blocks), dim3(256), 0, s, g, D);       \
+        else if (nch <= 2) hipLaunchKernelGGL((ln_fwd_kernel<2, RPW_>), dim3(blocks), dim3(256), 0, s, g, D);  \
+        else if (nch <= 4) hipLaunchKernelGGL((ln_fwd_kernel<4, RPW_>), dim3(blocks), dim3(256), 0, s, g, D);  \
+        else hipLaunchKernelGGL((ln_fwd_kernel<8, RPW_>), dim3(blocks), dim3(256), 0, s, g, D);                \
     } while (0)
 
 extern "C" int mh_layernorm_fwd_grouped(const MhLnFwdJob* jobs, int n_jobs, int D, mh_stream_t stream) {
     if (!jobs || n_jobs < 1 || n_jobs > MH_LN_MAX_JOBS) return MH_EINVAL;
     if (D < 8 || (D % 8) || D > 4096) return MH_ESHAPE;
+    static int rpw = -1;      // rows per wave: 2; MEMEHIP_LN_FWD_RPW=4 (D <= 1024) for A/B runs
+    if (rpw < 0) {
+        const char* e = getenv("MEMEHIP_LN_FWD_RPW");
+        rpw = (e && atoi(e) == 4) ? 4 : 2;      // (measured, tools/ln_probe.py, 6304 rows: 2 rows 9.6 us, 4 rows 12.5 us)
+    }
+    const int use_rpw = (rpw == 4 && D <= 1024) ? 4 : 2;
     LnFwdGroup g;
     g.n = n_jobs;
     int blocks = 0;
@@ -343,11 +351,12 @@ extern "C" int mh_layernorm_fwd_grouped(const MhLnFwdJob* jobs, int n_jobs, int 
         if (jb.rows < 1) return MH_ESHAPE;
         g.job[i] = jb;
         g.start[i] = blocks;
-        blocks += (jb.rows + LN_FWD_ROWS_PER_WG - 1) / LN_FWD_ROWS_PER_WG;
+        blocks += (jb.rows + 4 * use_rpw - 1) / (4 * use_rpw);
     }
     for (int i = n_jobs; i <= MH_LN_MAX_JOBS; ++i) g.start[i] = blocks;
     hipStream_t s = (hipStream_t)stream;
-    LN_DISPATCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, s, g, D);
+    if (use_rpw == 4) LN_FWD_GO(4);
+    else LN_FWD_GO(2);
     return mh_launch_status();
 }
 
