@@ -525,8 +525,13 @@ typedef struct MhConvGeom {
     int32_t KH, KW, stride, pad;
     int32_t Cout, ldk;             /* filters; row pitch of the packed weights (multiple of 64, >= KH*KW*C) */
 } MhConvGeom;
-int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_part, const MhConvGeom* g, mh_stream_t stream);
-int mh_conv_dgrad(const void* dy, const void* wk, void* dx, const MhConvGeom* g, mh_stream_t stream);
+/* workspace (forward, dgrad): NULL, or f32 [mh_conv_splitk(g, dgrad)][rows][columns] of the OUTPUT (rows x columns = B*Ho*Wo x Cout
+ * forward, B*H*W x C dgrad).  With it, a convolution whose tile count leaves most CUs idle and whose contraction is long (ResNet-50's
+ * last two stages at batch 32: 52-98 tiles of 32-72 K steps) is cut into that many K chunks -- f32 slabs summed in slab order by a
+ * finishing launch that also rounds, stores and leaves the BatchNorm partials.  mh_conv_splitk returns 1 when no split is taken. */
+int mh_conv_splitk(const MhConvGeom* g, int dgrad);
+int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_part, float* workspace, const MhConvGeom* g, mh_stream_t stream);
+int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* workspace, const MhConvGeom* g, mh_stream_t stream);
 int mh_conv_wgrad(const void* dy, const void* x, float* slabs, int ksplit, float alpha, const MhConvGeom* g, mh_stream_t stream);
 /* mh_bn2d_fwd in training mode from statistics partials part[2][C][nblk] produced elsewhere (mh_conv_fwd): finish + apply */
 int mh_bn2d_fwd_parts(const void* x, const float* part, int nblk, const float* gamma, const float* beta, float* running_mean,

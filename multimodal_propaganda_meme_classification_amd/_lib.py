@@ -173,8 +173,9 @@ _PROTOS = {
     "mh_conv_weight_unpack": [c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p],
     "mh_conv_weight_pack_batched": [C.POINTER(MhConvPackJob), c_int, c_void_p],
     "mh_conv_wgrad_finish_batched": [C.POINTER(MhConvWgradJob), c_int, c_void_p],
-    "mh_conv_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
-    "mh_conv_dgrad": [c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
+    "mh_conv_splitk": [C.POINTER(MhConvGeom), c_int],
+    "mh_conv_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
+    "mh_conv_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
     "mh_conv_wgrad": [c_void_p, c_void_p, c_void_p, c_int, c_float, C.POINTER(MhConvGeom), c_void_p],
     "mh_bn2d_fwd_parts": [c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_int, c_void_p],
     "mh_bn2d_workspace_elems": [c_int, c_int],

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvAr
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
     int ks = 0;
-    if (MODE == MODE_WGRAD) {
+    if (MODE == MODE_WGRAD || a.nsplit > 1) {
         const int per = a.tiles_m * a.tiles_n;
         ks = t / per;
         t -= ks * per;
@@ -92,8 +92,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvAr
         tm = g * a.group_m + (r - tn * rows);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = (MODE == MODE_WGRAD) ? ks * a.kchunk : 0;
-    const int kend = (MODE == MODE_WGRAD) ? min(a.K, kbeg + a.kchunk) : a.K;
+    const bool split = (MODE == MODE_WGRAD) || a.nsplit > 1;      // f32 slab per K chunk, summed by a finishing launch
+    const int kbeg = split ? ks * a.kchunk : 0;
+    const int kend = split ? min(a.K, kbeg + a.kchunk) : a.K;
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,8 +150,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvAr
         }
     }
 
-    // wave-uniform tap walk of the K tiles (fwd / dgrad; K starts at 0)
+    // wave-uniform tap walk of the K tiles (fwd / dgrad), from this split's first K tile
     int u_kh = 0, u_kw = 0, u_c0 = 0;
+    if (UNI && MODE != MODE_WGRAD && kbeg > 0) {
+        const int tap = kbeg / a.C;
+        u_c0 = kbeg - tap * a.C;
+        u_kh = tap / a.KW;
+        u_kw = tap - u_kh * a.KW;
+    }
     auto issue = [&](int kt, char* st) {
         char* la = st;
         char* lb = st + BM * BK * 2;
@@ -248,8 +255,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvAr
                 cs[cs_index(wm0 + i * 16 + (lane >> 4) * 4 + r, wn0 + j * 16 + (lane & 15))] = acc[i][j][r];
     __syncthreads();
     const float alpha = a.alpha;
-    if (MODE == MODE_WGRAD) {
-        float* slab = (float*)a.out + (size_t)ks * (size_t)a.M * (size_t)a.ldc;
+    if (split) {
+        float* slab = (float*)(MODE == MODE_WGRAD ? a.out : (void*)a.part) + (size_t)ks * (size_t)a.M * (size_t)a.ldc;
 #pragma unroll
         for (int it = 0; it < BM * 16 / (NW * 64); ++it) {
             const int q = it * NW * 64 + tid;
@@ -302,6 +309,68 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvAr
     }
 }
 
+// split-K forward / dgrad: y = 16-bit(sum of the f32 slabs, in slab order); with `part`, the BatchNorm partial sums of the stored
+// values per 128-row block (what the unsplit epilogue leaves).  Block = 128 rows x 64 columns: thread (ty = row lane of 32, tx = 8
+// columns), 4 rows each; column sums through LDS in row-lane order.
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ slabs, int nsplit, h16* __restrict__ y,
+                                                                 float* __restrict__ part, int M, int N, int tiles_m) {
+    __shared__ float red[32][2][64];
+    const int blk = blockIdx.x, n0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int col = n0 + tx * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (col < N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = blk * 128 + ty + 32 * i;
+            if (r >= M) break;
+            const float* src = slabs + (size_t)r * N + col;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < nsplit; ++k, src += (size_t)M * N) {
+                a0 += *(const f32x4*)src;
+                a1 += *(const f32x4*)(src + 4);
+            }
+            Pack8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o.e[e] = mh_f2bf(a0[e]); o.e[4 + e] = mh_f2bf(a1[e]); }
+            *(i32x4*)(y + (size_t)r * N + col) = o.v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = mh_bf2f(o.e[e]);
+                s[e] += v;
+                q[e] += v * v;
+            }
+        }
+    }
+    if (!part) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[ty][0][tx * 8 + e] = s[e]; red[ty][1][tx * 8 + e] = q[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float v = 0.f;
+        for (int r = 0; r < 32; ++r) v += red[r][which][c];
+        if (n0 + c < N) part[((size_t)which * N + n0 + c) * tiles_m + blk] = v;
+    }
+}
+
+// K chunks for the forward / input gradient of a convolution whose tile count leaves most CUs idle (ResNet-50's last two stages
+// at batch 32: 52-98 tiles of 32-72 K steps): enough chunks for ~256 workgroups, never fewer than 8 K steps per chunk
+int splitk_for(int tiles, int K) {
+    const int nk = K / BK;
+    if (tiles * 2 > 256 || nk < 16) return 1;
+    int sp = 256 / tiles;
+    if (sp > nk / 8) sp = nk / 8;
+    if (sp > 8) sp = 8;
+    for (; sp > 1; --sp) {      // every chunk must hold K tiles (chunk = ceil(nk / sp) tiles)
+        const int kc = (nk + sp - 1) / sp;
+        if ((nk + kc - 1) / kc == sp) break;
+    }
+    return sp < 1 ? 1 : sp;
+}
+
 template <int MODE, bool UNI>
 int conv_launch(const ConvArgs& a, hipStream_t s) {
     static bool attr_set = false;
@@ -340,7 +409,39 @@ int group_m_setting() {
 
 }  // namespace
 
-extern "C" int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_part, const MhConvGeom* g, mh_stream_t stream) {
+extern "C" int mh_conv_splitk(const MhConvGeom* g, int dgrad) {
+    int Ho, Wo;
+    if (geom_check(g, Ho, Wo) != MH_OK) return 1;
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("MEMEHIP_CONV_SPLITK");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (!on) return 1;
+    const int M = dgrad ? g->B * g->H * g->W : g->B * Ho * Wo, N = dgrad ? g->C : g->Cout;
+    const int K = dgrad ? g->KH * g->KW * g->Cout : g->ldk;
+    const bool uni = dgrad ? true : ((g->C % BK) == 0 && g->ldk == g->KH * g->KW * g->C);
+    if (!uni) return 1;
+    return splitk_for(((M + BM - 1) / BM) * ((N + BN - 1) / BN), K);
+}
+
+namespace {
+int finish_split(const ConvArgs& a, void* y, float* bn_part, hipStream_t s) {
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(a.tiles_m, (a.N + 63) / 64), dim3(256), 0, s, (const float*)a.part, a.nsplit, (h16*)y,
+                       bn_part, a.M, a.N, a.tiles_m);
+    return mh_launch_status();
+}
+void set_split(ConvArgs& a, int nsplit, float* workspace) {
+    const int nk = a.K / BK;
+    a.nsplit = nsplit;
+    a.kchunk = (nk + nsplit - 1) / nsplit * BK;
+    a.total_tiles = a.tiles_m * a.tiles_n * nsplit;
+    a.part = workspace;          // the split kernel writes its f32 slabs here ([nsplit][M][ldc = N])
+}
+}  // namespace
+
+extern "C" int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_part, float* workspace, const MhConvGeom* g,
+                           mh_stream_t stream) {
     int Ho, Wo;
     const int st = geom_check(g, Ho, Wo);
     if (st != MH_OK) return st;
@@ -365,10 +466,17 @@ extern "C" int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_par
     a.alpha = 1.f;
     a.inv_wo = 1.0f / (float)Wo; a.inv_howo = 1.0f / (float)(Ho * Wo);
     const bool uni = (g->C % BK) == 0 && g->ldk == g->KH * g->KW * g->C;
+    const int nsplit = workspace ? mh_conv_splitk(g, 0) : 1;
+    if (nsplit > 1) {       // few tiles, long K: K chunks into f32 slabs, then sum + 16-bit store + BatchNorm partials
+        set_split(a, nsplit, workspace);
+        const int st2 = conv_launch<MODE_FWD, true>(a, (hipStream_t)stream);
+        if (st2 != MH_OK) return st2;
+        return finish_split(a, y, bn_part, (hipStream_t)stream);
+    }
     return uni ? conv_launch<MODE_FWD, true>(a, (hipStream_t)stream) : conv_launch<MODE_FWD, false>(a, (hipStream_t)stream);
 }
 
-extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, const MhConvGeom* g, mh_stream_t stream) {
+extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* workspace, const MhConvGeom* g, mh_stream_t stream) {
     int Ho, Wo;
     const int st = geom_check(g, Ho, Wo);
     if (st != MH_OK) return st;
@@ -395,6 +503,13 @@ extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, const MhC
     a.kchunk = 0; a.nsplit = 1;
     a.alpha = 1.f;
     a.inv_wo = 1.0f / (float)a.Wo; a.inv_howo = 1.0f / (float)(a.Ho * a.Wo);
+    const int nsplit = workspace ? mh_conv_splitk(g, 1) : 1;
+    if (nsplit > 1) {
+        set_split(a, nsplit, workspace);
+        const int st2 = conv_launch<MODE_DGRAD, true>(a, (hipStream_t)stream);
+        if (st2 != MH_OK) return st2;
+        return finish_split(a, dx, nullptr, (hipStream_t)stream);
+    }
     return conv_launch<MODE_DGRAD, true>(a, (hipStream_t)stream);
 }
 

@@ -78,8 +78,11 @@ class _Conv:
         M = B * Ho * Wo
         y = torch.empty((M, self.cout), dtype=T16, device=x.device)
         part = torch.empty((2, self.cout, (M + 127) // 128), dtype=F32, device=x.device) if want_stats else None
-        check(lib.mh_conv_fwd(x.data_ptr(), wk.data_ptr(), y.data_ptr(), None if part is None else part.data_ptr(), self.geom(B, H, W),
-                              _stream()), "mh_conv_fwd")
+        geom = self.geom(B, H, W)
+        sp = int(lib.mh_conv_splitk(geom, 0))          # > 1: a few-tile, long-contraction layer is cut into K chunks (f32 slabs)
+        ws = torch.empty((sp, M, self.cout), dtype=F32, device=x.device) if sp > 1 else None
+        check(lib.mh_conv_fwd(x.data_ptr(), wk.data_ptr(), y.data_ptr(), None if part is None else part.data_ptr(),
+                              None if ws is None else ws.data_ptr(), geom, _stream()), "mh_conv_fwd")
         return y, part, Ho, Wo
 
     def _wgrad(self, lib, dy, x, B, H, W, Ho, Wo, gscale):
@@ -113,13 +116,17 @@ class _Conv:
         wjobs.append((self, slabs, sp, dy, x))
         if not need_dx:
             return None
-        if self.direct:
+        if self.direct and self.cout % 64:
             dx = torch.empty((M, self.cp), dtype=dy.dtype, device=dev)
             ops.gemm_grouped([ops.Gemm(dy, wk, dx, M, self.ldk, self.cout, self.cout, self.ldk, self.ldk)], False, True)
             return dx
         dx = torch.empty((B * H * W, self.cp), dtype=dy.dtype, device=dev)
         if self.stride == 1 and self.kh == self.kw and self.cout % 64 == 0:
-            check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), self.geom(B, H, W), _stream()), "mh_conv_dgrad")
+            geom = self.geom(B, H, W)
+            sp = int(lib.mh_conv_splitk(geom, 1))
+            ws = torch.empty((sp, B * H * W, self.cp), dtype=F32, device=dev) if sp > 1 else None
+            check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, _stream()),
+                  "mh_conv_dgrad")
             return dx
         dA = torch.empty((M, self.ldk), dtype=dy.dtype, device=dev)
         ops.gemm_grouped([ops.Gemm(dy, wk, dA, M, self.ldk, self.cout, self.cout, self.ldk, self.ldk)], False, True)

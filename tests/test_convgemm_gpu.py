@@ -73,7 +73,7 @@ def test_implicit_conv_forward_and_bn_partials_are_exact_on_integers(pkg, T16):
         nblk = (M + 127) // 128
         part = torch.full((2, Cout, nblk), -1.0, dtype=F32, device="cuda")
         geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
-        pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y.data_ptr(), part.data_ptr(), geom, st), "mh_conv_fwd")
+        pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y.data_ptr(), part.data_ptr(), None, geom, st), "mh_conv_fwd")
         assert torch.equal(_nchw(y, B, Ho, Wo), ref), (B, C, H, W, Cout, k, s, p)
         rows = ref.permute(0, 2, 3, 1).reshape(M, Cout)
         pad_rows = torch.zeros((nblk * 128, Cout))
@@ -83,7 +83,7 @@ def test_implicit_conv_forward_and_bn_partials_are_exact_on_integers(pkg, T16):
         assert torch.equal(part[1].cpu(), (blocks * blocks).sum(1).t().contiguous())
         # without the statistics request the output is the same
         y2 = torch.empty_like(y)
-        pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y2.data_ptr(), None, geom, st), "mh_conv_fwd")
+        pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y2.data_ptr(), None, None, geom, st), "mh_conv_fwd")
         assert torch.equal(y, y2)
 
 
@@ -96,7 +96,7 @@ def test_implicit_conv_input_gradient_is_exact_on_integers(pkg, T16):
         if s != 1 or Cout % 64:
             geom = _geom(pkg, B, H, W, C, k, s, p, Cout, (k * k * C + 63) // 64 * 64)
             d = torch.zeros(16, dtype=T16, device="cuda")
-            assert lib.mh_conv_dgrad(d.data_ptr(), d.data_ptr(), d.data_ptr(), geom, st) == 2       # MH_ESHAPE: the explicit path serves it
+            assert lib.mh_conv_dgrad(d.data_ptr(), d.data_ptr(), d.data_ptr(), None, geom, st) == 2       # MH_ESHAPE: the explicit path serves it
             continue
         x = torch.zeros((B, C, H, W), requires_grad=True)
         w = torch.randint(-2, 3, (Cout, C, k, k), generator=g).float()
@@ -109,7 +109,7 @@ def test_implicit_conv_input_gradient_is_exact_on_integers(pkg, T16):
         dyd = _nhwc(dy, T16)
         dx = torch.full((B * H * W, C), 7.0, dtype=T16, device="cuda")
         geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
-        pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), geom, st), "mh_conv_dgrad")
+        pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None, geom, st), "mh_conv_dgrad")
         assert torch.equal(_nchw(dx, B, H, W), x.grad.to(T16).float()), (B, C, H, W, Cout, k, s, p)
 
 
@@ -159,7 +159,7 @@ def test_implicit_conv_equals_the_explicit_im2col_path_bit_for_bit(pkg):
     ops.gemm_grouped([ops.Gemm(col, wk, y_ref, M, Cout, ldk, ldk, ldk, Cout)], False, False)
     y = torch.empty_like(y_ref)
     geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
-    pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y.data_ptr(), None, geom, st), "mh_conv_fwd")
+    pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y.data_ptr(), None, None, geom, st), "mh_conv_fwd")
     assert torch.equal(y, y_ref)
     # against the fp32 oracle the error is the 16-bit rounding of the operands and of the result
     ref = F.conv2d(x.to(F16).float(), w.to(F16).float(), stride=s, padding=p)
@@ -176,10 +176,52 @@ def test_implicit_conv_equals_the_explicit_im2col_path_bit_for_bit(pkg):
     dx_ref = torch.empty((B * H * W, C), dtype=F16, device="cuda")
     pkg._lib.check(lib.mh_col2im_nhwc(dcol.data_ptr(), dx_ref.data_ptr(), B, H, W, C, k, k, s, p, ldk, st), "col2im")
     dx = torch.empty_like(dx_ref)
-    pkg._lib.check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), geom, st), "mh_conv_dgrad")
+    pkg._lib.check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), None, geom, st), "mh_conv_dgrad")
     xr = x.to(F16).float().requires_grad_(True)
     F.conv2d(xr, w.to(F16).float(), stride=s, padding=p).backward(_nchw(dy, B, Ho, Wo))
     scale = float(xr.grad.abs().max())
     e_imp = float((_nchw(dx, B, H, W) - xr.grad).abs().max())
     e_exp = float((_nchw(dx_ref, B, H, W) - xr.grad).abs().max())
     assert e_imp < 1.5e-3 * scale and e_imp <= e_exp * 1.05
+
+
+@pytest.mark.parametrize("T16", [F16, BF16])
+def test_split_k_forward_and_dgrad_equal_the_unsplit_kernels_on_integers(pkg, T16):
+    """Deep, few-tile layers (ResNet-50 layer3 / layer4 at batch 32) are cut into K chunks: on integers the slab sum is exact, so the
+    split results -- output, BatchNorm partials, input gradient -- must equal the unsplit ones bit for bit (and torch's conv2d)."""
+    lib = pkg._lib.load("fp16" if T16 == F16 else "bf16")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(15)
+    for (B, C, H, W, Cout, k, s, p) in ((2, 512, 7, 7, 512, 3, 1, 1), (3, 256, 14, 14, 256, 3, 1, 1), (2, 2048, 7, 7, 512, 1, 1, 0), (4, 256, 14, 14, 256, 3, 2, 1)):
+        x = torch.randint(-1, 2, (B, C, H, W), generator=g).float()
+        w = torch.randint(-1, 2, (Cout, C, k, k), generator=g).float()
+        xr = x.clone().requires_grad_(True)
+        yr = F.conv2d(xr, w, stride=s, padding=p)
+        Ho, Wo = yr.shape[2], yr.shape[3]
+        M, ldk = B * Ho * Wo, k * k * C
+        xd, wk = _nhwc(x, T16), _pack(pkg, lib, w, C, ldk, T16)
+        geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
+        sp = int(lib.mh_conv_splitk(geom, 0))
+        assert sp > 1, (B, C, H, W, Cout, k, s, p)
+        nblk = (M + 127) // 128
+        outs = []
+        for ws in (None, torch.empty((sp, M, Cout), dtype=F32, device="cuda")):
+            y = torch.full((M, Cout), 7.0, dtype=T16, device="cuda")
+            part = torch.full((2, Cout, nblk), -1.0, dtype=F32, device="cuda")
+            pkg._lib.check(lib.mh_conv_fwd(xd.data_ptr(), wk.data_ptr(), y.data_ptr(), part.data_ptr(), None if ws is None else ws.data_ptr(), geom, st), "fwd")
+            outs.append((y, part))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert torch.equal(_nchw(outs[1][0], B, Ho, Wo), yr.detach().to(T16).float())
+        if s != 1:
+            continue
+        dy = torch.randint(-1, 2, yr.shape, generator=g).float()
+        yr.backward(dy)
+        dyd = _nhwc(dy, T16)
+        spd = int(lib.mh_conv_splitk(geom, 1))
+        assert spd > 1 or k == 1          # (the 1x1 layer's input gradient contracts over 512 filters only: too short to cut)
+        res = []
+        for ws in (None, torch.empty((max(spd, 1), B * H * W, C), dtype=F32, device="cuda")):
+            dx = torch.full((B * H * W, C), 7.0, dtype=T16, device="cuda")
+            pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, st), "dgrad")
+            res.append(dx)
+        assert torch.equal(res[0], res[1]) and torch.equal(_nchw(res[1], B, H, W), xr.grad.to(T16).float())
