@@ -112,6 +112,15 @@ int mh_gemm_ksplit_for(int K, int want);
  * two groups of four waves (64x64 per wave), accumulators merged in the epilogue (both measured slower or equal: DESIGN.md 5.1).
  * Default 4 (or env MEMEHIP_GEMM_VARIANT at first launch). */
 int mh_gemm_set_variant(int variant);
+/* STREAM-K for the forward / dgrad layouts (default kernel variant only; A/B switch, OFF by default -- measured slower on this
+ * path's shapes, gemm.hip): 512 workgroups, each a contiguous piece of its XCD's tile run measured in K ITERATIONS; the pieces of a
+ * cut tile are accumulated from zero in parallel, the workgroup holding the tile's last K step adds the others' accumulator images
+ * (stored in the workspace) in a fixed order and runs the epilogue -- deterministic, exact on integers, not the unsplit rounding.
+ * mode: 0 off, 1 where the launch's shape says it pays, 2 every launch that can.  workspace: device memory of
+ * mh_gemm_streamk_workspace_bytes() bytes, its last 2112 bytes (the flags) ZERO, alive for as long as the mode is on; the launches
+ * that use it must be ordered on ONE stream. */
+int64_t mh_gemm_streamk_workspace_bytes(void);
+int mh_gemm_set_streamk(void* workspace, int mode);
 /* profiling knob: device buffer of 4 x uint64 per workgroup of the largest launch; the default kernel records 100-MHz stamps per
  * workgroup {entry, first K stage landed, main loop done, epilogue stores issued}; NULL = off (tools/gemm_timeline.py) */
 int mh_gemm_set_trace(void* device_buffer);

@@ -113,6 +113,8 @@ _PROTOS = {
     "mh_gemm_set_trace": [c_void_p],
     "mh_gemm_set_variant": [c_int],
     "mh_gemm_ksplit_for": [c_int, c_int],
+    "mh_gemm_streamk_workspace_bytes": [],
+    "mh_gemm_set_streamk": [c_void_p, c_int],
     "mh_layernorm_fwd": [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p],
     "mh_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_layernorm_fwd_grouped": [C.POINTER(MhLnFwdJob), c_int, c_int, c_void_p],
@@ -199,7 +201,8 @@ _PROTOS = {
     "mh_version": [],
     "mh_status_str": [c_int],
 }
-_RESTYPES = {"mh_version": C.c_char_p, "mh_status_str": C.c_char_p, "mh_bn2d_workspace_elems": c_int64}
+_RESTYPES = {"mh_version": C.c_char_p, "mh_status_str": C.c_char_p, "mh_bn2d_workspace_elems": c_int64,
+             "mh_gemm_streamk_workspace_bytes": c_int64}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

@@ -32,6 +32,8 @@ struct GemmGroup {
     int total_tiles;
     int group_m;      // L2 blocking of the tile order: GROUP_M row panels are swept column by column (0/1: n-fastest)
     int xcd_balance;  // 1: every XCD gets its share of EVERY problem (problems whose tiles differ in length: the weight gradients of both towers)
+    float* sk_partial;           // stream-K (gemm_sk_kernel): one accumulator image (512 threads x 32 f32) per workgroup
+    unsigned* sk_flags;          //   [0..grid): "workgroup b's partial is stored"; [grid]: spin time-out marker
     unsigned long long* trace;   // debug (mh_gemm_set_trace): per workgroup 4 x 100-MHz stamps {entry, first stage landed, main loop done, stores issued}
     DevProblem d[MH_GEMM_MAX_GROUP];
 };
@@ -1426,7 +1428,214 @@ __global__ __launch_bounds__(512, 4) void gemm_persist_kernel(const GemmGroup g)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// STREAM-K form of the default kernel (K-contiguous A: forward and dgrad; same tile, waves, LDS-DMA stages, epilogue).
+// BUILT, VERIFIED, MEASURED SLOWER, OFF BY DEFAULT (mh_gemm_set_streamk; tools/gemm_sk_check.py, profiles/r03_gemm_streamk.txt):
+// +12..+33 % on every shape of this path, also on the single-round long-K launches it was built for (402 tiles x 48 K steps on
+// 512 slots: 60 -> 72 us).  In the tile-per-workgroup launch the ~50 tiles an XCD runs at once walk K IN STEP, so every operand
+// panel chunk is fetched into the XCD's L2 once and shared by the tiles of its row / column; pieces that start at different K
+// offsets lose that (6.3 MB of A panels + 4.7 MB of B per XCD against a 4 MB L2), and what the idle slots would have returned
+// goes to L2 misses.
+// The launches of this path have 402 / 1206 / 1608 tiles for 512 resident workgroups: 0.79 / 2.36 / 3.14 rounds, every one paying
+// for a whole last round (tools/gemm_timeline.py).  Here exactly 512 workgroups (two per CU) are launched and the K ITERATIONS of
+// the launch, not its tiles, are dealt out evenly:
+//   * every XCD keeps the contiguous run of tiles the tile-per-workgroup kernel gives it (same L2 locality); the run's
+//     tiles x (K / 64) iterations are cut into 64 equal consecutive pieces, one per workgroup of that XCD;
+//   * a piece is [tail of a tile][whole tiles][head of a tile].  Every piece of a cut tile is accumulated FROM ZERO, in parallel;
+//     a workgroup that does not hold the tile's last K step stores its accumulator registers (a "partial": 64 KB, register image,
+//     coalesced) and raises a flag; the one that does adds the partials to its own, nearest first, and runs the epilogue.  (A
+//     first version kept the unsplit kernel's K order -- the second workgroup LOADED the first one's image and continued -- and
+//     was bit-identical to it, but a tile then still takes K / 64 sequential steps from the start of the launch: no gain, measured
+//     +19..+47 %.)  The sum order is fixed by the cut, the cut by the shapes and the live row count: deterministic, but not the
+//     unsplit kernel's rounding.
+//   * a workgroup runs its head piece FIRST, so partials are published early, then its tail and whole tiles; producers never wait;
+//     an owner only waits for workgroups below it on the same XCD, which were dispatched earlier: no cycle.
+//     The wait is a bounded relaxed poll by one lane + one agent-scope acquire (cdna_hip_programming.md Guideline 16); the
+//     partial is published by plain stores + vmcnt drain + barrier + one agent-scope release; the consumer clears the flag.
+//   * live rows of packed operands (rows_dev) are read first: tiles past them do not exist in the iteration space, so the
+//     balance holds for ragged batches.
+// All problems of the launch must share K (the grouped launches of the two towers do).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SK_GRID = 512;
+constexpr size_t SK_PARTIAL_FLOATS = 512 * 32;
+constexpr unsigned SK_SPIN_MAX = 1u << 22;
+
+template <int LB, bool DROP>
+__global__ __launch_bounds__(512, 4) void gemm_sk_kernel(const GemmGroup g) {
+    constexpr int NW = 8, NWN = 4, NI = 4, NJ = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / NWN) * (NI * 16), wn0 = (wave % NWN) * (NJ * 16);
+
+    // ---- the launch's tile list with the LIVE row counts, this XCD's run of it, this workgroup's piece of the run --------
+    int tstart[MH_GEMM_MAX_GROUP + 1], tm_live[MH_GEMM_MAX_GROUP];
+    int T = 0;
+#pragma unroll
+    for (int p = 0; p < MH_GEMM_MAX_GROUP; ++p) {
+        tstart[p] = T;
+        tm_live[p] = 0;
+        if (p < g.n) {
+            int M = g.d[p].p.M;
+            if (g.d[p].p.rows_dev) M = min(M, *g.d[p].p.rows_dev);
+            tm_live[p] = (M + BM - 1) / BM;
+            T += tm_live[p] * g.d[p].tiles_n;
+        }
+    }
+    tstart[MH_GEMM_MAX_GROUP] = T;
+    const int nk = g.d[0].p.K / BK;
+    const int x = blockIdx.x & 7, wi = blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    const int tq = T >> 3, tr = T & 7;
+    const int t_lo = x < tr ? x * (tq + 1) : tr * (tq + 1) + (x - tr) * tq;
+    const long long I = (long long)(tq + (x < tr ? 1 : 0)) * nk;
+    const long long it0 = I * wi / per_xcd, it1 = I * (wi + 1) / per_xcd;
+    const int f = (int)(it0 / nk), kf = (int)(it0 - (long long)f * nk);
+    const int l = (int)((it1 - 1) / nk), kl = (int)(it1 - (long long)l * nk);     // last tile of the piece, its K end (1..nk)
+
+    f32x4 acc[NI][NJ];
+    float* my_partial = g.sk_partial + (size_t)blockIdx.x * SK_PARTIAL_FLOATS;
+
+    // one segment: K tiles [kb, ke) of tile `ts` (index in this XCD's run)
+    auto segment = [&](int ts, int kb, int ke) {
+        // ---- which problem / tile ------------------------------------------------------------------------------------
+        const int t = t_lo + ts;
+        int pi = 0, ts0 = 0, tml = tm_live[0];
+#pragma unroll
+        for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
+            if (i < g.n && t >= tstart[i]) { pi = i; ts0 = tstart[i]; tml = tm_live[i]; }      // (no dynamic indexing: the arrays stay in SGPRs)
+        const MhGemmProblem& P = g.d[pi].p;
+        DevProblem dp;
+        dp.tiles_n = g.d[pi].tiles_n;
+        dp.tiles_m = tml;
+        int tm, tn;
+        tile_coords(dp, g.group_m, t - ts0, tm, tn);
+        const int m0 = tm * BM, n0 = tn * BN;
+        int M = P.M;
+        if (P.rows_dev) M = min(M, *P.rows_dev);
+        const int N = P.N, K = P.K;
+        const uint32_t a_bytes = (uint32_t)((M - 1) * P.lda + K) * 2u;
+        const uint32_t b_bytes = (LB == 0) ? (uint32_t)((N - 1) * P.ldb + K) * 2u : (uint32_t)((K - 1) * P.ldb + N) * 2u;
+        const __amdgpu_buffer_rsrc_t ra = mh_rsrc(P.A, a_bytes);
+        const __amdgpu_buffer_rsrc_t rb = mh_rsrc(P.B, b_bytes);
+
+        __syncthreads();        // the previous segment's epilogue is done with the LDS
+        // first stage on its way before anything else
+        dma_tile<0, 2>(ra, P.lda, m0, kb * BK, wave, lane, smem);
+        dma_tile<LB, 2>(rb, P.ldb, n0, kb * BK, wave, lane, smem + BM * BK * 2);
+
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- main loop over the K tiles of the segment (two LDS-DMA stages, one barrier per K tile) ----------------------
+        const int nks = ke - kb;
+        __syncthreads();
+        for (int kt = 0; kt < nks; ++kt) {
+            char* cur = smem + (kt & 1) * STAGE_BYTES;
+            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            if (kt + 1 < nks) {
+                dma_tile<0, 2>(ra, P.lda, m0, (kb + kt + 1) * BK, wave, lane, nxt);
+                dma_tile<LB, 2>(rb, P.ldb, n0, (kb + kt + 1) * BK, wave, lane, nxt + BM * BK * 2);
+            }
+            const char* la = cur;
+            const char* lb = cur + BM * BK * 2;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                h16x8 fa[NI], fb[NJ];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fa[i] = read_frag<0>(la, wm0 + i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = read_frag<LB>(lb, wn0 + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = MH_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+
+        if (ke < nk) {
+            // ---- not the end of the tile: publish the accumulator image for the workgroup that continues it ------------
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) *(f32x4*)(my_partial + ((size_t)(i * NJ + j) * 512 + tid) * 4) = acc[i][j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(g.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // ---- end of the tile.  The K range below kb was accumulated by the workgroups below this one (same XCD), each from zero
+        // and each published before its owner work began: add their images, nearest first (a fixed order), then the default
+        // kernel's epilogue
+        EpiPrefetch<BM, NW * 64> pf;
+        epilogue_prefetch<BM, NW * 64>(P, m0, n0, tid, M, pf);
+        if (kb > 0) {
+            long long need = (long long)ts * nk;          // first iteration of this tile in the XCD run
+            int pw = wi;
+            bool more = true;
+            while (more) {
+                --pw;
+                while (pw > 0 && I * pw / per_xcd >= I * (pw + 1) / per_xcd) --pw;      // (empty pieces publish nothing)
+                more = I * pw / per_xcd > need;         // this producer's piece begins inside the tile: another one lies below it
+                const int pb = pw * 8 + x;
+                unsigned* flag = g.sk_flags + pb;
+                if (tid == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > SK_SPIN_MAX) {      // never expected: give up loudly instead of hanging the GPU
+                            __hip_atomic_store(g.sk_flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // consumed: clean for the next launch
+                }
+                __syncthreads();
+                const float* src = g.sk_partial + (size_t)pb * SK_PARTIAL_FLOATS;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] += *(const f32x4*)(src + ((size_t)(i * NJ + j) * 512 + tid) * 4);
+            }
+        }
+        float* cs = (float*)smem;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cs[cs_index(wm0 + i * 16 + (lane >> 4) * 4 + r, wn0 + j * 16 + (lane & 15))] = acc[i][j][r];
+        __syncthreads();
+        epilogue_rows<BM, NW * 64, DROP, true>(P, cs, m0, n0, tid, M, &pf);
+    };
+
+    if (I < 8LL * per_xcd) {        // few live tiles (a ragged batch): pieces shorter than 8 K steps are not worth their hand-offs --
+        for (int ts = wi; (long long)ts * nk < I; ts += per_xcd) segment(ts, 0, nk);       // whole tiles, dealt round-robin
+        return;
+    }
+    if (f == l) {
+        segment(f, kf, kl);
+        return;
+    }
+    if (kl < nk) segment(l, 0, kl);                 // the head piece first: nobody waits longer than one segment for it
+    segment(f, kf, nk);
+    for (int ts = f + 1; ts < l; ++ts) segment(ts, 0, nk);
+    if (kl == nk) segment(l, 0, nk);
+}
+
 unsigned long long* g_trace = nullptr;      // mh_gemm_set_trace
+float* g_sk_partial = nullptr;                 // mh_gemm_set_streamk
+unsigned* g_sk_flags = nullptr;
+
 int g_variant = -1;  // -1: read MEMEHIP_GEMM_VARIANT once; 0 = register staging, 1 = LDS-DMA 4 waves, 2 = 256x128 ring,
                      // 3 = ping-pong ring, 4 = LDS-DMA 8 waves (default), 5 = LDS-DMA 16 waves
 
@@ -1582,8 +1791,46 @@ int launch_persist(const GemmGroup& g, hipStream_t s) {
     if (LB == 0 && any_drop) return launch_persist2<LB, true>(g, s);
     return launch_persist2<LB, false>(g, s);
 }
+template <int LB, bool DROP>
+int launch_sk2(const GemmGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_sk_kernel<LB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_sk_kernel<LB, DROP>), dim3(SK_GRID), dim3(512), LDS_BYTES, s, g);
+    return mh_launch_status();
+}
+template <int LB>
+int launch_sk(const GemmGroup& g, hipStream_t s) {
+    bool any_drop = false;
+    for (int i = 0; i < g.n; ++i) any_drop |= (g.d[i].p.drop_rng != nullptr && g.d[i].p.drop_p > 0.f);
+    if (LB == 0 && any_drop) return launch_sk2<LB, true>(g, s);
+    return launch_sk2<LB, false>(g, s);
+}
+// stream-K pays when the tile-per-workgroup launch wastes a good part of its last round of 512 workgroups: estimated times in K
+// steps of one workgroup (a tile costs nk steps + ~6 steps' worth of fill and epilogue; a cut tile ~4 more for the partial)
+int g_sk_mode = 0, g_sk_force = 0;      // mh_gemm_set_streamk: 0 off (default), 1 where the estimate says it pays, 2 every launch that can
+bool streamk_legal(const GemmGroup& g) {
+    for (int i = 0; i < g.n; ++i)
+        if (g.d[i].p.K != g.d[0].p.K || g.d[i].kchunk != 0 || g.d[i].p.rowsum) return false;
+    return true;
+}
+bool streamk_pays(const GemmGroup& g) {
+    const int nk = g.d[0].p.K / BK;
+    if (!streamk_legal(g)) return false;
+    // measured (tools/gemm_sk_check.py): launches of several rounds lose (a workgroup's consecutive tiles are no longer the
+    // neighbours of what the rest of its XCD is working on); the single-round, long-K launches are where the idle slots are
+    const double T = g.total_tiles;
+    if (T > SK_GRID || nk < 24) return false;
+    const double now = nk + 6.0, sk = T * nk / SK_GRID + 6.0 + 5.0;
+    return sk < 0.9 * now;
+}
 template <int LA, int LB>
 int launch(const GemmGroup& g, hipStream_t s) {
+    if (g_variant == 4 && LA == 0 && g.sk_partial != nullptr && (g_sk_force ? streamk_legal(g) : streamk_pays(g))) {
+        if constexpr (LA == 0) return launch_sk<LB>(g, s);
+    }
     if (g_variant == 9) {          // persistent, register epilogue: K-contiguous A without split-K; everything else = variant 4
         bool plain = (LA == 0);
         for (int i = 0; i < g.n; ++i) plain = plain && g.d[i].kchunk == 0 && g.d[i].p.rowsum == nullptr && (g.d[i].p.N % 4) == 0;
@@ -1686,6 +1933,8 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     }
     g.xcd_balance = (xcd_balance && g_variant == 4 && a_kmajor && n_problems > 1) ? 1 : 0;
     g.trace = g_trace;
+    g.sk_partial = g_sk_mode ? g_sk_partial : nullptr;
+    g.sk_flags = g_sk_flags;
     hipStream_t s = (hipStream_t)stream;
     if (wide) return b_kmajor ? launch_wide<1>(g, s) : launch_wide<0>(g, s);
     if (!a_kmajor && !b_kmajor) return launch<0, 0>(g, s);
@@ -1706,6 +1955,18 @@ extern "C" int mh_gemm_ksplit_for(int K, int want) {
 // 100-MHz stamps per workgroup {entry, first K stage landed, main loop done, epilogue stores issued}; NULL switches it off
 extern "C" int mh_gemm_set_trace(void* device_buffer) {
     g_trace = (unsigned long long*)device_buffer;
+    return MH_OK;
+}
+
+// stream-K workspace: (512 x 64 KB accumulator images + 513 flag words, the flags ZERO) in device memory that outlives every launch;
+// launches that use it must be ordered on one stream (the forward / dgrad chain is).  NULL switches stream-K off.
+extern "C" int64_t mh_gemm_streamk_workspace_bytes(void) { return (int64_t)(SK_GRID * SK_PARTIAL_FLOATS * 4 + (SK_GRID + 16) * 4); }
+extern "C" int mh_gemm_set_streamk(void* workspace, int mode) {
+    if (mode < 0 || mode > 2 || (mode > 0 && !workspace)) return MH_EINVAL;
+    g_sk_partial = (float*)workspace;
+    g_sk_flags = workspace ? (unsigned*)((char*)workspace + SK_GRID * SK_PARTIAL_FLOATS * 4) : nullptr;
+    g_sk_mode = workspace ? mode : 0;
+    g_sk_force = mode == 2;
     return MH_OK;
 }
 

@@ -2,6 +2,7 @@
 // 16-B accesses, grid-stride).  All per-step scalars come from DEVICE memory so a captured
 // hipGraph of the whole step can be replayed with new values.  See include/memehip.h.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -283,7 +284,20 @@ extern "C" int mh_adam_step(float* p, float* m, float* v, const float* g, void* 
     if (!p || !m || !v || !g || !hyper) return MH_EINVAL;
     if (n < 4 || (n & 3) || (n_shadow & 3) || n_shadow > n) return MH_ESHAPE;
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
+    // MEMEHIP_ADAM_BLOCKS (A/B switch): cap on the grid of a GUARDED launch, i.e. of a slice that runs on the side stream beside the
+    // backward's GEMMs -- a grid-stride loop, so fewer workgroups mean a slower, thinner stream of HBM traffic
+    static int cap = -1;
+    if (cap < 0) {
+        const char* e = getenv("MEMEHIP_ADAM_BLOCKS");
+        cap = e ? atoi(e) : 0;
+        if (cap < 0) cap = 0;
+    }
+    int grid = grid_for(n / 4);
+    if (cap > 0 && overflow) {
+        const int64_t b = (n / 4 + 255) / 256;
+        grid = (int)(b < cap ? b : cap);
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
                        (h16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm, overflow);
     return mh_launch_status();
 }

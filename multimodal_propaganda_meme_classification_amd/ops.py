@@ -31,8 +31,36 @@ def _kind(t: torch.Tensor) -> str:
     return "fp16" if t.dtype == F16 else "bf16"
 
 
+_STREAMK_WS = {}      # (library kind, device index) -> workspace tensor, kept for the life of the process
+
+
+def ensure_streamk(lib, kind: str, device, mode=None) -> None:
+    """Stream-K GEMM (mh_gemm_set_streamk) is OFF by default -- measured slower on this path's shapes (csrc/gemm.hip).
+    ``mode`` (or env MEMEHIP_GEMM_STREAMK) 1 / 2 allocates the workspace on this device (accumulator images of 512 workgroups +
+    zeroed flags, kept for the life of the process) and switches it on; 0 switches it off.  The library holds ONE workspace:
+    launches that use it must be stream-ordered -- the forward / dgrad chain is."""
+    import os
+    if mode is None:
+        mode = int(os.environ.get("MEMEHIP_GEMM_STREAMK", "0"))
+        if (kind, "env") in _STREAMK_WS:
+            return
+        _STREAMK_WS[(kind, "env")] = mode
+    if mode == 0:
+        if any(isinstance(k[1], int) for k in _STREAMK_WS if k[0] == kind):
+            check(lib.mh_gemm_set_streamk(None, 0), "mh_gemm_set_streamk")
+        return
+    dev = torch.device(device)
+    key = (kind, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _STREAMK_WS:
+        _STREAMK_WS[key] = torch.zeros(int(lib.mh_gemm_streamk_workspace_bytes()), dtype=torch.uint8, device=dev)
+    check(lib.mh_gemm_set_streamk(_STREAMK_WS[key].data_ptr(), int(mode)), "mh_gemm_set_streamk")
+
+
 def _L(t: torch.Tensor):
-    return _lib.load(_kind(t))
+    kind = _kind(t)
+    lib = _lib.load(kind)
+    ensure_streamk(lib, kind, t.device)
+    return lib
 
 
 def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
