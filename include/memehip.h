@@ -542,6 +542,18 @@ int mh_conv_splitk(const MhConvGeom* g, int dgrad);
 int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_part, float* workspace, const MhConvGeom* g, mh_stream_t stream);
 int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* workspace, const MhConvGeom* g, mh_stream_t stream);
 int mh_conv_wgrad(const void* dy, const void* x, float* slabs, int ksplit, float alpha, const MhConvGeom* g, mh_stream_t stream);
+/* the weight gradients of up to 6 convolutions in ONE launch (each alone is ~256 tiles: half of the 512 workgroup slots for ~26 us;
+ * the backward defers them and launches consecutive layers together, with fewer K chunks each) */
+#define MH_CONV_MAX_GROUP 6
+typedef struct MhConvWgradProblem {
+    const void* dy;      /* 16-bit [B*Ho*Wo][Cout] */
+    const void* x;       /* 16-bit [B][H][W][C] */
+    float* slabs;        /* f32 [ksplit][Cout][ldk] */
+    int32_t ksplit;
+    float alpha;
+    MhConvGeom geom;
+} MhConvWgradProblem;
+int mh_conv_wgrad_grouped(const MhConvWgradProblem* problems /*host*/, int n, mh_stream_t stream);
 /* mh_bn2d_fwd in training mode from statistics partials part[2][C][nblk] produced elsewhere (mh_conv_fwd): finish + apply */
 int mh_bn2d_fwd_parts(const void* x, const float* part, int nblk, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, const void* residual, void* y, float* save_mean, float* save_rstd, int M, int C, float eps,

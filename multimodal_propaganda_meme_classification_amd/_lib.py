@@ -54,6 +54,11 @@ class MhConvGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "KH", "KW", "stride", "pad", "Cout", "ldk")]
 
 
+class MhConvWgradProblem(C.Structure):
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("slabs", c_void_p), ("ksplit", C.c_int32), ("alpha", C.c_float), ("geom", MhConvGeom)]
+
+
+MH_CONV_MAX_GROUP = 6
 MH_CONV_MAX_JOBS = 64
 MH_BN_RELU, MH_BN_ACCUM_PARAM_GRADS = 1, 2
 
@@ -179,6 +184,7 @@ _PROTOS = {
     "mh_conv_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
     "mh_conv_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
     "mh_conv_wgrad": [c_void_p, c_void_p, c_void_p, c_int, c_float, C.POINTER(MhConvGeom), c_void_p],
+    "mh_conv_wgrad_grouped": [C.POINTER(MhConvWgradProblem), c_int, c_void_p],
     "mh_bn2d_fwd_parts": [c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_int, c_void_p],
     "mh_bn2d_workspace_elems": [c_int, c_int],
     "mh_bn2d_fwd": [c_void_p] * 10 + [c_int, c_int, c_float, c_float, c_int, c_int, c_void_p],

@@ -60,19 +60,33 @@ MH_DEV void pix_decomp(const ConvArgs& a, int m, int& b, int& po, int& qo) {
 }
 
 // UNI: C % 64 == 0 and K == taps * C, so a 64-deep K tile lies inside ONE tap and the tap walk is wave-uniform (scalar).
+// several convolutions in one launch (weight gradients of consecutive layers: each alone fills half the chip for 26 us)
+constexpr int CONV_MAX_GROUP = 6;
+struct ConvGroup {
+    int n, total_tiles;
+    int tile_start[CONV_MAX_GROUP];
+    ConvArgs a[CONV_MAX_GROUP];
+};
+
 template <int MODE, bool UNI>
-__global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGroup grp) {
     constexpr int LA = (MODE == MODE_WGRAD) ? 1 : 0;
     constexpr int LB = (MODE == MODE_FWD) ? 0 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     int t;
     {
-        const int nwg = a.total_tiles;
+        const int nwg = grp.total_tiles;
         const int b = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, x = b & 7;       // blocks b, b+8, ... share an XCD (and its L2): contiguous tile runs
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CONV_MAX_GROUP; ++i)
+        if (i < grp.n && t >= grp.tile_start[i]) pi = i;
+    const ConvArgs& a = grp.a[pi];
+    t -= grp.tile_start[pi];
     int ks = 0;
     if (MODE == MODE_WGRAD || a.nsplit > 1) {
         const int per = a.tiles_m * a.tiles_n;
@@ -372,14 +386,23 @@ int splitk_for(int tiles, int K) {
 }
 
 template <int MODE, bool UNI>
-int conv_launch(const ConvArgs& a, hipStream_t s) {
+int conv_launch_group(const ConvGroup& grp, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<MODE, UNI>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, UNI>), dim3(a.total_tiles), dim3(NW * 64), CONV_LDS, s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, UNI>), dim3(grp.total_tiles), dim3(NW * 64), CONV_LDS, s, grp);
     return mh_launch_status();
+}
+template <int MODE, bool UNI>
+int conv_launch(const ConvArgs& a, hipStream_t s) {
+    ConvGroup grp = {};
+    grp.n = 1;
+    grp.total_tiles = a.total_tiles;
+    grp.tile_start[0] = 0;
+    grp.a[0] = a;
+    return conv_launch_group<MODE, UNI>(grp, s);
 }
 
 int geom_check(const MhConvGeom* g, int& Ho, int& Wo) {
@@ -513,14 +536,14 @@ extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* wo
     return conv_launch<MODE_DGRAD, true>(a, (hipStream_t)stream);
 }
 
-extern "C" int mh_conv_wgrad(const void* dy, const void* x, float* slabs, int ksplit, float alpha, const MhConvGeom* g,
-                             mh_stream_t stream) {
+namespace {
+int wgrad_args(const void* dy, const void* x, float* slabs, int ksplit, float alpha, const MhConvGeom* g, ConvArgs& a) {
     int Ho, Wo;
     const int st = geom_check(g, Ho, Wo);
     if (st != MH_OK) return st;
     if (!dy || !x || !slabs || ksplit < 1) return MH_EINVAL;
     if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)slabs) & 15) return MH_EINVAL;
-    ConvArgs a = {};
+    a = ConvArgs{};
     a.src = (const h16*)x;
     a.reg = (const h16*)dy;
     a.out = slabs;
@@ -540,5 +563,29 @@ extern "C" int mh_conv_wgrad(const void* dy, const void* x, float* slabs, int ks
     a.group_m = group_m_setting();
     a.alpha = alpha == 0.f ? 1.f : alpha;
     a.inv_wo = 1.0f / (float)Wo; a.inv_howo = 1.0f / (float)(Ho * Wo);
+    return MH_OK;
+}
+}  // namespace
+
+extern "C" int mh_conv_wgrad(const void* dy, const void* x, float* slabs, int ksplit, float alpha, const MhConvGeom* g,
+                             mh_stream_t stream) {
+    ConvArgs a;
+    const int st = wgrad_args(dy, x, slabs, ksplit, alpha, g, a);
+    if (st != MH_OK) return st;
     return conv_launch<MODE_WGRAD, false>(a, (hipStream_t)stream);
+}
+
+extern "C" int mh_conv_wgrad_grouped(const MhConvWgradProblem* p, int n, mh_stream_t stream) {
+    if (!p || n < 1 || n > CONV_MAX_GROUP) return MH_EINVAL;
+    ConvGroup grp = {};
+    grp.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const int st = wgrad_args(p[i].dy, p[i].x, p[i].slabs, p[i].ksplit, p[i].alpha, &p[i].geom, grp.a[i]);
+        if (st != MH_OK) return st;
+        grp.tile_start[i] = total;
+        total += grp.a[i].total_tiles;
+    }
+    grp.total_tiles = total;
+    return conv_launch_group<MODE_WGRAD, false>(grp, (hipStream_t)stream);
 }

@@ -85,18 +85,20 @@ class _Conv:
                               None if ws is None else ws.data_ptr(), geom, _stream()), "mh_conv_fwd")
         return y, part, Ho, Wo
 
+    def _wgrad_split(self, lib, M, target):
+        tiles = ((self.cout + 127) // 128) * ((self.kh * self.kw * self.cp + 127) // 128)
+        want = max(1, min(64, -(-target // tiles), M // 256))
+        return max(1, lib.mh_gemm_ksplit_for(int(M), int(want)))
+
     def _wgrad(self, lib, dy, x, B, H, W, Ho, Wo, gscale):
         M = B * Ho * Wo
-        tiles = ((self.cout + 127) // 128) * ((self.kh * self.kw * self.cp + 127) // 128)
-        target = int(os.environ.get("MEMEHIP_WGRAD_TILES", 256))      # (512 / 384 / 256 / 192: 7.78 / 7.74 / 7.74 / 7.72 ms per step; 256 halves the slabs)
-        want = max(1, min(64, -(-target // tiles), M // 256))
-        sp = max(1, lib.mh_gemm_ksplit_for(int(M), int(want)))
+        sp = self._wgrad_split(lib, M, int(os.environ.get("MEMEHIP_WGRAD_TILES", 256)))      # (512 / 384 / 256 / 192: 7.78 / 7.74 / 7.74 / 7.72 ms per step; 256 halves the slabs)
         slabs = torch.empty((sp, self.cout, self.ldk), dtype=F32, device=dy.device)
         check(lib.mh_conv_wgrad(dy.data_ptr(), x.data_ptr(), slabs.data_ptr(), sp, 1.0 / gscale, self.geom(B, H, W), _stream()),
               "mh_conv_wgrad")
         return slabs, sp
 
-    def backward(self, lib, dy, x, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True, side=None):
+    def backward(self, lib, dy, x, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True, side=None, wq=None):
         """dy [M, cout] 16-bit -> dx [B*H*W, cp] 16-bit (or None); the weight gradient's split-K slabs are queued in `wjobs`
         (summed, un-packed and added to .grad for all convolutions at once at the end of the backward).  With `side`, the
         weight-gradient kernel -- which nothing later in the backward chain reads -- runs on that stream beside the input-gradient
@@ -111,9 +113,13 @@ class _Conv:
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 slabs, sp = self._wgrad(lib, dy, x, B, H, W, Ho, Wo, gscale)
+        elif wq is not None:      # deferred: consecutive layers' weight gradients go out together (flush_wgrads)
+            wq.append((self, dy, x, B, H, W, Ho, Wo))
+            slabs = None
         else:
             slabs, sp = self._wgrad(lib, dy, x, B, H, W, Ho, Wo, gscale)
-        wjobs.append((self, slabs, sp, dy, x))
+        if slabs is not None:
+            wjobs.append((self, slabs, sp, dy, x))
         if not need_dx:
             return None
         if self.direct and self.cout % 64:
@@ -133,6 +139,26 @@ class _Conv:
         check(lib.mh_col2im_nhwc(dA.data_ptr(), dx.data_ptr(), B, H, W, self.cp, self.kh, self.kw, self.stride, self.pad, self.ldk,
                                  _stream()), "mh_col2im_nhwc")
         return dx
+
+
+def flush_wgrads(lib, wq, wjobs, gscale):
+    """The deferred weight gradients of up to MH_CONV_MAX_GROUP convolutions as ONE launch (mh_conv_wgrad_grouped): alone each is
+    ~256 tiles -- half of the 512 workgroup slots for ~26 us, most of it fill / epilogue; together they fill the slots with fewer K
+    chunks (= fewer f32 slabs to write and sum) each."""
+    if not wq:
+        return
+    n = len(wq)
+    probs = (_lib.MhConvWgradProblem * n)()
+    target = max(48, 512 // n)
+    for i, (cv, dy, x, B, H, W, Ho, Wo) in enumerate(wq):
+        M = B * Ho * Wo
+        sp = cv._wgrad_split(lib, M, target)
+        slabs = torch.empty((sp, cv.cout, cv.ldk), dtype=F32, device=dy.device)
+        probs[i].dy, probs[i].x, probs[i].slabs = dy.data_ptr(), x.data_ptr(), slabs.data_ptr()
+        probs[i].ksplit, probs[i].alpha, probs[i].geom = sp, 1.0 / gscale, cv.geom(B, H, W)
+        wjobs.append((cv, slabs, sp, dy, x))
+    check(lib.mh_conv_wgrad_grouped(probs, n, _stream()), "mh_conv_wgrad_grouped")
+    wq.clear()
 
 
 class _BN:
@@ -349,12 +375,18 @@ class ResNet50(nn.Module):
                 self._side = torch.cuda.Stream()
             side = self._side
 
+        group = int(os.environ.get("MEMEHIP_WGRAD_GROUP", "4"))       # weight gradients launched together (1: one launch each)
+        group = max(1, min(group, _lib.MH_CONV_MAX_GROUP))
+        wq = [] if (group > 1 and side is None) else None
+
         def conv_bn_bwd(op, dy, want_dres, need_dx=True):
             _, cv, bn, A, wk, z, y, sm, sr, hh, ww, ho, wo, relu, has_res = op
             M = B * ho * wo
             # the ReLU mask: from y where a residual was added before the ReLU, recomputed from z otherwise (one tensor less to read)
             dz, dres = bn.backward(lib, dy, z, y if (relu and has_res) else None, sm, sr, M, relu, want_dres, self.gscale, grads)
-            dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx, side=side)
+            dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx, side=side, wq=wq)
+            if wq is not None and len(wq) >= group:
+                flush_wgrads(lib, wq, wjobs, self.gscale)
             return dxin, dres
 
         while i >= 0:
@@ -393,6 +425,8 @@ class ResNet50(nn.Module):
             raise AssertionError(kind)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+        if wq:
+            flush_wgrads(lib, wq, wjobs, self.gscale)
         for i0 in range(0, len(wjobs), _lib.MH_CONV_MAX_JOBS):
             chunk = wjobs[i0:i0 + _lib.MH_CONV_MAX_JOBS]
             jobs = (_lib.MhConvWgradJob * len(chunk))()
