@@ -31,7 +31,7 @@ struct GemmGroup {
     int n;
     int total_tiles;
     int group_m;      // L2 blocking of the tile order: GROUP_M row panels are swept column by column (0/1: n-fastest)
-    int xcd_balance;  // 1: every XCD gets its share of EVERY problem (problems whose tiles differ in length: the weight gradients of both towers)
+    int pad_;
     float* sk_partial;           // stream-K (gemm_sk_kernel): one accumulator image (512 threads x 32 f32) per workgroup
     unsigned* sk_flags;          //   [0..grid): "workgroup b's partial is stored"; [grid]: spin time-out marker
     unsigned long long* trace;   // debug (mh_gemm_set_trace): per workgroup 4 x 100-MHz stamps {entry, first stage landed, main loop done, stores issued}
@@ -261,39 +261,18 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     // ---- which tile ----------------------------------------------------------------------------
     trace_stamp(g, 0);
     const int nwg = g.total_tiles;
-    int pi = 0, lt;
-    if (g.xcd_balance) {
-        // XCD x (= blockIdx & 7) runs, in dispatch order, its contiguous share of problem 0, then of problem 1, ...: problems listed
-        // longest tiles first start first everywhere and the short ones fill in behind.  Problem p's T_p % 8 left-over tiles go to
-        // the XCDs after those that took problem p-1's, so every XCD ends up with exactly the blocks the grid gives it.
-        const int x = blockIdx.x & 7;
-        int i = blockIdx.x >> 3, off = 0;
-        lt = 0;
-        for (int p = 0; p < g.n; ++p) {
-            const int T = (p + 1 < g.n ? g.d[p + 1].tile_start : nwg) - g.d[p].tile_start;
-            const int q = T >> 3, r = T & 7, xr = (x - off) & 7;
-            const int mine = q + (xr < r ? 1 : 0);
-            if (i < mine) {
-                pi = p;
-                lt = xr * q + min(xr, r) + i;
-                break;
-            }
-            i -= mine;
-            off = (off + r) & 7;
-        }
-    } else {
-        int t;
-        {
-            const int b = blockIdx.x;
-            const int q = nwg >> 3, r = nwg & 7, x = b & 7;
-            t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        }
-#pragma unroll
-        for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
-            if (i < g.n && t >= g.d[i].tile_start) pi = i;
-        lt = t - g.d[pi].tile_start;
+    int t;
+    {
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
+        if (i < g.n && t >= g.d[i].tile_start) pi = i;
     const MhGemmProblem& P = g.d[pi].p;
+    int lt = t - g.d[pi].tile_start;
     // split-K: the problem's tiles are replicated ksplit times; split s contracts over [s * kchunk, (s+1) * kchunk) and
     // writes its own f32 partial output at C + s * split_stride (summed by the caller: mh_colsum_partials_f32)
     const int kchunk = g.d[pi].kchunk;
@@ -1921,17 +1900,10 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
         if (group_m < 0 || group_m > 64) group_m = 8;
     }
     g.group_m = group_m;
-    // MEMEHIP_GEMM_XCD_BALANCE=1 (A/B switch, default off): in a weight-gradient launch of several problems every XCD takes its share
-    // of EVERY problem instead of one contiguous run of the whole tile list.  Built for both towers' weight gradients in ONE launch
-    // (MEMEHIP_WGRAD_ONE_LAUNCH=1); measured in the step, same box: one launch 11.18-11.22 ms with or without the balanced shares
-    // against 10.16-10.25 ms for a launch per tower -- an 864-tile side-stream launch holds every workgroup slot for ~150 us and
-    // starves the main chain; the two 432-tile launches leave 80 slots free.  Both switches stay off.
-    static int xcd_balance = -1;
-    if (xcd_balance < 0) {
-        const char* e = getenv("MEMEHIP_GEMM_XCD_BALANCE");
-        xcd_balance = (e && atoi(e) == 1) ? 1 : 0;
-    }
-    g.xcd_balance = (xcd_balance && g_variant == 4 && a_kmajor && n_problems > 1) ? 1 : 0;
+    // (round 3: a tile -> XCD mapping that gave every XCD its share of EVERY problem of a launch -- for both towers' weight gradients
+    //  in ONE launch, MEMEHIP_WGRAD_ONE_LAUNCH=1 -- was built and measured: 11.18-11.22 ms per step with or without it against
+    //  10.16-10.25 ms for a launch per tower; removed again, its branch in the prologue changed the default kernel's code)
+    g.pad_ = 0;
     g.trace = g_trace;
     g.sk_partial = g_sk_mode ? g_sk_partial : nullptr;
     g.sk_flags = g_sk_flags;
