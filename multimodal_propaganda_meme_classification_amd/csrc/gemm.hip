@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_kernel(const GemmGroup g
     int M = P.M, K = P.K;
     const int N = P.N;
     if (P.rows_dev) {   // packed (padding-free) token rows: the live row count is only known on the device
-        const int live = *P.rows_dev;
+        const int live = __builtin_amdgcn_readfirstlane(*P.rows_dev);      // (uniform: a VGPR here puts the operand's buffer resource in VGPRs and a waterfall loop around every LDS-DMA load)
         if (LA == 0) {
             M = min(M, live);
             if (m0 >= M) return;     // whole tile past the live rows (uniform per workgroup)
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_ring_kernel(const GemmGroup
     int M = P.M, K = P.K;
     const int N = P.N;
     if (P.rows_dev) {
-        const int live = *P.rows_dev;
+        const int live = __builtin_amdgcn_readfirstlane(*P.rows_dev);      // (uniform: a VGPR here puts the operand's buffer resource in VGPRs and a waterfall loop around every LDS-DMA load)
         if (LA == 0) {
             M = min(M, live);
             if (m0 >= M) return;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_pp_kernel(const GemmGroup g
     int M = P.M, K = P.K;
     const int N = P.N;
     if (P.rows_dev) {
-        const int live = *P.rows_dev;
+        const int live = __builtin_amdgcn_readfirstlane(*P.rows_dev);      // (uniform: a VGPR here puts the operand's buffer resource in VGPRs and a waterfall loop around every LDS-DMA load)
         if (LA == 0) {
             M = min(M, live);
             if (m0 >= M) return;
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(512, 4) void gemm_s4_kernel(const GemmGroup g) {
     int M = P.M, K = P.K;
     const int N = P.N;
     if (P.rows_dev) {
-        const int live = *P.rows_dev;
+        const int live = __builtin_amdgcn_readfirstlane(*P.rows_dev);      // (uniform: a VGPR here puts the operand's buffer resource in VGPRs and a waterfall loop around every LDS-DMA load)
         if (LA == 0) {
             M = min(M, live);
             if (m0 >= M) return;
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(512, 4) void gemm_wide_kernel(const GemmGroup g) {
     int M = P.M;
     const int N = P.N, K = P.K;
     if (P.rows_dev) {
-        M = min(M, *P.rows_dev);
+        M = min(M, __builtin_amdgcn_readfirstlane(*P.rows_dev));
         if (m0 >= M) return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(512, 4) void gemm_persist_kernel(const GemmGroup g)
         T.m0 = tm * BM;
         T.n0 = tn * BN;
         T.M = P.M;
-        if (P.rows_dev) T.M = min(T.M, *P.rows_dev);      // packed token rows: the live row count is only known on the device
+        if (P.rows_dev) T.M = min(T.M, __builtin_amdgcn_readfirstlane(*P.rows_dev));      // packed token rows: the live row count is only known on the device
         T.nk = P.K / BK;
         return T;
     };
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(512, 4) void gemm_sk_kernel(const GemmGroup g) {
         tm_live[p] = 0;
         if (p < g.n) {
             int M = g.d[p].p.M;
-            if (g.d[p].p.rows_dev) M = min(M, *g.d[p].p.rows_dev);
+            if (g.d[p].p.rows_dev) M = min(M, __builtin_amdgcn_readfirstlane(*g.d[p].p.rows_dev));
             tm_live[p] = (M + BM - 1) / BM;
             T += tm_live[p] * g.d[p].tiles_n;
         }
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(512, 4) void gemm_sk_kernel(const GemmGroup g) {
         tile_coords(dp, g.group_m, t - ts0, tm, tn);
         const int m0 = tm * BM, n0 = tn * BN;
         int M = P.M;
-        if (P.rows_dev) M = min(M, *P.rows_dev);
+        if (P.rows_dev) M = min(M, __builtin_amdgcn_readfirstlane(*P.rows_dev));
         const int N = P.N, K = P.K;
         const uint32_t a_bytes = (uint32_t)((M - 1) * P.lda + K) * 2u;
         const uint32_t b_bytes = (LB == 0) ? (uint32_t)((N - 1) * P.ldb + K) * 2u : (uint32_t)((K - 1) * P.ldb + N) * 2u;
