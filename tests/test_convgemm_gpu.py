@@ -53,6 +53,10 @@ CASES = [
     (2, 8, 20, 18, 64, 7, 2, 3),
     (1, 24, 7, 9, 16, 3, 1, 1),
     (5, 64, 14, 14, 64, 3, 1, 1),
+    (1, 16, 6, 5, 24, 5, 1, 2),       # 5x5, padding 2, one image
+    (3, 64, 4, 4, 64, 3, 1, 1),       # 4x4 images: every window touches the padding
+    (2, 72, 9, 9, 40, 3, 3, 0),       # stride 3, no padding, channel counts that are multiples of 8 only
+    (1, 128, 3, 3, 128, 3, 1, 0),     # one output pixel per image
 ]
 
 
