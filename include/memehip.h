@@ -540,7 +540,22 @@ typedef struct MhConvGeom {
  * finishing launch that also rounds, stores and leaves the BatchNorm partials.  mh_conv_splitk returns 1 when no split is taken. */
 int mh_conv_splitk(const MhConvGeom* g, int dgrad);
 int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_part, float* workspace, const MhConvGeom* g, mh_stream_t stream);
-int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* workspace, const MhConvGeom* g, mh_stream_t stream);
+/* bn (dgrad, or NULL): the BatchNorm2d (+ReLU, no residual) whose OUTPUT is this convolution's input.  dx is then that BatchNorm's
+ * dy: the epilogue masks it by the ReLU (recomputed from z as the forward computed it), stores the MASKED gradient and leaves the
+ * per-128-row-tile column sums part[2][C][ceil(B*H*W / 128)] = sum g', sum g' xhat -- the BatchNorm backward's statistics pass
+ * over (dy, z) disappears: mh_bn2d_bwd_parts(dx, ...) finishes the sums and applies. */
+typedef struct MhConvBnBwd {
+    const void* z;                               /* 16-bit [B*H*W][C]: the BatchNorm's input */
+    const float *mean, *rstd, *gamma, *beta;     /* f32 [C] */
+    float* part;                                 /* f32 [2][C][ceil(B*H*W / 128)] */
+    int32_t relu, reserved_;
+} MhConvBnBwd;
+int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* workspace, const MhConvGeom* g, const MhConvBnBwd* bn,
+                  mh_stream_t stream);
+/* BatchNorm2d backward from mh_conv_dgrad's partial sums: dy is ALREADY masked; finish (dgamma, dbeta, sums) + apply (dx) */
+int mh_bn2d_bwd_parts(const void* dy_masked, const void* x, const float* part, int nblk, const float* gamma, const float* save_mean,
+                      const float* save_rstd, void* dx, float* dgamma, float* dbeta, float* sums /* f32 [2][C] scratch */, int M, int C,
+                      int flags /* MH_BN_ACCUM_PARAM_GRADS */, float scale, mh_stream_t stream);
 int mh_conv_wgrad(const void* dy, const void* x, float* slabs, int ksplit, float alpha, const MhConvGeom* g, mh_stream_t stream);
 /* the weight gradients of up to 6 convolutions in ONE launch (each alone is ~256 tiles: half of the 512 workgroup slots for ~26 us;
  * the backward defers them and launches consecutive layers together, with fewer K chunks each) */

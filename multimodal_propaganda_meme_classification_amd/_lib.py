@@ -54,6 +54,10 @@ class MhConvGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "KH", "KW", "stride", "pad", "Cout", "ldk")]
 
 
+class MhConvBnBwd(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("z", "mean", "rstd", "gamma", "beta", "part")] + [("relu", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class MhConvWgradProblem(C.Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("slabs", c_void_p), ("ksplit", C.c_int32), ("alpha", C.c_float), ("geom", MhConvGeom)]
 
@@ -182,7 +186,8 @@ _PROTOS = {
     "mh_conv_wgrad_finish_batched": [C.POINTER(MhConvWgradJob), c_int, c_void_p],
     "mh_conv_splitk": [C.POINTER(MhConvGeom), c_int],
     "mh_conv_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
-    "mh_conv_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), c_void_p],
+    "mh_conv_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(MhConvGeom), C.POINTER(MhConvBnBwd), c_void_p],
+    "mh_bn2d_bwd_parts": [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_void_p],
     "mh_conv_wgrad": [c_void_p, c_void_p, c_void_p, c_int, c_float, C.POINTER(MhConvGeom), c_void_p],
     "mh_conv_wgrad_grouped": [C.POINTER(MhConvWgradProblem), c_int, c_void_p],
     "mh_bn2d_fwd_parts": [c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_int, c_int, c_float, c_float, c_int, c_void_p],

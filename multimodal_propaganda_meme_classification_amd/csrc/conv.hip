@@ -692,6 +692,18 @@ extern "C" int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const f
                        (const h16*)y, save_mean, save_rstd, gamma, beta, sums, (h16*)dx, (h16*)dres, (size_t)M, C, relu);
     return mh_launch_status();
 }
+extern "C" int mh_bn2d_bwd_parts(const void* dy_masked, const void* x, const float* part, int nblk, const float* gamma,
+                                 const float* save_mean, const float* save_rstd, void* dx, float* dgamma, float* dbeta, float* sums, int M,
+                                 int C, int flags, float scale, mh_stream_t stream) {
+    const int accumulate = (flags & MH_BN_ACCUM_PARAM_GRADS) ? 1 : 0;
+    if (!dy_masked || !x || !part || !gamma || !save_mean || !save_rstd || !dx || !sums) return MH_EINVAL;
+    if (M < 1 || C < 8 || (C % 8) || nblk < 1) return MH_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn2d_bwd_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, nblk, C, scale, dgamma, dbeta, sums, accumulate);
+    hipLaunchKernelGGL(bn2d_bwd_apply_kernel, dim3(grid1((size_t)M * (C / 8))), dim3(256), 0, s, (const h16*)dy_masked, (const h16*)x,
+                       (const h16*)nullptr, save_mean, save_rstd, gamma, (const float*)nullptr, sums, (h16*)dx, (h16*)nullptr, (size_t)M, C, 0);
+    return mh_launch_status();
+}
 extern "C" int mh_maxpool_fwd(const void* x, void* y, uint8_t* arg, int B, int H, int W, int C, int K, int stride, int pad,
                               mh_stream_t stream) {
     if (!x || !y || !arg) return MH_EINVAL;

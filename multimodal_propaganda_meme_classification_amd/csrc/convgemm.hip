@@ -21,7 +21,7 @@ namespace {
 using namespace mh_tile;
 
 constexpr int NW = 8, NWM = 2, NWN = 4, NI = 4, NJ = 2;      // waves: 2 along M x 4 along N, 64x32 each (gemm.hip variant 4)
-constexpr int RED_BYTES = 4 * 2 * 128 * 4;                   // BatchNorm column partials of the four 32-row quarters of a tile
+constexpr int RED_BYTES = 8 * 2 * 128 * 4;                   // BatchNorm column partials: 4 row quarters (forward) / 8 waves (dgrad) x {sum, sum2} x 128 columns
 constexpr int CONV_LDS = LDS_BYTES + RED_BYTES;
 constexpr uint32_t OOB = 0x80000000u;                        // >= num_records of every operand (sizes are checked < 2 GiB)
 
@@ -43,6 +43,11 @@ struct ConvArgs {
     int kchunk, nsplit;
     float alpha;
     float inv_wo, inv_howo;
+    // dgrad only: the BatchNorm (+ReLU) that PRODUCED this convolution's input -- its backward statistics from this epilogue
+    const h16* bn_z;                       // that BatchNorm's input z [M][N] (the producing convolution's output), or NULL
+    const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta;
+    float* bn_part;                        // [2][N][tiles_m]: sum g', sum g' xhat per 128-row tile
+    int bn_relu;
 };
 
 // m -> (image, row, column) of the anchored pixel grid.  m < 2^24 (checked on the host): the float quotient is off by at
@@ -285,6 +290,68 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
         }
         return;
     }
+    if (MODE == MODE_DGRAD && a.bn_z) {
+        // This tile of dX is dY of the BatchNorm (+ReLU) that produced the convolution's input: mask it by that ReLU (recomputed
+        // from z as the forward computed it), store the MASKED gradient, and leave the column sums sum g', sum g' xhat the
+        // BatchNorm backward needs -- its statistics pass over (dy, z) disappears (mh_bn2d_bwd_parts).  A thread's 8 columns are the
+        // same in all four of its rows (cc = tid & 15).
+        const int cc = tid & 15, gn = n0 + cc * 8;
+        float mu[8], rs[8], ga[8], be[8], s[8], q2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = 0.f; rs[e] = 0.f; ga[e] = 0.f; be[e] = 0.f; s[e] = 0.f; q2[e] = 0.f; }
+        if (gn < a.N) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mu[e] = a.bn_mean[gn + e]; rs[e] = a.bn_rstd[gn + e];
+                ga[e] = a.bn_gamma[gn + e]; be[e] = a.bn_beta[gn + e];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < BM * 16 / (NW * 64); ++it) {
+            const int row = (it * NW * 64 + tid) >> 4;
+            const int gm = m0 + row;
+            if (gm >= a.M || gn >= a.N) continue;
+            const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
+            const f32x4 x1 = *(const f32x4*)(cs + cs_index(row, cc * 8 + 4));
+            Pack8 zv, u;
+            zv.v = *(const i32x4*)(a.bn_z + (size_t)gm * a.ldc + gn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float g = mh_bf2f(mh_f2bf((e < 4 ? x0[e] : x1[e - 4]) * alpha));
+                const float xh = (mh_bf2f(zv.e[e]) - mu[e]) * rs[e];
+                if (a.bn_relu && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) g = 0.f;
+                u.e[e] = mh_f2bf(g);
+                s[e] += g;
+                q2[e] += g * xh;
+            }
+            *(i32x4*)((h16*)a.out + (size_t)gm * a.ldc + gn) = u.v;
+        }
+        // the 32 threads that share cc: 4 lanes per wave (xor 16, 32), then the 8 waves through LDS in wave order
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[e] += __shfl_xor(s[e], 16, 64);
+            s[e] += __shfl_xor(s[e], 32, 64);
+            q2[e] += __shfl_xor(q2[e], 16, 64);
+            q2[e] += __shfl_xor(q2[e], 32, 64);
+        }
+        float* red = (float*)(smem + LDS_BYTES);          // [8 waves][2][128 columns]
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 2 + 0) * 128 + cc * 8 + e] = s[e];
+                red[(wave * 2 + 1) * 128 + cc * 8 + e] = q2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int which = tid >> 7, c = tid & 127;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * 128 + c];
+            if (n0 + c < a.N) a.bn_part[((size_t)which * a.N + n0 + c) * a.tiles_m + tm] = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < BM * 16 / (NW * 64); ++it) {
         const int q = it * NW * 64 + tid;
@@ -326,15 +393,24 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
 // split-K forward / dgrad: y = 16-bit(sum of the f32 slabs, in slab order); with `part`, the BatchNorm partial sums of the stored
 // values per 128-row block (what the unsplit epilogue leaves).  Block = 128 rows x 64 columns: thread (ty = row lane of 32, tx = 8
 // columns), 4 rows each; column sums through LDS in row-lane order.
+struct BnFuse {       // dgrad: see conv_gemm_kernel's dgrad epilogue
+    const h16* z;
+    const float *mean, *rstd, *gamma, *beta;
+    int relu;
+};
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ slabs, int nsplit, h16* __restrict__ y,
-                                                                 float* __restrict__ part, int M, int N, int tiles_m) {
+                                                                 float* __restrict__ part, int M, int N, int tiles_m, const BnFuse bf) {
     __shared__ float red[32][2][64];
     const int blk = blockIdx.x, n0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int col = n0 + tx * 8;
-    float s[8], q[8];
+    float s[8], q[8], mu[8], rs[8], ga[8], be[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; mu[e] = 0.f; rs[e] = 0.f; ga[e] = 0.f; be[e] = 0.f; }
+    if (bf.z && col < N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = bf.mean[col + e]; rs[e] = bf.rstd[col + e]; ga[e] = bf.gamma[col + e]; be[e] = bf.beta[col + e]; }
+    }
     if (col < N) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -349,6 +425,21 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
             Pack8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o.e[e] = mh_f2bf(a0[e]); o.e[4 + e] = mh_f2bf(a1[e]); }
+            if (bf.z) {       // dgrad feeding a BatchNorm (+ReLU) backward: masked gradient + its two column sums
+                Pack8 zv;
+                zv.v = *(const i32x4*)(bf.z + (size_t)r * N + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float g = mh_bf2f(o.e[e]);
+                    const float xh = (mh_bf2f(zv.e[e]) - mu[e]) * rs[e];
+                    if (bf.relu && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) g = 0.f;
+                    o.e[e] = mh_f2bf(g);
+                    s[e] += g;
+                    q[e] += g * xh;
+                }
+                *(i32x4*)(y + (size_t)r * N + col) = o.v;
+                continue;
+            }
             *(i32x4*)(y + (size_t)r * N + col) = o.v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -449,9 +540,11 @@ extern "C" int mh_conv_splitk(const MhConvGeom* g, int dgrad) {
 }
 
 namespace {
-int finish_split(const ConvArgs& a, void* y, float* bn_part, hipStream_t s) {
+int finish_split(const ConvArgs& a, void* y, float* bn_part, hipStream_t s, const BnFuse* bf = nullptr) {
+    BnFuse f = {};
+    if (bf) f = *bf;
     hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(a.tiles_m, (a.N + 63) / 64), dim3(256), 0, s, (const float*)a.part, a.nsplit, (h16*)y,
-                       bn_part, a.M, a.N, a.tiles_m);
+                       bn_part, a.M, a.N, a.tiles_m, f);
     return mh_launch_status();
 }
 void set_split(ConvArgs& a, int nsplit, float* workspace) {
@@ -499,7 +592,8 @@ extern "C" int mh_conv_fwd(const void* x, const void* wk, void* y, float* bn_par
     return uni ? conv_launch<MODE_FWD, true>(a, (hipStream_t)stream) : conv_launch<MODE_FWD, false>(a, (hipStream_t)stream);
 }
 
-extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* workspace, const MhConvGeom* g, mh_stream_t stream) {
+extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* workspace, const MhConvGeom* g, const MhConvBnBwd* bn,
+                             mh_stream_t stream) {
     int Ho, Wo;
     const int st = geom_check(g, Ho, Wo);
     if (st != MH_OK) return st;
@@ -526,12 +620,21 @@ extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* wo
     a.kchunk = 0; a.nsplit = 1;
     a.alpha = 1.f;
     a.inv_wo = 1.0f / (float)a.Wo; a.inv_howo = 1.0f / (float)(a.Ho * a.Wo);
+    if (bn && (!bn->z || !bn->mean || !bn->rstd || !bn->gamma || !bn->beta || !bn->part)) return MH_EINVAL;
     const int nsplit = workspace ? mh_conv_splitk(g, 1) : 1;
     if (nsplit > 1) {
         set_split(a, nsplit, workspace);
         const int st2 = conv_launch<MODE_DGRAD, true>(a, (hipStream_t)stream);
         if (st2 != MH_OK) return st2;
+        if (bn) {
+            const BnFuse f = {(const h16*)bn->z, bn->mean, bn->rstd, bn->gamma, bn->beta, bn->relu};
+            return finish_split(a, dx, bn->part, (hipStream_t)stream, &f);
+        }
         return finish_split(a, dx, nullptr, (hipStream_t)stream);
+    }
+    if (bn) {
+        a.bn_z = (const h16*)bn->z; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
+        a.bn_part = bn->part; a.bn_relu = bn->relu;
     }
     return conv_launch<MODE_DGRAD, true>(a, (hipStream_t)stream);
 }

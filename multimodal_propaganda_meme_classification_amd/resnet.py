@@ -98,7 +98,7 @@ class _Conv:
               "mh_conv_wgrad")
         return slabs, sp
 
-    def backward(self, lib, dy, x, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True, side=None, wq=None):
+    def backward(self, lib, dy, x, wk, B, H, W, Ho, Wo, gscale, wjobs, need_dx=True, side=None, wq=None, bnb=None):
         """dy [M, cout] 16-bit -> dx [B*H*W, cp] 16-bit (or None); the weight gradient's split-K slabs are queued in `wjobs`
         (summed, un-packed and added to .grad for all convolutions at once at the end of the backward).  With `side`, the
         weight-gradient kernel -- which nothing later in the backward chain reads -- runs on that stream beside the input-gradient
@@ -121,24 +121,31 @@ class _Conv:
         if slabs is not None:
             wjobs.append((self, slabs, sp, dy, x))
         if not need_dx:
-            return None
+            return None, None
         if self.direct and self.cout % 64:
             dx = torch.empty((M, self.cp), dtype=dy.dtype, device=dev)
             ops.gemm_grouped([ops.Gemm(dy, wk, dx, M, self.ldk, self.cout, self.cout, self.ldk, self.ldk)], False, True)
-            return dx
+            return dx, None
         dx = torch.empty((B * H * W, self.cp), dtype=dy.dtype, device=dev)
         if self.stride == 1 and self.kh == self.kw and self.cout % 64 == 0:
             geom = self.geom(B, H, W)
             sp = int(lib.mh_conv_splitk(geom, 1))
             ws = torch.empty((sp, B * H * W, self.cp), dtype=F32, device=dev) if sp > 1 else None
-            check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, _stream()),
+            fuse, part = None, None
+            if bnb is not None:      # dx is the dy of the BatchNorm (+ReLU) that produced x: mask it and sum its statistics right here
+                z_prev, bn_mod, sm_prev, sr_prev, relu_prev = bnb
+                part = torch.empty((2, self.cp, (B * H * W + 127) // 128), dtype=F32, device=dev)
+                fuse = _lib.MhConvBnBwd()
+                fuse.z, fuse.mean, fuse.rstd = z_prev.data_ptr(), sm_prev.data_ptr(), sr_prev.data_ptr()
+                fuse.gamma, fuse.beta, fuse.part, fuse.relu = bn_mod.weight.data_ptr(), bn_mod.bias.data_ptr(), part.data_ptr(), int(relu_prev)
+            check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, fuse, _stream()),
                   "mh_conv_dgrad")
-            return dx
+            return dx, part
         dA = torch.empty((M, self.ldk), dtype=dy.dtype, device=dev)
         ops.gemm_grouped([ops.Gemm(dy, wk, dA, M, self.ldk, self.cout, self.cout, self.ldk, self.ldk)], False, True)
         check(lib.mh_col2im_nhwc(dA.data_ptr(), dx.data_ptr(), B, H, W, self.cp, self.kh, self.kw, self.stride, self.pad, self.ldk,
                                  _stream()), "mh_col2im_nhwc")
-        return dx
+        return dx, None
 
 
 def flush_wgrads(lib, wq, wjobs, gscale):
@@ -202,6 +209,23 @@ class _BN:
                               sr.data_ptr(), dx.data_ptr(), None if dres is None else dres.data_ptr(), dg.data_ptr(), db.data_ptr(),
                               ws.data_ptr(), M, self.C, flags, 1.0 / gscale, _stream()), "mh_bn2d_bwd")
         return dx, dres
+
+
+def _bn_backward_parts(bn, lib, dy_masked, x, sm, sr, part, M, gscale, grads):
+    """BatchNorm2d backward when the producing dgrad epilogue already masked dy and summed its statistics (mh_conv_dgrad with `bn`)."""
+    m = bn.mod
+    dx = torch.empty_like(x)
+    dg, acc_g = _grad_target(m.weight, grads)
+    db, acc_b = _grad_target(m.bias, grads)
+    if acc_g != acc_b:
+        dg, db = torch.empty_like(m.weight), torch.empty_like(m.bias)
+        grads[id(m.weight)], grads[id(m.bias)] = dg, db
+        acc_g = False
+    sums = torch.empty((2, bn.C), dtype=F32, device=x.device)
+    check(lib.mh_bn2d_bwd_parts(dy_masked.data_ptr(), x.data_ptr(), part.data_ptr(), part.shape[2], m.weight.data_ptr(), sm.data_ptr(),
+                                sr.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), sums.data_ptr(), M, bn.C,
+                                _lib.MH_BN_ACCUM_PARAM_GRADS if acc_g else 0, 1.0 / gscale, _stream()), "mh_bn2d_bwd_parts")
+    return dx
 
 
 class Bottleneck(nn.Module):
@@ -379,32 +403,45 @@ class ResNet50(nn.Module):
         group = max(1, min(group, _lib.MH_CONV_MAX_GROUP))
         wq = [] if (group > 1 and side is None) else None
 
-        def conv_bn_bwd(op, dy, want_dres, need_dx=True):
+        fuse_on = os.environ.get("MEMEHIP_BN_BWD_FUSE", "1") != "0"
+
+        def conv_bn_bwd(op, dy, want_dres, need_dx=True, fuse_prev=None, pre_part=None):
+            """Backward of one conv + BatchNorm (+ReLU).  `pre_part`: dy arrives MASKED with its column sums already taken by the
+            dgrad epilogue that produced it; `fuse_prev`: the conv + BatchNorm whose output is this convolution's input -- when its
+            BatchNorm has a ReLU and no residual, this dgrad's epilogue does that BatchNorm's masking and statistics."""
             _, cv, bn, A, wk, z, y, sm, sr, hh, ww, ho, wo, relu, has_res = op
             M = B * ho * wo
-            # the ReLU mask: from y where a residual was added before the ReLU, recomputed from z otherwise (one tensor less to read)
-            dz, dres = bn.backward(lib, dy, z, y if (relu and has_res) else None, sm, sr, M, relu, want_dres, self.gscale, grads)
-            dxin = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx, side=side, wq=wq)
+            if pre_part is not None:
+                dz, dres = _bn_backward_parts(bn, lib, dy, z, sm, sr, pre_part, M, self.gscale, grads), None
+            else:
+                # the ReLU mask: from y where a residual was added before the ReLU, recomputed from z otherwise (one tensor less to read)
+                dz, dres = bn.backward(lib, dy, z, y if (relu and has_res) else None, sm, sr, M, relu, want_dres, self.gscale, grads)
+            bnb = None
+            if fuse_on and fuse_prev is not None and fuse_prev[13] and not fuse_prev[14]:
+                bnb = (fuse_prev[5], fuse_prev[2].mod, fuse_prev[7], fuse_prev[8], True)
+            dxin, part = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx, side=side, wq=wq, bnb=bnb)
             if wq is not None and len(wq) >= group:
                 flush_wgrads(lib, wq, wjobs, self.gscale)
-            return dxin, dres
+            return dxin, dres, part
 
         while i >= 0:
             op = ops_[i]
             kind = op[0]
             if kind == "block_end":
                 has_ds = op[1]
-                # conv3 + bn3 (+ residual + relu): dres is the gradient of the identity branch
-                d_o, dres = conv_bn_bwd(ops_[i - 1], dx, want_dres=True)
+                # conv3 + bn3 (+ residual + relu): dres is the gradient of the identity branch; its dgrad epilogue already does
+                # bn2's masking + statistics, conv2's does bn1's
+                jc2 = i - 4 if has_ds else i - 2
+                d_o, dres, part2 = conv_bn_bwd(ops_[i - 1], dx, want_dres=True, fuse_prev=ops_[jc2])
                 j = i - 2
                 d_ident = dres
                 if has_ds:
                     assert ops_[j][0] == "branch_end"
-                    d_branch_in, _ = conv_bn_bwd(ops_[j - 1], dres, want_dres=False)      # downsample conv + bn (no relu)
+                    d_branch_in, _, _ = conv_bn_bwd(ops_[j - 1], dres, want_dres=False)      # downsample conv + bn (no relu)
                     d_ident = d_branch_in
                     j -= 2
-                d_o, _ = conv_bn_bwd(ops_[j], d_o, want_dres=False)        # conv2
-                d_o, _ = conv_bn_bwd(ops_[j - 1], d_o, want_dres=False)    # conv1
+                d_o, _, part1 = conv_bn_bwd(ops_[j], d_o, want_dres=False, fuse_prev=ops_[j - 1], pre_part=part2)        # conv2
+                d_o, _, _ = conv_bn_bwd(ops_[j - 1], d_o, want_dres=False, pre_part=part1)    # conv1
                 assert ops_[j - 2][0] == "block_begin"
                 merged = torch.empty_like(d_o)
                 check(lib.mh_add_h16(d_o.data_ptr(), d_ident.data_ptr(), merged.data_ptr(), d_o.numel(), _stream()), "mh_add_h16")
@@ -419,7 +456,7 @@ class ResNet50(nn.Module):
                 i -= 1
                 continue
             if kind == "conv_bn":      # the stem
-                conv_bn_bwd(op, dx, want_dres=False, need_dx=False)
+                conv_bn_bwd(op, dx, want_dres=False, need_dx=False)      # the stem
                 i -= 1
                 continue
             raise AssertionError(kind)

@@ -77,7 +77,7 @@ def test_ctypes_structs_match_the_c_compiler(tmp_path):
     import ctypes
     import subprocess
     from multimodal_propaganda_meme_classification_amd import _lib as lib
-    names = ["MhGemmProblem", "MhColsumJob", "MhLnFwdJob", "MhLnBwdJob", "MhAttnProblem", "MhHeadParams", "MhHeadGrads", "MhGemmF32", "MhConvPackJob", "MhConvWgradJob", "MhConvGeom", "MhConvWgradProblem", "MhAdamSkipGroups", "MhLossScale"]
+    names = ["MhGemmProblem", "MhColsumJob", "MhLnFwdJob", "MhLnBwdJob", "MhAttnProblem", "MhHeadParams", "MhHeadGrads", "MhGemmF32", "MhConvPackJob", "MhConvWgradJob", "MhConvGeom", "MhConvWgradProblem", "MhConvBnBwd", "MhAdamSkipGroups", "MhLossScale"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "memehip.h"\nint main(void){' +

@@ -100,7 +100,7 @@ def test_implicit_conv_input_gradient_is_exact_on_integers(pkg, T16):
         if s != 1 or Cout % 64:
             geom = _geom(pkg, B, H, W, C, k, s, p, Cout, (k * k * C + 63) // 64 * 64)
             d = torch.zeros(16, dtype=T16, device="cuda")
-            assert lib.mh_conv_dgrad(d.data_ptr(), d.data_ptr(), d.data_ptr(), None, geom, st) == 2       # MH_ESHAPE: the explicit path serves it
+            assert lib.mh_conv_dgrad(d.data_ptr(), d.data_ptr(), d.data_ptr(), None, geom, None, st) == 2       # MH_ESHAPE: the explicit path serves it
             continue
         x = torch.zeros((B, C, H, W), requires_grad=True)
         w = torch.randint(-2, 3, (Cout, C, k, k), generator=g).float()
@@ -113,7 +113,7 @@ def test_implicit_conv_input_gradient_is_exact_on_integers(pkg, T16):
         dyd = _nhwc(dy, T16)
         dx = torch.full((B * H * W, C), 7.0, dtype=T16, device="cuda")
         geom = _geom(pkg, B, H, W, C, k, s, p, Cout, ldk)
-        pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None, geom, st), "mh_conv_dgrad")
+        pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None, geom, None, st), "mh_conv_dgrad")
         assert torch.equal(_nchw(dx, B, H, W), x.grad.to(T16).float()), (B, C, H, W, Cout, k, s, p)
 
 
@@ -180,7 +180,7 @@ def test_implicit_conv_equals_the_explicit_im2col_path_bit_for_bit(pkg):
     dx_ref = torch.empty((B * H * W, C), dtype=F16, device="cuda")
     pkg._lib.check(lib.mh_col2im_nhwc(dcol.data_ptr(), dx_ref.data_ptr(), B, H, W, C, k, k, s, p, ldk, st), "col2im")
     dx = torch.empty_like(dx_ref)
-    pkg._lib.check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), None, geom, st), "mh_conv_dgrad")
+    pkg._lib.check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), None, geom, None, st), "mh_conv_dgrad")
     xr = x.to(F16).float().requires_grad_(True)
     F.conv2d(xr, w.to(F16).float(), stride=s, padding=p).backward(_nchw(dy, B, Ho, Wo))
     scale = float(xr.grad.abs().max())
@@ -226,6 +226,49 @@ def test_split_k_forward_and_dgrad_equal_the_unsplit_kernels_on_integers(pkg, T1
         res = []
         for ws in (None, torch.empty((max(spd, 1), B * H * W, C), dtype=F32, device="cuda")):
             dx = torch.full((B * H * W, C), 7.0, dtype=T16, device="cuda")
-            pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, st), "dgrad")
+            pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, None, st), "dgrad")
             res.append(dx)
         assert torch.equal(res[0], res[1]) and torch.equal(_nchw(res[1], B, H, W), xr.grad.to(T16).float())
+
+
+def test_dgrad_epilogue_does_the_producing_batchnorms_mask_and_statistics(pkg):
+    """mh_conv_dgrad with `bn`: the input gradient of a convolution IS the dy of the BatchNorm (+ReLU) that produced its input; the
+    epilogue (or the split-K finishing launch) masks it and leaves sum g', sum g' xhat per 128-row tile.  Checked against the unfused
+    dgrad + the definition, for an unsplit 3x3 layer, a split-K one and a 1x1 layer."""
+    lib = pkg._lib.load("fp16")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(16)
+    for (B, C, H, W, Cout, k, p) in ((4, 64, 14, 14, 64, 3, 1), (2, 512, 7, 7, 512, 3, 1), (3, 128, 10, 10, 256, 1, 0)):
+        Mi = B * H * W
+        w = torch.randint(-1, 2, (Cout, C, k, k), generator=g).float()
+        dy = torch.randint(-2, 3, (B, Cout, H, W), generator=g).float()
+        ldk = k * k * C
+        wk, dyd = _pack(pkg, lib, w, C, ldk, F16), _nhwc(dy, F16)
+        geom = _geom(pkg, B, H, W, C, k, 1, p, Cout, ldk)
+        sp = int(lib.mh_conv_splitk(geom, 1))
+        ws = torch.empty((sp, Mi, C), dtype=F32, device="cuda") if sp > 1 else None
+        dx_ref = torch.empty((Mi, C), dtype=F16, device="cuda")
+        pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx_ref.data_ptr(), None if ws is None else ws.data_ptr(), geom, None, st), "dgrad")
+        z = (torch.randn((Mi, C), generator=g) * 1.3 + 0.2).to(F16).cuda()
+        mean, rstd = (torch.randn(C, generator=g) * 0.3).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+        nblk = (Mi + 127) // 128
+        for relu in (1, 0):
+            f = pkg._lib.MhConvBnBwd()
+            part = torch.full((2, C, nblk), -7.0, dtype=F32, device="cuda")
+            f.z, f.mean, f.rstd, f.gamma, f.beta, f.part, f.relu = z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), relu
+            dx = torch.empty_like(dx_ref)
+            pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, f, st), "dgrad+bn")
+            xh = (z.float() - mean) * rstd
+            v = xh * gamma + beta
+            keep = (v.to(F16).float() > 0) if relu else torch.ones_like(v, dtype=torch.bool)
+            want = torch.where(keep, dx_ref.float(), torch.zeros_like(v))
+            sure = (v.abs() > 1e-3) | (relu == 0)          # (a value a rounding away from zero may fall either way)
+            assert torch.equal(dx.float()[sure], want[sure]), (B, C, H, W, Cout, k, relu)
+            gm = dx.float()                                # the statistics are of what was stored
+            pad = torch.zeros((nblk * 128, C), device="cuda")
+            pad[:Mi] = gm
+            pad2 = torch.zeros((nblk * 128, C), device="cuda")
+            pad2[:Mi] = gm * xh
+            s0, s1 = pad.view(nblk, 128, C).sum(1).t(), pad2.view(nblk, 128, C).sum(1).t()
+            assert torch.allclose(part[0], s0, rtol=1e-4, atol=1e-2) and torch.allclose(part[1], s1, rtol=1e-4, atol=1e-2), (B, C, k, relu)
