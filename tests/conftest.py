@@ -19,3 +19,13 @@ def pytest_configure(config):
 def golden_dir():
     return GOLDEN
 
+
+
+def free_port() -> int:
+    """A TCP port nobody listens on right now (bind to 0, read it back): the rendezvous of the multi-process tests.  Ports derived
+    from the process id collided (the module-scoped 1-rank RCCL group of tests/test_model_gpu.py and the two-rank subprocess test drew
+    the same number: EADDRINUSE, once in a GPU run of round 3)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -166,7 +166,8 @@ def test_gradient_reducer_bf16_compression_gloo_world2():
     model of the compressed arithmetic."""
     import torch.multiprocessing as mp
     world = 2
-    port = 31500 + os.getpid() % 2000
+    from conftest import free_port
+    port = free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_ddp_bf16_worker, args=(world, port, out), nprocs=world, join=True)
@@ -178,7 +179,8 @@ def test_gradient_reducer_bf16_compression_gloo_world2():
 def test_gradient_reducer_gloo_world2():
     import torch.multiprocessing as mp
     world = 2
-    port = 29500 + os.getpid() % 2000
+    from conftest import free_port
+    port = free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_ddp_worker, args=(world, port, out), nprocs=world, join=True)

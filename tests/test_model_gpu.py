@@ -260,7 +260,8 @@ def rccl_world1():
     process.  MEMEHIP_DEBUG_PG_PER_TEST=1 (and MEMEHIP_DEBUG_RAW_DESTROY=1) restore the crashing set-up for a reproduction."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+    from conftest import free_port
+    os.environ["MASTER_PORT"] = str(free_port())
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         yield dist
@@ -352,7 +353,8 @@ def test_ddp_two_ranks_on_one_gpu_match_the_global_batch():
     (tools/ddp2_check.py asserts losses, parameters within 2.05 * k * lr / mean 2e-5, and identical ranks)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29700 + os.getpid() % 200
+    from conftest import free_port
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tools", "ddp2_check.py")]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
