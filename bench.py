@@ -246,7 +246,7 @@ def bench_config2(args):
     torch.cuda.synchronize()
     if not args.no_graph:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             launches()
     run = one_step
     for _ in range(max(args.warmup, 1)):

@@ -1129,6 +1129,13 @@ def flatten_parameters(module: nn.Module) -> nn.Module:
     return module
 
 
+# Every capture is THREAD-LOCAL: other threads may touch the runtime while this one captures.  The process group's watchdog thread
+# queries the events of earlier collectives (parameter broadcast, the warm-up step's all-reduces) and a DataLoader's pin-memory
+# thread allocates -- under the default "global" mode either one invalidates the capture (`bench.py --force-ddp` died in
+# hipErrorStreamCaptureInvalidated at the first segment graph, round 3: the path every N > 1 run takes).
+CAPTURE_MODE = "thread_local"
+
+
 class GraphedStep:
     """Whole fine-tune step (forward, loss, backward, clip, Adam) captured into hipGraphs and
     replayed per batch, so the ~600 kernel launches of a step cost a handful of host calls.
@@ -1474,7 +1481,7 @@ class GraphedStep:
         if self.ddp_graph:
             e0, w0 = self.reducer.reduced_elems, self.reducer.wire_bytes
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (the process group's watchdog thread queries events)
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 stream = torch.cuda.current_stream().cuda_stream
                 for name, fn, rng in pieces:
                     if name == "opt":
@@ -1487,13 +1494,13 @@ class GraphedStep:
             self.reducer.reduced_elems, self.reducer.wire_bytes = e0, w0
         elif self.ddp_stream:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 pieces[0][1](torch.cuda.current_stream().cuda_stream)
             graphs.append((g, "fwd", None))
             self._tail = pieces[1:]
         elif self.reducer is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 stream = torch.cuda.current_stream().cuda_stream
                 for name, fn, rng in pieces:
                     fn(stream)
@@ -1505,7 +1512,7 @@ class GraphedStep:
                     graphs.append((None, "gather", None))
                     continue
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=CAPTURE_MODE):
                     fn(torch.cuda.current_stream().cuda_stream)
                 pool = g.pool()
                 graphs.append((g, name, rng))

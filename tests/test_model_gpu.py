@@ -314,6 +314,31 @@ def test_ddp_segmented_graph_path_world1(pkg, clip, ddp_mode, rccl_world1):
         assert 4 <= len(g2.graphs) <= len(g2.plan.bwd) + 3   # fwd, opt, gather marker + segments (paired)
 
 
+def test_capture_survives_the_process_groups_watchdog(pkg, rccl_world1):
+    """The segment graphs are captured while the process group's watchdog thread may be querying the events of earlier
+    collectives (`bench.py --force-ddp` died in hipErrorStreamCaptureInvalidated at its first capture, round 3): every capture of
+    GraphedStep is thread-local.  Here collectives are left in flight right before the first step captures."""
+    import torch.distributed as dist
+    from multimodal_propaganda_meme_classification_amd import ddp, model as M
+    assert M.CAPTURE_MODE == "thread_local"
+    O = _oracle()
+    cfg = O.tiny_config("cls")
+    text, image, mask, labels = O.synthetic_batch(cfg, 4, 16, seed=21)
+    dev = [t.cuda() for t in (text, image, mask, labels)]
+    m, _ = _make(pkg, O, cfg, 22)
+    o = pkg.Adam(m.parameters(), lr=LR)
+    red = ddp.GradientReducer(m.flat_grads, bucket_cap_elems=1 << 16)
+    g = pkg.GraphedStep(m, o, 4, 16, reducer=red, ddp_mode="segments")
+    big = torch.ones(1 << 24, device="cuda")
+    works = [dist.all_reduce(big, async_op=True) for _ in range(8)]      # pending work for the watchdog to poll
+    g.load_batch(*dev)
+    loss, _ = g.step()                                                      # captures the segment graphs now
+    for w in works:
+        w.wait()
+    torch.cuda.synchronize()
+    assert float(loss) == float(loss) and float(big[0]) == 1.0
+
+
 def test_ddp_bf16_compressed_exchange_world1(pkg, rccl_world1):
     """ddp.GradientReducer(compress="bf16") on a real RCCL communicator (1 rank): all-to-all + fp32 shard sum + all-gather
     between the backward segments' graphs.  The gradients arrive bf16-rounded, so the step is not bit-identical to the fp32
