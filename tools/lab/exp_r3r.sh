@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 3: HEAD against the round's starting point (.ab_baseline = a worktree of e1e1e6f with its own build) on ONE box, alternating
+# round 3: HEAD against the round's starting point on ONE box, alternating.  Needs the baseline next to the tree first (it is git-ignored):
+#   git worktree add -f .ab_baseline e1e1e6f && make -C .ab_baseline/multimodal_propaganda_meme_classification_amd/csrc -j6   (remove with: git worktree remove --force .ab_baseline)
 OUT=gpurun_out/r3r
 mkdir -p $OUT
 B="--no-extras --no-cpu-baseline --steps 60 --warmup 10"
