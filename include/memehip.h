@@ -102,25 +102,10 @@ int mh_gemm_bf16_grouped(const MhGemmProblem* problems /*host*/, int n_problems,
                          int b_kmajor, mh_stream_t stream);
 /* a split count <= want for which every chunk of ceil(K/ksplit) rounded up to 64 is non-empty (1 when K is short) */
 int mh_gemm_ksplit_for(int K, int want);
-/* kernel variant for A/B measurements in one process (all 128x128x64 tiles unless noted):
- * 0 = 4 waves, tiles staged global->VGPR->LDS; 1 = 4 waves, LDS-DMA (buffer_load ... lds);
- * 2 = 256x128 tile, 8 waves, 3-stage LDS-DMA ring with counted vmcnt; 3 = that ring with the two wave
- * groups in ping-pong read/MFMA slots; 4 = LDS-DMA, 8 waves of 64x32 (default: 4 waves/SIMD hide the
- * barrier + LDS latency best on this path's shapes); 5 = LDS-DMA, 16 waves of 32x32; 6 = variant 4's tile with a
- * four-slot ring of 32-deep K steps and counted vmcnt (slower: a barrier per 8 MFMAs).
- * 7 = variant 4 with the MFMA fragments double-buffered in registers; 8 = variant 4's tile with the two halves of a K tile on
- * two groups of four waves (64x64 per wave), accumulators merged in the epilogue (both measured slower or equal: DESIGN.md 5.1).
- * Default 4 (or env MEMEHIP_GEMM_VARIANT at first launch). */
-int mh_gemm_set_variant(int variant);
-/* STREAM-K for the forward / dgrad layouts (default kernel variant only; A/B switch, OFF by default -- measured slower on this
- * path's shapes, gemm.hip): 512 workgroups, each a contiguous piece of its XCD's tile run measured in K ITERATIONS; the pieces of a
- * cut tile are accumulated from zero in parallel, the workgroup holding the tile's last K step adds the others' accumulator images
- * (stored in the workspace) in a fixed order and runs the epilogue -- deterministic, exact on integers, not the unsplit rounding.
- * mode: 0 off, 1 where the launch's shape says it pays, 2 every launch that can.  workspace: device memory of
- * mh_gemm_streamk_workspace_bytes() bytes, its last 2112 bytes (the flags) ZERO, alive for as long as the mode is on; the launches
- * that use it must be ordered on ONE stream. */
-int64_t mh_gemm_streamk_workspace_bytes(void);
-int mh_gemm_set_streamk(void* workspace, int mode);
+/* (The GEMM variants that lost the measurements of rounds 1-4 -- register staging, 4 / 16 waves, 256x128 rings, four-slot ring,
+ * double-buffered fragments, K-split waves, persistent workgroups, stream-K, the 128x256 tile, the direct-from-accumulator epilogue
+ * -- are not in this library: `make -C csrc LAB=1` builds libmemehip_lab*.so with them behind mh_gemm_set_variant /
+ * mh_gemm_set_streamk, declared in csrc/lab/memehip_lab.h, for tools/ only.) */
 /* profiling knob: device buffer of 4 x uint64 per workgroup of the largest launch; the default kernel records 100-MHz stamps per
  * workgroup {entry, first K stage landed, main loop done, epilogue stores issued}; NULL = off (tools/gemm_timeline.py) */
 int mh_gemm_set_trace(void* device_buffer);

@@ -120,10 +120,7 @@ class MhHeadGrads(C.Structure):
 _PROTOS = {
     "mh_gemm_bf16_grouped": [C.POINTER(MhGemmProblem), c_int, c_int, c_int, c_void_p],
     "mh_gemm_set_trace": [c_void_p],
-    "mh_gemm_set_variant": [c_int],
     "mh_gemm_ksplit_for": [c_int, c_int],
-    "mh_gemm_streamk_workspace_bytes": [],
-    "mh_gemm_set_streamk": [c_void_p, c_int],
     "mh_layernorm_fwd": [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p],
     "mh_layernorm_bwd": [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p, c_void_p, c_float, C.c_uint32, c_void_p],
     "mh_layernorm_fwd_grouped": [C.POINTER(MhLnFwdJob), c_int, c_int, c_void_p],
@@ -212,8 +209,10 @@ _PROTOS = {
     "mh_version": [],
     "mh_status_str": [c_int],
 }
-_RESTYPES = {"mh_version": C.c_char_p, "mh_status_str": C.c_char_p, "mh_bn2d_workspace_elems": c_int64,
-             "mh_gemm_streamk_workspace_bytes": c_int64}
+_RESTYPES = {"mh_version": C.c_char_p, "mh_status_str": C.c_char_p, "mh_bn2d_workspace_elems": c_int64}
+# extra entry points of the LAB build (csrc/lab/memehip_lab.h; `make LAB=1`), bound only when the loaded library has them
+_LAB_PROTOS = {"mh_gemm_set_variant": ([c_int], c_int), "mh_gemm_streamk_workspace_bytes": ([], c_int64),
+               "mh_gemm_set_streamk": ([c_void_p, c_int], c_int)}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
@@ -234,6 +233,8 @@ def load(kind: str = "bf16") -> C.CDLL:
     path = LIB_PATHS[kind]
     if kind == "bf16" and os.environ.get("MEMEHIP_LIB"):      # A/B of two builds of the library in one session
         path = os.environ["MEMEHIP_LIB"]
+    if kind == "fp16" and os.environ.get("MEMEHIP_LIB_F16"):
+        path = os.environ["MEMEHIP_LIB_F16"]
     if not os.path.exists(path):
         raise MemehipError(
             f"{path} is missing: build the HIP extension first "
@@ -244,6 +245,10 @@ def load(kind: str = "bf16") -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
+    for name, (argtypes, restype) in _LAB_PROTOS.items():      # tools/ with MEMEHIP_LIB=libmemehip_lab*.so
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = argtypes, restype
     _libs[kind] = lib
     return lib
 

@@ -150,8 +150,6 @@ class Engine:
         self.T16 = torch.float16 if self.kind == "fp16" else torch.bfloat16
         assert SH.dtype == self.T16
         self.lib = _lib.load(self.kind)
-        from . import ops as _ops
-        _ops.ensure_streamk(self.lib, self.kind, self.dev)
         self.gscale = cfg.stream_scale          # scale carried by the 16-bit gradient streams
         # padding-free text tower (rows with attention_mask == 0 are never computed); MEMEHIP_PACK_TEXT=0 for A/B runs
         import os

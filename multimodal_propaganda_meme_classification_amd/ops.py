@@ -35,19 +35,13 @@ _STREAMK_WS = {}      # (library kind, device index) -> workspace tensor, kept f
 
 
 def ensure_streamk(lib, kind: str, device, mode=None) -> None:
-    """Stream-K GEMM (mh_gemm_set_streamk) is OFF by default -- measured slower on this path's shapes (csrc/gemm.hip).
-    ``mode`` (or env MEMEHIP_GEMM_STREAMK) 1 / 2 allocates the workspace on this device (accumulator images of 512 workgroups +
-    zeroed flags, kept for the life of the process) and switches it on; 0 switches it off.  The library holds ONE workspace:
-    launches that use it must be stream-ordered -- the forward / dgrad chain is."""
-    import os
-    if mode is None:
-        mode = int(os.environ.get("MEMEHIP_GEMM_STREAMK", "0"))
-        if (kind, "env") in _STREAMK_WS:
-            return
-        _STREAMK_WS[(kind, "env")] = mode
+    """LAB builds only (libmemehip_lab*.so through MEMEHIP_LIB; tools/gemm_sk_check.py): the stream-K GEMM is not in the product
+    library -- it measured slower on this path's shapes (csrc/lab/gemm_lab.inc).  ``mode`` 1 / 2 allocates the workspace on this
+    device (accumulator images of 512 workgroups + zeroed flags, kept for the life of the process) and switches it on; 0 off."""
+    if not hasattr(lib, "mh_gemm_set_streamk"):
+        raise _lib.MemehipError("stream-K is a lab kernel: build `make -C csrc LAB=1` and load it through MEMEHIP_LIB / MEMEHIP_LIB_F16")
     if mode == 0:
-        if any(isinstance(k[1], int) for k in _STREAMK_WS if k[0] == kind):
-            check(lib.mh_gemm_set_streamk(None, 0), "mh_gemm_set_streamk")
+        check(lib.mh_gemm_set_streamk(None, 0), "mh_gemm_set_streamk")
         return
     dev = torch.device(device)
     key = (kind, dev.index if dev.index is not None else torch.cuda.current_device())
@@ -58,9 +52,7 @@ def ensure_streamk(lib, kind: str, device, mode=None) -> None:
 
 def _L(t: torch.Tensor):
     kind = _kind(t)
-    lib = _lib.load(kind)
-    ensure_streamk(lib, kind, t.device)
-    return lib
+    return _lib.load(kind)
 
 
 def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):

@@ -88,3 +88,24 @@ def test_ctypes_structs_match_the_c_compiler(tmp_path):
     sizes = dict(line.split() for line in out.strip().splitlines())
     for n in names:
         assert ctypes.sizeof(getattr(lib, n)) == int(sizes[n]), (n, ctypes.sizeof(getattr(lib, n)), sizes[n])
+
+
+def test_isa_guard_bands_hold(lib):
+    """tools/isa_guard.py (run by __graft_entry__.build()): register counts, spills, scratch and the K-loop ISA of the hot kernels
+    are inside the committed bands -- and the guard does fire: a band moved away from the build must fail."""
+    import json
+    import subprocess
+    import sys
+    guard = os.path.join(ROOT, "tools", "isa_guard.py")
+    r = subprocess.run([sys.executable, guard], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    bands = json.load(open(os.path.join(ROOT, "tools", "isa_bands.json")))["kernels"]
+    assert any("gemm_kernel<0, 0, false>" in k for k in bands) and any("conv_gemm_kernel" in k for k in bands) and any("attn_" in k for k in bands)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_guard
+    got = isa_guard.collect()
+    k = "gemm.f16.o:gemm_kernel<0, 0, false>"
+    assert bands[k]["vgpr_count"][0] <= got[k]["vgpr_count"] <= bands[k]["vgpr_count"][1]
+    assert got[k]["loop_mfma"] == 16 and got[k]["vgpr_spill_count"] == 0 and got[k]["waterfall_loops"] == 0
+    # the accident of round 3 (112 -> 90 VGPRs) would have left the band
+    assert not (bands[k]["vgpr_count"][0] <= 90 <= bands[k]["vgpr_count"][1])

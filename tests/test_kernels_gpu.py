@@ -428,47 +428,3 @@ def test_gemm_split_k_weight_gradient(ops):
         assert torch.equal(got, want), (M, N, K)
         got2 = ops.wgrad_splitk(dy, x, M, N, K, M, N, alpha=0.5, target_tiles=8)
         assert torch.equal(got2, 0.5 * want)
-
-
-def test_streamk_gemm_is_exact_on_integers_and_close_on_random_data(ops):
-    """The stream-K form (off by default: measured slower, csrc/gemm.hip) cuts tiles along K between workgroups and sums the
-    pieces in a fixed order: exact on small integers (any summation order is), within an ulp of the 16-bit result on random data,
-    flags left clean, no spin time-out; packed (rows_dev) operands and ragged tiles included."""
-    from multimodal_propaganda_meme_classification_amd import _lib as L
-    lib = L.load("fp16")
-    dev = torch.device("cuda")
-    g = torch.Generator(device="cuda").manual_seed(5)
-    try:
-        for (shapes, bk, live, ints) in (([(6304, 768, 3072), (2096, 768, 3072)], False, None, True),
-                                         ([(4096, 768, 3072), (1000, 768, 3072)], True, 2093, False),
-                                         ([(3000, 1536, 768)], False, None, False),
-                                         ([(4096, 256, 2048)], False, 1, True)):
-            tens = []
-            for (M, N, K) in shapes:
-                if ints:
-                    A = torch.randint(-2, 3, (M, K), device=dev, generator=g).to(torch.float16)
-                    Bm = torch.randint(-1, 2, (K, N) if bk else (N, K), device=dev, generator=g).to(torch.float16)
-                else:
-                    A = (torch.randn((M, K), device=dev, generator=g) * 0.5).to(torch.float16)
-                    Bm = (torch.randn((K, N) if bk else (N, K), device=dev, generator=g) * 0.05).to(torch.float16)
-                tens.append((A, Bm, torch.randn(N, device=dev, generator=g)))
-            rows = torch.tensor([live], dtype=torch.int32, device=dev) if live is not None else None
-            outs = []
-            for mode in (0, 2):
-                ops.ensure_streamk(lib, "fp16", dev, mode=mode)
-                Cs = [torch.zeros((M, N), dtype=torch.float16, device=dev) for (M, N, K) in shapes]
-                ops.gemm_grouped([ops.Gemm(A, Bm, C, M, N, K, K, (N if bk else K), N, bias=(None if ints else bias), rows_dev=(rows if i == 0 else None))
-                                  for i, ((M, N, K), (A, Bm, bias), C) in enumerate(zip(shapes, tens, Cs))], False, bk)
-                torch.cuda.synchronize()
-                outs.append(Cs)
-            ws = ops._STREAMK_WS[("fp16", torch.cuda.current_device())]
-            flags = ws[512 * 512 * 32 * 4:].view(torch.int32)
-            assert int(flags[:513].abs().sum()) == 0
-            for i, (a, b) in enumerate(zip(*outs)):
-                n = live if (live is not None and i == 0) else a.shape[0]
-                if ints:
-                    assert torch.equal(a[:n], b[:n])
-                else:
-                    assert float((a[:n].float() - b[:n].float()).abs().max()) <= 2.0 ** -8 * max(1.0, float(a[:n].float().abs().max()) / 2)
-    finally:
-        ops.ensure_streamk(lib, "fp16", dev, mode=0)

@@ -10,7 +10,8 @@ import tools.gemm_ab as ab          # noqa: E402  (defines the cases; exits befo
 from multimodal_propaganda_meme_classification_amd import ops, _lib  # noqa: E402
 
 lib = _lib.load()
-lib.mh_gemm_set_variant(4)
+if hasattr(lib, "mh_gemm_set_variant"):
+    lib.mh_gemm_set_variant(int(os.environ.get("GEMM_VARIANT", "-2")))
 buf = torch.zeros(4 * 4096, dtype=torch.int64, device="cuda")
 for name in ("fwd qkv", "fwd out", "fwd ffn1", "fwd ffn2", "dgrad ffn2", "dgrad qkv"):
     ps, ak, bk, fl = ab.cases[name]
