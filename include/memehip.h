@@ -574,7 +574,11 @@ int mh_add_h16(const void* a, const void* b, void* y, int64_t n, mh_stream_t str
  *     hyper = f32[8] {lr, beta1, beta2, eps, weight_decay, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale}
  *     g' = g * grad_scale * min(1, max_norm / (sqrt(*gnorm_sq)*|grad_scale| + 1e-6)) (clip only
  *          when gnorm_sq != NULL and max_norm > 0); a NON-FINITE *gnorm_sq skips the update altogether
- *          (parameters and moments untouched), as GradScaler.step does after an fp16 overflow
+ *          (parameters and moments untouched), as GradScaler.step does after an fp16 overflow.
+ *          clip_norm_mult > 0 replaces |grad_scale| in the clip coefficient (only there): with clip_norm_mult = the static
+ *          gradient-stream scale, sqrt(*gnorm_sq) * clip_norm_mult is the norm of the LOSS-SCALED gradients, i.e. the clip of the
+ *          reference's default fp16 branch, which calls clip_grad_norm_(model.parameters(), 1.0) on the scaled gradients before
+ *          scaler.step unscales them (Multimodal_example_task2C.py:712-717); 0 = clip the true gradients
  *     m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
  *     (L2 wd folds into g', decoupled wd scales p first); also refreshes the bf16 shadow copy
  *     p_bf16[i] for i < n_shadow (the GEMM operands).  n, n_shadow multiples of 4.
@@ -584,9 +588,13 @@ int mh_add_h16(const void* a, const void* b, void* y, int64_t n, mh_stream_t str
  *     of HBM traffic on the 49 M-element table (a batch touches at most B*S of its 64 000 rows).
  *   mh_cast_f32_bf16: shadow refresh on its own (after load_state_dict).
  *     `overflow` (device int32[1] or NULL) selects the GUARDED form used when a slice is updated before the global norm can
- *     exist (optimizer-in-backward): a launch that finds *overflow already set does nothing; otherwise a 4-element vector whose
- *     gradient is not finite keeps its parameters and moments and sets *overflow.  The slices of a step run in backward order on one
- *     stream, so an overflow at the loss skips the whole step, one further down leaves the layers above it updated.
+ *     exist (optimizer-in-backward); `guard_ordinal` >= 1 is then this launch's position among the step's guarded launches (1, 2,
+ *     ... in stream order).  *overflow holds the ordinal of the first launch of the step that met a non-finite gradient (0 = none):
+ *     a launch that finds an EARLIER launch's mark does nothing; otherwise a 4-element vector whose gradient is not finite keeps its
+ *     parameters and moments and marks *overflow with this launch's ordinal.  A launch never skips for its own mark, so what it
+ *     updates depends on the gradient data only, not on workgroup scheduling: deterministic, identical on data-parallel replicas.
+ *     The slices of a step run in backward order on one stream, so an overflow at the loss skips the whole step, one further down
+ *     leaves the layers above it updated.
  *   mh_adam_skip_account (steps that may be skipped: fp16 runs, the reference's GradScaler, Multimodal_example_task2C.py:60-64,
  *     712-717): ONE launch per step AFTER the update launches.  A step is "bad" when *gnorm_sq is not finite (exact path: the
  *     update kernels skipped it as a whole) or *loss_scale->overflow is set (guarded path; cleared here).  It counts bad steps in
@@ -620,13 +628,14 @@ int mh_sumsq_f32(const float* g, int64_t n, float* workspace /*>=1024 f32*/, flo
                  mh_stream_t stream);
 int mh_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t n,
                  int64_t n_shadow, const float* hyper /*device f32[8]*/, int decoupled,
-                 const float* gnorm_sq /*device or NULL*/, float max_norm, int32_t* overflow /*device or NULL*/,
-                 mh_stream_t stream);
+                 const float* gnorm_sq /*device or NULL*/, float max_norm, float clip_norm_mult /*0: clip true gradients*/,
+                 int32_t* overflow /*device or NULL*/, int guard_ordinal /*>= 1 with overflow, else ignored*/, mh_stream_t stream);
 int mh_adam_step_rows(float* p, float* m, float* v, const float* g,
                       uint8_t* row_live /*[rows] optimizer state: 1 = this row's m / v may be non-zero*/,
                       const uint8_t* row_touched /*[rows] or NULL: rows that have received a gradient (mh_bert_embed_bwd);
                       OR-ed into row_live*/, int rows, int D, const float* hyper /*device f32[8]*/, int decoupled,
-                      const float* gnorm_sq, float max_norm, int32_t* overflow /*device or NULL*/, mh_stream_t stream);
+                      const float* gnorm_sq, float max_norm, float clip_norm_mult, int32_t* overflow /*device or NULL*/,
+                      int guard_ordinal, mh_stream_t stream);
 int mh_cast_f32_bf16(const float* src, void* dst, int64_t n, mh_stream_t stream);
 int mh_cast_bf16_f32(const void* src, float* dst, int64_t n, mh_stream_t stream);
 /* Data-parallel gradient exchange with 16-bit wire format (ddp.GradientReducer(compress="bf16")): out[i] = 16-bit(sum_w

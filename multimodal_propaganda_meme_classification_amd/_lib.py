@@ -201,8 +201,8 @@ _PROTOS = {
     "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p],
     "mh_adam_skip_account": [C.POINTER(MhAdamSkipGroups), c_void_p, c_void_p, c_void_p, C.POINTER(MhLossScale), c_void_p],
     "mh_sumsq_f32": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
-    "mh_adam_step": [c_void_p] * 5 + [c_int64, c_int64, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p],
-    "mh_adam_step_rows": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p],
+    "mh_adam_step": [c_void_p] * 5 + [c_int64, c_int64, c_void_p, c_int, c_void_p, c_float, c_float, c_void_p, c_int, c_void_p],
+    "mh_adam_step_rows": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_float, c_void_p, c_int, c_void_p],
     "mh_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "mh_cast_bf16_f32": [c_void_p, c_void_p, c_int64, c_void_p],
     "mh_sum_shards_16": [c_void_p, c_void_p, c_int, c_int64, c_void_p],

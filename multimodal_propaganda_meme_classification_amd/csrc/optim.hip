@@ -42,12 +42,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float* __restrict__ v, const float* __restrict__ g,
                                                    h16* __restrict__ shadow, int64_t n, int64_t n_shadow,
                                                    const float* __restrict__ hyper, int decoupled,
-                                                   const float* __restrict__ gnorm_sq, float max_norm,
-                                                   int32_t* __restrict__ overflow) {
-    // guarded form: once a slice of this step has met a non-finite gradient, every later launch of the step is a no-op -- the
+                                                   const float* __restrict__ gnorm_sq, float max_norm, float clip_norm_mult,
+                                                   int32_t* __restrict__ overflow, int ordinal) {
+    // guarded form: once a slice of this step has met a non-finite gradient, every LATER launch of the step is a no-op -- the
     // slices run in backward order on one stream, so an overflow at the loss skips the whole step (GradScaler.step), one that
-    // appears further down the gradient stream leaves only the layers above it updated, with the finite gradients they had
-    if (overflow && *(volatile int32_t*)overflow) return;
+    // appears further down the gradient stream leaves only the layers above it updated, with the finite gradients they had.
+    // *overflow holds the ORDINAL (1, 2, ... in launch order within the step) of the first launch that met one, 0 = none.  A
+    // launch skips only for an EARLIER launch's mark (w < ordinal), never for one its own workgroups are writing: which
+    // workgroups of the overflowing launch still update depends on the gradient data alone, not on block scheduling -- replicas
+    // that see the same reduced gradients end with the same master weights, and a run is reproducible.
+    if (overflow) {
+        const int w = *(volatile int32_t*)overflow;
+        if (w != 0 && w < ordinal) return;
+    }
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
     const float inv_bc1 = hyper[5], inv_sqrt_bc2 = hyper[6];
     float gs = hyper[7];
@@ -56,7 +63,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         // a non-finite gradient norm (an overflowed 16-bit gradient stream): the whole step is skipped, parameters and
         // moments untouched -- what torch.cuda.amp.GradScaler.step does (Multimodal_example_task2C.py:712-717)
         if (!(nrm <= 3.0e38f)) return;
-        if (max_norm > 0.f) gs *= fminf(1.0f, max_norm / (nrm + 1e-6f));
+        // clip_norm_mult > 0: the clip coefficient is computed on the norm of the gradients AS THE LOSS SCALE LEFT THEM (the buffer's
+        // norm times the static stream scale) -- the reference's default branch clips before unscaling (Multimodal_example_task2C.py:713-717)
+        const float nrm_clip = clip_norm_mult > 0.f ? sqrtf(gnorm_sq[0]) * clip_norm_mult : nrm;
+        if (max_norm > 0.f) gs *= fminf(1.0f, max_norm / (nrm_clip + 1e-6f));
     }
     const float step = lr * inv_bc1;
     const float decay = decoupled ? 1.0f - lr * wd : 1.0f;
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
             // mh_adam_skip_account counts it and backs the loss scale off
             const float a = fabsf(gv[0]) + fabsf(gv[1]) + fabsf(gv[2]) + fabsf(gv[3]);
             if (!(a <= 3.0e38f)) {
-                *overflow = 1;
+                *overflow = ordinal;
                 continue;
             }
         }
@@ -158,9 +168,12 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
                                                         uint8_t* __restrict__ row_live,
                                                         const uint8_t* __restrict__ row_touched, int rows, int D,
                                                         const float* __restrict__ hyper, int decoupled,
-                                                        const float* __restrict__ gnorm_sq, float max_norm,
-                                                        int32_t* __restrict__ overflow) {
-    if (overflow && *(volatile int32_t*)overflow) return;
+                                                        const float* __restrict__ gnorm_sq, float max_norm, float clip_norm_mult,
+                                                        int32_t* __restrict__ overflow, int ordinal) {
+    if (overflow) {      // (as in adam_kernel: only an EARLIER launch's mark stops this one)
+        const int w = *(volatile int32_t*)overflow;
+        if (w != 0 && w < ordinal) return;
+    }
     const int lane = threadIdx.x & 63;
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
     const float inv_bc1 = hyper[5], inv_sqrt_bc2 = hyper[6];
@@ -170,7 +183,10 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
         // a non-finite gradient norm (an overflowed 16-bit gradient stream): the whole step is skipped, parameters and
         // moments untouched -- what torch.cuda.amp.GradScaler.step does (Multimodal_example_task2C.py:712-717)
         if (!(nrm <= 3.0e38f)) return;
-        if (max_norm > 0.f) gs *= fminf(1.0f, max_norm / (nrm + 1e-6f));
+        // clip_norm_mult > 0: the clip coefficient is computed on the norm of the gradients AS THE LOSS SCALE LEFT THEM (the buffer's
+        // norm times the static stream scale) -- the reference's default branch clips before unscaling (Multimodal_example_task2C.py:713-717)
+        const float nrm_clip = clip_norm_mult > 0.f ? sqrtf(gnorm_sq[0]) * clip_norm_mult : nrm;
+        if (max_norm > 0.f) gs *= fminf(1.0f, max_norm / (nrm_clip + 1e-6f));
     }
     const float step = lr * inv_bc1;
     const float decay = decoupled ? 1.0f - lr * wd : 1.0f;
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
             if (overflow) {
                 const float a = fabsf(gv[0]) + fabsf(gv[1]) + fabsf(gv[2]) + fabsf(gv[3]);
                 if (!(a <= 3.0e38f)) {
-                    *overflow = 1;
+                    *overflow = ordinal;
                     continue;
                 }
             }
@@ -280,8 +296,9 @@ extern "C" int mh_adam_skip_account(const MhAdamSkipGroups* groups, const float*
 
 extern "C" int mh_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t n,
                             int64_t n_shadow, const float* hyper, int decoupled, const float* gnorm_sq,
-                            float max_norm, int32_t* overflow, mh_stream_t stream) {
+                            float max_norm, float clip_norm_mult, int32_t* overflow, int guard_ordinal, mh_stream_t stream) {
     if (!p || !m || !v || !g || !hyper) return MH_EINVAL;
+    if (overflow && guard_ordinal < 1) return MH_EINVAL;
     if (n < 4 || (n & 3) || (n_shadow & 3) || n_shadow > n) return MH_ESHAPE;
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
     // MEMEHIP_ADAM_BLOCKS (A/B switch): cap on the grid of a GUARDED launch, i.e. of a slice that runs on the side stream beside the
@@ -298,19 +315,21 @@ extern "C" int mh_adam_step(float* p, float* m, float* v, const float* g, void* 
         grid = (int)(b < cap ? b : cap);
     }
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, m, v, g,
-                       (h16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm, overflow);
+                       (h16*)p_bf16, n, n_shadow, hyper, decoupled, gnorm_sq, max_norm, clip_norm_mult, overflow, guard_ordinal);
     return mh_launch_status();
 }
 
 extern "C" int mh_adam_step_rows(float* p, float* m, float* v, const float* g, uint8_t* row_live,
                                  const uint8_t* row_touched, int rows, int D, const float* hyper, int decoupled,
-                                 const float* gnorm_sq, float max_norm, int32_t* overflow, mh_stream_t stream) {
+                                 const float* gnorm_sq, float max_norm, float clip_norm_mult, int32_t* overflow, int guard_ordinal,
+                                 mh_stream_t stream) {
     if (!p || !m || !v || !g || !row_live || !hyper) return MH_EINVAL;
+    if (overflow && guard_ordinal < 1) return MH_EINVAL;
     if (rows < 1 || D < 4 || (D & 3)) return MH_ESHAPE;
     if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) return MH_EINVAL;
     const int blocks = (rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096;
     hipLaunchKernelGGL(adam_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, g, row_live, row_touched,
-                       rows, D, hyper, decoupled, gnorm_sq, max_norm, overflow);
+                       rows, D, hyper, decoupled, gnorm_sq, max_norm, clip_norm_mult, overflow, guard_ordinal);
     return mh_launch_status();
 }
 

@@ -106,7 +106,8 @@ best_macro_f1 = 0.0          # the reference's module global (Multimodal_example
 
 def train(model, train_loader, criterion, optimizer, scheduler, device, epoch, scaler=None, image_pipeline: Optional[DeviceImagePipeline] = None,
           max_grad_norm: Optional[float] = None, eval_fn: Optional[Callable] = None, log_every: int = 10, test_df=None, val_df=None,
-          stay_in_eval_mode_after_check: bool = True, evaluate_kwargs: Optional[dict] = None) -> Tuple[float, float]:
+          stay_in_eval_mode_after_check: bool = True, evaluate_kwargs: Optional[dict] = None,
+          clip_scaled_gradients: Optional[bool] = None) -> Tuple[float, float]:
     """Multimodal_example_task2C.py:688-776.
 
     ``test_df`` / ``val_df`` (the reference reads them as globals, :756-759): when given, the reference's mid-epoch check runs every
@@ -121,12 +122,26 @@ def train(model, train_loader, criterion, optimizer, scheduler, device, epoch, s
     object carries the dynamic scale (halved on a skipped step, doubled after ``growth_interval`` clean ones) the way
     ``torch.cuda.amp.GradScaler`` does for the reference's fp16 branch (:712-717).  With ``memehip.Adam(..., max_grad_norm=...)`` the
     clip happens inside the fused update (one global norm); for any other optimizer ``max_grad_norm`` (reference: 1.0 under fp16, 10.0
-    otherwise) is applied with ``clip_grad_norm_``."""
+    otherwise) is applied with ``clip_grad_norm_``.
+
+    ``clip_scaled_gradients`` (default: True when a scaler is passed, else False): the reference's DEFAULT branch (``USE_FP16 = True``,
+    :60) clips the gradients as ``scaler.scale(loss).backward()`` left them -- ``clip_grad_norm_(model.parameters(), 1.0)`` at :715
+    with no ``unscale_`` before it -- and only then lets ``scaler.step`` divide by the scale (:716).  With torch's scale of 65536 the
+    clipped TRUE gradient has norm <= 1.5e-5: the step is a fraction of the learning rate.  True reproduces exactly that (pinned to
+    the reference run: tests/golden/ref_kevin_2c_fp16.npz); False unscales first and clips the true gradients, the corrected
+    semantics.  With ``memehip.Adam`` the flag is written to ``optimizer.clip_scaled_gradients``."""
     global best_macro_f1
     from .model import Adam
     model.train()
     pipe = image_pipeline or DeviceImagePipeline(mode="stretch", augment=True, device=device)
     fused = isinstance(optimizer, Adam)
+    if clip_scaled_gradients is None:
+        clip_scaled_gradients = scaler is not None and hasattr(scaler, "scale")
+    if fused:
+        optimizer.clip_scaled_gradients = bool(clip_scaled_gradients)
+        if scaler is not None and hasattr(scaler, "step") and hasattr(optimizer, "_attach_scaler") and getattr(scaler, "is_enabled", lambda: True)():
+            if hasattr(scaler, "_optimizers"):
+                optimizer._attach_scaler(scaler)          # before the first grad_norm(): the logged norm divides the scale out
     loss_sum = torch.zeros((), device=device)
     correct = torch.zeros((), device=device)
     total_batches = len(train_loader)
@@ -145,8 +160,8 @@ def train(model, train_loader, criterion, optimizer, scheduler, device, epoch, s
         if fused:
             grad_norm = optimizer.grad_norm() if (log_every and batch_idx % log_every == 0) else None
         else:
-            if scaler is not None and hasattr(scaler, "unscale_"):
-                scaler.unscale_(optimizer)                      # torch.cuda.amp.GradScaler with a torch optimizer: clip the true gradients
+            if scaler is not None and hasattr(scaler, "unscale_") and not clip_scaled_gradients:
+                scaler.unscale_(optimizer)                      # corrected semantics: clip the TRUE gradients (the reference clips the scaled ones, :713-715)
             grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), float("inf"))
             if max_grad_norm is not None:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)

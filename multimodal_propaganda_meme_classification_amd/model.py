@@ -642,11 +642,19 @@ class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, decoupled_weight_decay: bool = False, max_grad_norm: Optional[float] = None,
                  model: Optional[MultimodalClassifier] = None, skip_untouched_embedding_rows: bool = True,
-                 skip_nonfinite=None):
+                 skip_nonfinite=None, clip_scaled_gradients: bool = False):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.decoupled = decoupled_weight_decay
         self.max_grad_norm = max_grad_norm
+        # clip_scaled_gradients: the clip coefficient min(1, max_grad_norm / norm) is computed on the norm of the LOSS-SCALED gradients
+        # (true norm x GradScaler scale x the fp16 build's static stream scale) -- what the reference's default branch does: USE_FP16 =
+        # True (Multimodal_example_task2C.py:60), clip_grad_norm_(model.parameters(), 1.0) on the gradients scaler.scale(loss).backward()
+        # left, no unscale_ first, then scaler.step (:712-717).  With torch's initial scale of 65536 that clips nearly every step to a
+        # true-gradient norm of 1.5e-5 -- elements ~1e-9, below Adam's eps -- so the update is a small fraction of lr.  False (default):
+        # clip the true gradients (what the fp32 branch does and what the fp16 branch presumably meant).  kevin.train() turns it on when
+        # a scaler is passed, as the reference behaves.
+        self.clip_scaled_gradients = bool(clip_scaled_gradients)
         # skip_nonfinite: never let a non-finite gradient (an overflowed fp16 gradient stream) into the master weights -- the
         # reference's fp16 branch gets this from GradScaler (Multimodal_example_task2C.py:60-64,712-717).
         #   None (default): on when a model this optimizer updates stores 16-bit values as fp16, or a GradScaler is attached
@@ -666,10 +674,32 @@ class Adam(torch.optim.Optimizer):
         self._model = model
         self._flat = None
         self._step = 0
-        self.grad_scale = 1.0          # DDP sets 1/world_size (all-reduce sums)
+        self._grad_scale = 1.0         # DDP sets 1/world_size (all-reduce sums)
         # word-embedding rows that never received a gradient have g = m = v = 0: the dense Adam update is the identity
         # on them (weight_decay == 0), so they are skipped -- same numbers as torch.optim.Adam, ~1.4 GB less HBM traffic
         self.skip_untouched_rows = bool(skip_untouched_embedding_rows)
+
+    @property
+    def grad_scale(self) -> float:
+        return self._grad_scale
+
+    @grad_scale.setter
+    def grad_scale(self, value: float):
+        """hyper[7] lives on the device and, once the step's accounting kernel owns it, is not rewritten from the host: a change here
+        (GraphedStep sets 1 / world from the reducer) must re-initialise it, or the clip threshold and the non-finite check keep the
+        stale factor."""
+        if float(value) != self._grad_scale:
+            self._grad_scale = float(value)
+            self._hyper_init = False
+
+    def _clip_mult(self) -> float:
+        """mh_adam_step's clip_norm_mult: 0 = clip the true gradients; else |grad_scale| x the static stream scale, so that the
+        buffer's norm (true gradient x dynamic loss scale) times it is the norm of the gradients as the reference's scaler left them."""
+        if not self.clip_scaled_gradients or self.max_grad_norm is None:
+            return 0.0
+        model = self._flat["model"] if self._flat is not None else self._model
+        static = float(model.config.stream_scale) if (model is not None and hasattr(model, "config")) else 1.0
+        return abs(self._grad_scale) * static
 
     def _bind(self):
         """Group the parameters by the flat buffer they live in.  Usually that is ONE MultimodalClassifier; Kevin's
@@ -780,6 +810,7 @@ class Adam(torch.optim.Optimizer):
         if self._scaler is None:
             self._scaler = scaler
             self._hyper_init = False
+            scaler._optimizers.append(self)        # a host-side change of the scale must reach hyper[7] (GradScaler._scale_written)
             if self.skip_nonfinite in (None, False):
                 self.skip_nonfinite = True
 
@@ -850,6 +881,7 @@ class Adam(torch.optim.Optimizer):
         optimizer.step() after an overflow, so torch's Adam does not advance t either.  One 64-thread launch, graph-replayable
         (the host's step count is read from device memory)."""
         f = self._flat
+        self._guard_ordinal = 0
         grp = _lib.MhAdamSkipGroups()
         grp.n = len(self.param_groups)
         for gi, g in enumerate(self.param_groups):
@@ -902,6 +934,16 @@ class Adam(torch.optim.Optimizer):
             n = n / self._scaler._tensor(self._flat["P"].device)[0]
         return n
 
+    _guard_ordinal = 0         # guarded update launches issued so far in the current step (mh_adam_step: guard_ordinal)
+
+    def _next_ordinal(self, flag) -> int:
+        """Position of the next guarded launch within the step, in issue (= stream) order; the step's accounting launch resets it.
+        Inside a captured step the ordinals are constants of the graph, which is what they should be."""
+        if flag is None:
+            return 0
+        self._guard_ordinal += 1
+        return self._guard_ordinal
+
     def _launch_bucket(self, f, nrm, only, skip, flag=None):
         model = f["model"]
         n_shadow = model.layout.n_shadow if model is not None else 0
@@ -931,7 +973,8 @@ class Adam(torch.optim.Optimizer):
                     if a < ta:
                         nxt.append((gi, a, ta))
                     ops.adam_step_rows(f["P"][ta:tb], f["M"][ta:tb], f["V"][ta:tb], f["G"][ta:tb], f["row_live"], touched, V, D,
-                                       f["hyper"][gi], self.decoupled, nrm, float(self.max_grad_norm or 0.0), flag)
+                                       f["hyper"][gi], self.decoupled, nrm, float(self.max_grad_norm or 0.0), flag, self._next_ordinal(flag),
+                                       self._clip_mult())
                     if tb < b:
                         nxt.append((gi, tb, b))
                 else:
@@ -941,7 +984,7 @@ class Adam(torch.optim.Optimizer):
             sh_n = max(0, min(b, n_shadow) - a)            # part of this run that has a 16-bit shadow
             shadow = model.flat_shadow[a:a + sh_n] if (model is not None and sh_n > 0) else None
             ops.adam_step(f["P"][a:b], f["M"][a:b], f["V"][a:b], f["G"][a:b], shadow, sh_n, f["hyper"][gi], self.decoupled,
-                          nrm, float(self.max_grad_norm or 0.0), flag)
+                          nrm, float(self.max_grad_norm or 0.0), flag, self._next_ordinal(flag), self._clip_mult())
         if model is not None and only is None:
             model._shadow_synced()
 
@@ -1032,6 +1075,15 @@ class GradScaler:
         self._scale = None            # device f32[1]
         self._growth = None           # device i32[1]
         self._found = None            # torch-optimizer path: device f32[1]
+        self._unscaled = set()        # torch-optimizer path: ids of optimizers whose gradients unscale_() has already divided this step
+        self._optimizers = []         # memehip.Adam objects this scaler is attached to
+
+    def _scale_written(self):
+        """The scale word was written from the HOST (update(new_scale), load_state_dict): the attached optimizers' grad_scale /
+        loss-scale word hyper[7] is otherwise only rewritten by the device-side accounting of a step, so Adam would divide by the old
+        scale for one step -- make their next step re-initialise it."""
+        for opt in self._optimizers:
+            opt._hyper_init = False
 
     def is_enabled(self) -> bool:
         return self._enabled
@@ -1059,18 +1111,34 @@ class GradScaler:
             return outputs
         return outputs * self._tensor(outputs.device)[0]
 
+    def unscale_(self, optimizer):
+        """``torch.cuda.amp.GradScaler.unscale_``: divide the optimizer's gradients by the scale now (so that a ``clip_grad_norm_``
+        between backward and step sees the true gradients) and remember it -- ``step`` must not unscale a second time.  A no-op for
+        ``memehip.Adam``: its fused update divides the scale out itself and clips on the true norm (or, with
+        ``clip_scaled_gradients``, on the scaled one)."""
+        if not self._enabled or isinstance(optimizer, Adam):
+            return
+        if id(optimizer) in self._unscaled:
+            raise RuntimeError("unscale_() has already been called on this optimizer since the last update().")
+        grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+        if not grads:
+            return
+        sc = self._tensor(grads[0].device)
+        if self._found is None:
+            self._found = torch.zeros(1, dtype=F32, device=sc.device)
+        torch._amp_foreach_non_finite_check_and_unscale_(grads, self._found, 1.0 / sc)
+        self._unscaled.add(id(optimizer))
+
     def step(self, optimizer, *args, **kwargs):
         if not self._enabled:
             return optimizer.step(*args, **kwargs)
         if isinstance(optimizer, Adam):
             optimizer._attach_scaler(self)
             return optimizer.step(*args, **kwargs)
-        grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
-        if not grads:
+        if id(optimizer) not in self._unscaled:
+            self.unscale_(optimizer)
+        if self._found is None:
             return None
-        sc = self._tensor(grads[0].device)
-        self._found = torch.zeros(1, dtype=F32, device=sc.device)
-        torch._amp_foreach_non_finite_check_and_unscale_(grads, self._found, 1.0 / sc)
         if float(self._found) == 0.0:
             return optimizer.step(*args, **kwargs)
         return None
@@ -1078,9 +1146,12 @@ class GradScaler:
     def update(self, new_scale: Optional[float] = None):
         if not self._enabled:
             return
+        self._unscaled.clear()
         if new_scale is not None:
             self._tensor(self._scale.device if self._scale is not None else "cuda").fill_(float(new_scale))
             self._growth.zero_()
+            self._found = None
+            self._scale_written()
         elif self._found is not None:          # torch-optimizer path; with memehip.Adam the step's accounting kernel has done it
             torch._amp_update_scale_(self._scale, self._growth, self._found, self.growth_factor, self.backoff_factor, self.growth_interval)
             self._scale.clamp_(self.min_scale, self.max_scale)
@@ -1101,6 +1172,7 @@ class GradScaler:
         else:
             self._scale.fill_(float(sd["scale"]))
             self._growth.fill_(int(sd["growth_tracker"]))
+            self._scale_written()
 
 
 def flatten_parameters(module: nn.Module) -> nn.Module:

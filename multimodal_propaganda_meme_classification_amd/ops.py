@@ -556,7 +556,7 @@ def sumsq(g, workspace, out):
     check(_lib.load().mh_sumsq_f32(_p(g), g.numel(), _p(workspace), _p(out), _stream()), "mh_sumsq_f32")
 
 
-def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0, overflow=None):
+def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0, overflow=None, ordinal=0, clip_norm_mult=0.0):
     for nm, t in (("p", p), ("m", m), ("v", v), ("g", g), ("hyper", hyper)):
         _chk(t, F32, nm)
     n = p.numel()
@@ -565,10 +565,10 @@ def adam_step(p, m, v, g, shadow, n_shadow, hyper, decoupled=False, gnorm_sq=Non
         _chk(shadow, BF16, "shadow")
         assert shadow.numel() >= n_shadow
     check(_L(shadow if shadow is not None else p).mh_adam_step(_p(p), _p(m), _p(v), _p(g), _p(shadow), n, n_shadow if shadow is not None else 0,
-                                   _p(hyper), int(decoupled), _p(gnorm_sq), float(max_norm), _p(overflow), _stream()), "mh_adam_step")
+                                   _p(hyper), int(decoupled), _p(gnorm_sq), float(max_norm), float(clip_norm_mult), _p(overflow), int(ordinal), _stream()), "mh_adam_step")
 
 
-def adam_step_rows(p, m, v, g, row_live, row_touched, rows, D, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0, overflow=None):
+def adam_step_rows(p, m, v, g, row_live, row_touched, rows, D, hyper, decoupled=False, gnorm_sq=None, max_norm=0.0, overflow=None, ordinal=0, clip_norm_mult=0.0):
     """mh_adam_step_rows: Adam over a [rows][D] table, rows with no gradient history skipped (row_live |= row_touched)."""
     for nm, t in (("p", p), ("m", m), ("v", v), ("g", g), ("hyper", hyper)):
         _chk(t, F32, nm)
@@ -577,7 +577,7 @@ def adam_step_rows(p, m, v, g, row_live, row_touched, rows, D, hyper, decoupled=
     if not (row_live.is_cuda and row_live.dtype == torch.uint8 and row_live.numel() >= rows):
         raise TypeError("row_live must be a device uint8 tensor with one byte per row")
     check(_lib.load().mh_adam_step_rows(_p(p), _p(m), _p(v), _p(g), _p(row_live), _p(row_touched), rows, D, _p(hyper), int(decoupled),
-                                        _p(gnorm_sq), float(max_norm), _p(overflow), _stream()), "mh_adam_step_rows")
+                                        _p(gnorm_sq), float(max_norm), float(clip_norm_mult), _p(overflow), int(ordinal), _stream()), "mh_adam_step_rows")
 
 
 def cast_f32_bf16(src, dst):

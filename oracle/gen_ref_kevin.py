@@ -13,6 +13,7 @@ fixture records that: ``train_mode_flags`` = [1, 1, 0, 0].
 """
 from __future__ import annotations
 
+import contextlib
 import json
 import os
 import random
@@ -31,7 +32,7 @@ NAMES = ("MultimodalDataset", "LLMWithClassificationHead", "MCA3", "ConcatAttent
          "train", "test", "evaluate")
 
 
-def kevin_namespace(workdir: str, cfg=E.KEVIN):
+def kevin_namespace(workdir: str, cfg=E.KEVIN, fp16: bool = False):
     import pandas as pd
     from PIL import Image
     from sklearn.metrics import auc, f1_score, roc_curve
@@ -81,8 +82,9 @@ def kevin_namespace(workdir: str, cfg=E.KEVIN):
               f1_score=f1_score, roc_curve=roc_curve, auc=auc, DataLoader=DataLoader, Dataset=Dataset, timm=timm, transforms=E.transforms,
               sigmoid_focal_loss=E.focal_standin, get_linear_schedule_with_warmup=get_linear_schedule_with_warmup, AutoModel=AutoModel,
               AutoTokenizer=AutoTokenizer, ImageCaptioning=ImageCaptioning,
-              # setup()'s globals (:59-86)
-              USE_FP16=False, scaler=None, fold=0, text_model=TEXT_NAME, english_text_model=ENG_NAME, image_model=IMAGE_NAME,
+              # setup()'s globals (:59-86).  fp16=True: the script's DEFAULT (USE_FP16 = True, :60); on this CPU `autocast()` is a null
+              # context (the arithmetic stays fp32: what is pinned is the order clip -> unscale of :712-717, not half precision)
+              USE_FP16=bool(fp16), autocast=contextlib.nullcontext, scaler=None, fold=0, text_model=TEXT_NAME, english_text_model=ENG_NAME, image_model=IMAGE_NAME,
               fusion_method="concatenation", train_max_seq_len=cfg["seq_len"], best_macro_f1=0.0, device=torch.device("cpu"))
     E.extract(REF_PY, NAMES, ns)
     return ns, tok_ar, tok_en, state
@@ -104,7 +106,10 @@ def ref_key(n: str, vit) -> str:
     return n
 
 
-def gen_kevin(cfg=E.KEVIN):
+def gen_kevin(cfg=E.KEVIN, fp16: bool = False):
+    """fp16=False: the fp32 branch (clip at 10.0 on the true gradients) -> ref_kevin_2c.npz.  fp16=True: the reference's DEFAULT branch
+    (:701-717: scaler.scale(loss).backward(), clip_grad_norm_ at 1.0 on the SCALED gradients, scaler.step, scaler.update) with
+    torch.amp.GradScaler("cpu", init_scale=65536) -> ref_kevin_2c_fp16.npz (+ the scale after every step, both clip calls' norms)."""
     import pandas as pd
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -114,7 +119,7 @@ def gen_kevin(cfg=E.KEVIN):
         E.write_dataset(work)
         os.chdir(work)
         try:
-            ns, tok_ar, tok_en, state = kevin_namespace(work, cfg)
+            ns, tok_ar, tok_en, state = kevin_namespace(work, cfg, fp16)
             recs = E.records24()
             l2id = {"not_propaganda": 0, "propaganda": 1}
             df = pd.DataFrame({"id": [r["id"] for r in recs], "text": [r["text"] for r in recs], "image": [r["img_path"] for r in recs],
@@ -212,10 +217,22 @@ def gen_kevin(cfg=E.KEVIN):
                     first.update({n: p.grad.detach().clone() for n, p in model.named_parameters()})
             optimizer.register_step_pre_hook(grab)
             saved = set_dropout(model, 0.0)
-            train_loss, acc = ns["train"](model, loader, criterion, optimizer, scheduler, device, 0, None)        # :178-180
+            ref_scaler = torch.amp.GradScaler("cpu", init_scale=65536.0) if fp16 else None          # :61-62 GradScaler(): torch's default initial scale
+            scales = []
+            if fp16:
+                real_update = ref_scaler.update
+
+                def update_spy(*a, **k):
+                    r = real_update(*a, **k)
+                    scales.append(float(ref_scaler.get_scale()))
+                    return r
+                ref_scaler.update = update_spy
+            train_loss, acc = ns["train"](model, loader, criterion, optimizer, scheduler, device, 0, ref_scaler)        # :178-180
             set_dropout(model, saved=saved)
             torch.nn.utils.clip_grad_norm_ = real_clip
             out["grad_norm_before_clip"] = np.array([n for mx, n in clip_norms if mx == float("inf")])
+            out["clip_max_norms"] = np.array(sorted({mx for mx, n in clip_norms if mx != float("inf")}))
+            out["scaler_scale_after_step"] = np.array(scales)
             tr = [(t, o) for ph, t, o in fwd if ph == "train"]
             out["mid_epoch_test_outputs"] = torch.stack([o for ph, t, o in fwd if ph == "test"]).numpy()      # 4 test() calls x 4 batches
             out["train_outputs"] = torch.stack([o for _, o in tr]).numpy()
@@ -258,17 +275,20 @@ def gen_kevin(cfg=E.KEVIN):
             out["evaluate_probs_tsv"] = np.array(open("task2C_kevinmathew_probs_fold_0.tsv", encoding="utf-8").read().split("\n"))
         finally:
             os.chdir(cwd)
-    out["notes"] = np.array("fp32 branch (USE_FP16=False, clip 10.0); seq_len=128 (script: 512); batch 6 x 4; ListLoader over items read once "
+    out["notes"] = np.array(("DEFAULT branch (USE_FP16=True: clip 1.0 on the SCALED gradients, then scaler.step; torch.amp.GradScaler('cpu', 65536); "
+                             "autocast = null context, fp32 arithmetic; grad_*_step1 are the gradients the optimizer saw: scaled, clipped, unscaled)" if fp16 else
+                             "fp32 branch (USE_FP16=False, clip 10.0)") + "; seq_len=128 (script: 512); batch 6 x 4; ListLoader over items read once "
                             "from the reference Dataset (AUG_GEN seeded); train pass with every nn.Dropout p set to 0; warmup_steps=2 of 8; "
                             "BERT 4 layers + caption BERT 2 layers + ViT(512 wide, 8 heads, 4 layers); cpu fp32")
     for k, v in cfg.items():
         if not isinstance(v, dict):
             out["cfg_" + k] = np.array(v)
-    path = os.path.join(GOLDEN, "ref_kevin_2c.npz")
+    path = os.path.join(GOLDEN, "ref_kevin_2c_fp16.npz" if fp16 else "ref_kevin_2c.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays); train loss {train_loss:.6f} acc {acc:.4f}")
     print("train outputs:", out["train_outputs"], "modes", out["train_mode_flags"], "\nmid tests", out["mid_epoch_tests"], "\nfinal", out["final_test"])
 
 
 if __name__ == "__main__":
-    gen_kevin()
+    import sys
+    gen_kevin(fp16="--fp16" in sys.argv)

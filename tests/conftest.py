@@ -29,3 +29,14 @@ def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
+
+
+def parity_log(line: str) -> None:
+    """Every parity measurement the GPU tests make (max |hip - reference|, error / spread, gradient deviations, TSV flips) is printed
+    AND, when MEMEHIP_PARITY_OUT names a file, appended to it: tools/publish_parity.py runs the reference-run tests that way and commits
+    the result as profiles/rNN_parity.txt, so that every tolerance asserted in tests/ has its measured value on record next to it."""
+    print(line)
+    out = os.environ.get("MEMEHIP_PARITY_OUT")
+    if out:
+        with open(out, "a", encoding="utf-8") as f:
+            f.write(line + "\n")

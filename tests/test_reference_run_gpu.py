@@ -43,10 +43,11 @@ def _z(golden_dir, name):
 
 
 def _report(tag, got, ref):
+    from conftest import parity_log
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     err = float(np.abs(got - ref).max())
     spread = float(ref.std())
-    print(f"[{tag}] max |hip - reference| = {err:.3e}; spread of the reference values {spread:.3e}; error / spread = {err / max(spread, 1e-12):.3e}")
+    parity_log(f"[{tag}] max |hip - reference| = {err:.3e}; spread of the reference values {spread:.3e}; error / spread = {err / max(spread, 1e-12):.3e}")
     return err, spread
 
 
@@ -190,7 +191,7 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
 # ----------------------------------------------------------------------------------------------------------------------
 # Kevin: Multimodal_example_task2C.py
 # ----------------------------------------------------------------------------------------------------------------------
-def _kevin_setup(pkg, E, z, tmp_path):
+def _kevin_setup(pkg, E, z, tmp_path, compute_dtype="fp16"):
     cfg = E.KEVIN
     E.write_dataset(str(tmp_path))
     recs, caps = E.records24(), E.captions24()
@@ -211,7 +212,7 @@ def _kevin_setup(pkg, E, z, tmp_path):
     tc = pkg.TextConfig(vocab_size=tok_ar.vocab_size, hidden=768, layers=cfg["text_layers"], heads=12, intermediate=3072, max_position=512)
     cc = pkg.TextConfig(vocab_size=tok_en.vocab_size, hidden=768, layers=cfg["caption_layers"], heads=12, intermediate=3072, max_position=512)
     ic = pkg.ImageConfig(image_size=v["image_size"], patch=v["patch"], hidden=v["hidden"], layers=v["layers"], heads=v["heads"], intermediate=v["intermediate"])
-    model = pkg.KevinMultimodalClassifier("concatenation", text=tc, image=ic, caption=cc, proj=cfg["proj"], compute_dtype="fp16")
+    model = pkg.KevinMultimodalClassifier("concatenation", text=tc, image=ic, caption=cc, proj=cfg["proj"], compute_dtype=compute_dtype)
     state = E.kevin_state(tok_ar.vocab_size, tok_en.vocab_size, cfg)
     pfx = "image_model.image_model."
     ref_sd = {k: t for k, t in state.items() if not k.startswith(pfx)}
@@ -411,3 +412,74 @@ def test_kevin_reference_checkpoint_keys_round_trip(pkg, E, golden_dir, tmp_path
         assert torch.equal(got.reshape(t.shape), t), n
     with pytest.raises(RuntimeError, match="load_reference_state_dict"):
         model.load_reference_state_dict({"text_model.model.embeddings.nonsense": torch.zeros(1)})
+
+
+def test_kevin_default_fp16_branch_clips_the_scaled_gradients(pkg, E, golden_dir, tmp_path):
+    """The reference's DEFAULT training branch (USE_FP16 = True, Multimodal_example_task2C.py:60): scaler.scale(loss).backward(), then
+    clip_grad_norm_(model.parameters(), 1.0) on the still-SCALED gradients, then scaler.step / update (:712-717).  The fixture is that
+    branch run from the reference's own source with torch.amp.GradScaler('cpu', 65536) (oracle/gen_ref_kevin.py --fp16): the gradients
+    the optimizer sees have norm 1.5e-5, the parameters move ~9 % of what the fp32 branch moves them.  kevin.train(..., scaler) follows it
+    (memehip.Adam(clip_scaled_gradients=True), set by train() when a scaler is passed); clip_scaled_gradients=False is the corrected order.
+    bf16 build: the scale of 65536 on fp16 gradient streams overflows in the reference loop's eval-mode steps 3-4 (real fp16 hardware
+    would skip them too; the fixture's CPU arithmetic is fp32 and cannot)."""
+    from conftest import parity_log
+    kv = pkg.kevin
+    z = _z(golden_dir, "ref_kevin_2c_fp16")
+    z32 = _z(golden_dir, "ref_kevin_2c")
+    assert float(z["clip_max_norms"][0]) == 1.0 and list(z["scaler_scale_after_step"]) == [65536.0] * 4
+    lr = float(E.KEVIN["lr"])
+    deltas = {}
+    for scaled in (True, False):
+        cfg, model, state, loader = _kevin_setup(pkg, E, z, tmp_path / ("s" if scaled else "t"), compute_dtype="bf16")
+        device = torch.device("cuda")
+        model.to(device)
+        optimizer = pkg.Adam(model.get_params(lr), max_grad_norm=1.0)                  # fp16 branch: max_grad_norm = 1.0 (:714)
+        scaler = pkg.GradScaler(init_scale=65536.0, max_scale=65536.0, growth_interval=2000)      # GradScaler() (:62): torch's defaults
+        scheduler = pkg.get_linear_schedule_with_warmup(optimizer, num_warmup_steps=2, num_training_steps=8)
+        criterion = pkg.SigmoidFocalLoss()
+        fwd, norms = [], []
+        model.register_forward_hook(lambda m, a, o: fwd.append((bool(m.training), o.detach().float().cpu().clone())))
+        optimizer.register_step_pre_hook(lambda opt, a, k: norms.append(float(opt.grad_norm())))
+        for m_ in (model.text_dropout, model.caption_text_dropout, model.image_fine_tune[2]):
+            m_.p = 0.0
+        kv.best_macro_f1 = 0.0
+        ekw = dict(team_name="kevinmathew", run_id="r", fold=0, out_dir=str(tmp_path))
+        train_loss, acc = kv.train(model, loader, criterion, optimizer, scheduler, device, 0, scaler, test_df=loader, val_df=loader,
+                                   evaluate_kwargs=ekw, log_every=0, clip_scaled_gradients=None if scaled else False)
+        assert optimizer.clip_scaled_gradients is scaled
+        assert scaler.get_scale() == 65536.0 and optimizer.skipped_steps == 0
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        names = [str(n) for n in z["param_names"]]
+        d_hip, d_ref, d_ref32 = [], [], []
+        for i, n in enumerate(names):
+            f = sd[_hip_name(n)].reshape(-1)
+            idx = E.sample_index(f.numel())
+            init = state[n].reshape(-1)[idx].numpy().astype(np.float64)
+            d_hip.append(f[idx].numpy().astype(np.float64) - init)
+            d_ref.append(z["param_samples_after"][i].astype(np.float64) - init)
+            d_ref32.append(z32["param_samples_after"][i].astype(np.float64) - init)
+        d_hip, d_ref, d_ref32 = (np.concatenate(x) for x in (d_hip, d_ref, d_ref32))
+        deltas[scaled] = d_hip
+        if scaled:
+            # what clip_grad_norm_(.., inf) returns in the reference's fp16 branch is the norm of the SCALED gradients (:713)
+            ref_norms = z["grad_norm_before_clip"]
+            hip_scaled = [n * 65536.0 for n in norms]
+            parity_log("[Kevin default branch] scaled gradient norm per step: hip " + " ".join(f"{n:.4g}" for n in hip_scaled) + " | reference " +
+                       " ".join(f"{n:.4g}" for n in ref_norms) + " | rel err " + " ".join(f"{abs(a - b) / b:.3f}" for a, b in zip(hip_scaled, ref_norms)))
+            tr = [o for t_, o in fwd]
+            rel = float(np.linalg.norm(d_hip - d_ref) / np.linalg.norm(d_ref))
+            ratio = float(np.linalg.norm(d_hip) / np.linalg.norm(d_ref))
+            ratio32 = float(np.linalg.norm(d_hip) / np.linalg.norm(d_ref32))
+            parity_log(f"[Kevin default branch] parameter movement after 4 steps over {d_ref.size} sampled elements: |d_hip - d_ref| / |d_ref| = {rel:.3f}; "
+                       f"|d_hip| / |d_ref| = {ratio:.3f}; against the fp32 branch's movement |d_hip| / |d_ref32| = {ratio32:.3f} "
+                       f"(reference: {np.linalg.norm(d_ref) / np.linalg.norm(d_ref32):.3f}); lr = {lr:g}, max |d_ref| = {np.abs(d_ref).max():.3e}")
+            parity_log(f"[Kevin default branch] train loss {train_loss:.5f} vs {float(z['train_loss']):.5f}, accuracy {acc:.4f} vs {float(z['train_acc']):.4f}")
+            # measured (profiles/r04_parity.txt, bf16 build): 0.023 / 0.114 / 0.096 / 0.272 -- steps 3-4 are the reference loop's eval-mode
+            # steps, where BatchNorm on running statistics amplifies the 8-bit significand's error; movement ratio 0.969, rel 0.366
+            assert all(abs(a - b) < tol * b for a, b, tol in zip(hip_scaled, ref_norms, (0.05, 0.23, 0.2, 0.55)))
+            assert 0.9 < ratio < 1.1 and rel < 0.7
+            assert abs(train_loss - float(z["train_loss"])) < 3e-2 and abs(acc - float(z["train_acc"])) <= 2 / 24 + 1e-9
+    # the corrected order (unscale, then clip the true gradients at 1.0) moves the parameters several times further
+    r = float(np.linalg.norm(deltas[False]) / np.linalg.norm(deltas[True]))
+    parity_log(f"[Kevin default branch] clip_scaled_gradients=False moves the parameters {r:.2f}x as far as the reference's order")
+    assert r > 3.0
