@@ -19,6 +19,25 @@ import torch.distributed as dist
 # everything that holds RCCL work handles, comm streams or hipGraphs built around them: closed, in order, by shutdown()
 _LIVE_REDUCERS: "weakref.WeakSet" = weakref.WeakSet()
 _LIVE_STEPS: "weakref.WeakSet" = weakref.WeakSet()
+# Communicators this process has torn down / seen.  A hipGraph with more than one stream, captured and launched AFTER an RCCL
+# communicator has been created and destroyed in the same process, can fault inside hipGraphLaunch on this stack (ROCm 7.2 / torch
+# 2.10): reproduced in rounds 2, 3 and -- with every capture thread-local -- 4 (profiles/r04_segfault_record.md); the cause sits below
+# the HIP API and is not known.  The product therefore (1) creates ONE communicator per process and (2) refuses to replay graphs once
+# one has been destroyed: GraphedStep falls back to eager launches of the same plan (same results, ~same speed: DESIGN.md section 5).
+_DESTROYED = 0
+_SEEN_GROUP = False
+
+
+def note_process_group() -> None:
+    global _SEEN_GROUP
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        _SEEN_GROUP = True
+
+
+def communicator_was_destroyed() -> bool:
+    """True once an RCCL process group has been destroyed in this process -- by shutdown() or behind this module's back
+    (a group a GradientReducer / GraphedStep saw is gone)."""
+    return _DESTROYED > 0 or (_SEEN_GROUP and not (dist.is_available() and dist.is_initialized()))
 
 
 class _EventWork:
@@ -53,6 +72,7 @@ class GradientReducer:
         self._cstream = torch.cuda.Stream() if (compress and flat_grads.is_cuda) else None
         self._bufs = {}
         self._had_group = dist.is_initialized()
+        note_process_group()
         self.closed = False
         _LIVE_REDUCERS.add(self)
 
@@ -182,6 +202,9 @@ def shutdown(destroy_process_group: bool = True):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     if destroy_process_group and dist.is_initialized():
+        global _DESTROYED
+        if dist.get_backend() == "nccl":
+            _DESTROYED += 1
         dist.destroy_process_group()
 
 

@@ -1242,6 +1242,16 @@ class GraphedStep:
         self.plan = eng.plan(batch, seq_len, True, gather_world=(reducer.world if reducer is not None else 0))
         if model.weights_changed():
             model.refresh_shadow()
+        from . import ddp as _ddp
+        _ddp.note_process_group()
+        if use_graph and _ddp.communicator_was_destroyed() and os.environ.get("MEMEHIP_GRAPH_AFTER_PG_DESTROY") != "1":
+            # the known crash configuration (ddp._DESTROYED): run the same plan with eager launches instead of replaying a hipGraph
+            import warnings
+            warnings.warn("memehip.GraphedStep: an RCCL process group has been destroyed in this process; hipGraph replay after a "
+                          "communicator create / destroy cycle can fault inside hipGraphLaunch on this ROCm stack "
+                          "(profiles/r04_segfault_record.md) -- falling back to eager launches of the same step "
+                          "(MEMEHIP_GRAPH_AFTER_PG_DESTROY=1 overrides).  Create ONE communicator per process.", RuntimeWarning, stacklevel=2)
+            use_graph = False
         self.use_graph = use_graph
         self.reducer = reducer
         if reducer is not None:

@@ -31,10 +31,11 @@ def free_port() -> int:
         return sk.getsockname()[1]
 
 
-def parity_log(line: str) -> None:
+def parity_log(*parts) -> None:
     """Every parity measurement the GPU tests make (max |hip - reference|, error / spread, gradient deviations, TSV flips) is printed
     AND, when MEMEHIP_PARITY_OUT names a file, appended to it: tools/publish_parity.py runs the reference-run tests that way and commits
     the result as profiles/rNN_parity.txt, so that every tolerance asserted in tests/ has its measured value on record next to it."""
+    line = " ".join(str(x) for x in parts)
     print(line)
     out = os.environ.get("MEMEHIP_PARITY_OUT")
     if out:

@@ -5,6 +5,7 @@ lengths against the CPU oracle (whose CLIP branch is pinned to transformers' CLI
 import numpy as np
 import pytest
 import torch
+from conftest import parity_log
 
 pytestmark = pytest.mark.gpu
 BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
@@ -98,7 +99,7 @@ def test_config5_two_layers_at_the_true_shapes(pkg, dtype, tol):
     loss.backward()
     torch.cuda.synchronize()
     err = float((logits.detach().float().cpu() - ref_logits).abs().max())
-    print(f"[config 5, 2 layers, {dtype}] max |logit - oracle| = {err:.3e}")
+    parity_log(f"[config 5, 2 layers, {dtype}] max |logit - oracle| = {err:.3e}")
     assert err < tol and abs(float(loss.detach()) - float(ref_loss)) < tol
     rel_tol = 2e-2 if dtype == "fp16" else 5e-2
     for name, p in model.named_parameters():
@@ -133,7 +134,7 @@ def test_config5_full_depth_smoke(pkg):
     with torch.no_grad():
         got = model(text.cuda(), image.cuda(), mask.cuda()).float().cpu()
     err = float((got - ref).abs().max())
-    print(f"[config 5, 24 layers, fp16] max |logit - oracle| = {err:.3e}")
+    parity_log(f"[config 5, 24 layers, fp16] max |logit - oracle| = {err:.3e}")
     assert err < 1.5e-3          # 1e-3 at 12 layers; twice the depth
     model.train()
     opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from conftest import parity_log
 
 pytestmark = pytest.mark.gpu
 
@@ -88,7 +89,7 @@ def test_config3_within_1e3(pkg, golden_dir):
     with torch.no_grad():
         got = model(text.cuda(), image.cuda(), mask.cuda()).float().cpu()
     err = float((got - torch.from_numpy(z["logits"])).abs().max())
-    print("config3 fp16 logits err", err)
+    parity_log("config3 fp16 logits err", err)
     assert err <= LOGIT_TOL, err
     labels = torch.tensor([0, 1])
     _, _, ref_grads = O.loss_and_grads(params, text, image, mask, labels, cfg)
@@ -96,7 +97,7 @@ def test_config3_within_1e3(pkg, golden_dir):
     model.forward_backward(text.cuda(), image.cuda(), mask.cuda(), labels.cuda())
     torch.cuda.synchronize()
     name, worst = _grad_rel(model, ref_grads)
-    print("config3 fp16 worst relative grad error", name, worst)
+    parity_log("config3 fp16 worst relative grad error", name, worst)
     assert worst <= 2e-2, (name, worst)
 
 
@@ -116,7 +117,7 @@ def test_config5_widths_two_layers(pkg):
     loss, _, logits = model.forward_backward(text.cuda(), image.cuda(), mask.cuda(), labels.cuda())
     torch.cuda.synchronize()
     err = float((logits.float().cpu() - ref_logits).abs().max())
-    print("config-5 widths: logits err", err)
+    parity_log("config-5 widths: logits err", err)
     assert err <= LOGIT_TOL and abs(float(loss) - float(ref_loss)) <= LOGIT_TOL
     name, worst = _grad_rel(model, ref_grads)
     assert worst <= 1e-2, (name, worst)

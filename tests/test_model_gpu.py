@@ -386,3 +386,19 @@ def test_ddp_two_ranks_on_one_gpu_match_the_global_batch():
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "DDP2 OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_graphed_step_falls_back_to_eager_after_a_communicator_was_destroyed():
+    """`ddp.shutdown()` + a fresh GraphedStep used to be able to segfault inside hipGraphLaunch (the create / destroy
+    cycle of an RCCL communicator, profiles/r04_segfault_record.md).  The product now notices that a communicator has been destroyed in
+    the process and runs the same plan with eager launches (RuntimeWarning), bit-identical results.  In a process of its own: destroying
+    a communicator inside the suite's process would push every later test onto the fallback."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from conftest import free_port
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.pop("MEMEHIP_GRAPH_AFTER_PG_DESTROY", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pg_destroy_guard_check.py")], cwd=root, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "PG-DESTROY GUARD OK" in out.stdout, out.stdout[-2000:]

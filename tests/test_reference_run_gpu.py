@@ -20,6 +20,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from conftest import parity_log
 
 pytestmark = pytest.mark.gpu
 
@@ -43,7 +44,6 @@ def _z(golden_dir, name):
 
 
 def _report(tag, got, ref):
-    from conftest import parity_log
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     err = float(np.abs(got - ref).max())
     spread = float(ref.std())
@@ -58,7 +58,21 @@ def _tsv_rows(lines):
 # ----------------------------------------------------------------------------------------------------------------------
 # organizers: Multimodal_example_task2C.txt
 # ----------------------------------------------------------------------------------------------------------------------
-def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, tmp_path):
+# what each dtype is held to: <= 2x the values measured on the MI355X (profiles/r04_parity.txt quotes them):
+#   err      max |logit - reference| over the 3 train batches         measured fp16 2.46e-2
+#   worst_t  worst step-1 gradient-norm deviation, text tower + head  measured fp16 0.42 %
+#   worst_r  the same for the ResNet-50 tower                          measured fp16 16.3 %
+#   err_t    max |logit - reference| of test() after the epoch        measured fp16 3.20e-2
+#   gsample  sampled step-1 gradient elements, error relative to the largest sampled element
+#            (measured bf16 31 % on fusion_fc.weight: the ResNet half of its input carries the tower's BatchNorm-amplified noise)
+#   bf16: err 3.32e-2, worst_t 2.26 %, worst_r 24.4 %
+ORG_TOL = {"fp16": dict(err=4e-2, worst_t=0.01, worst_r=0.33, err_t=4.5e-2, loss=5e-3, flips=0.97, gsample=0.05, bn=1.0),
+           "bf16": dict(err=6.5e-2, worst_t=0.045, worst_r=0.49, err_t=0.1, loss=2e-2, flips=0.9, gsample=0.6, bn=8.0)}
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, tmp_path, dtype):
+    TOL = ORG_TOL[dtype]
     z = _z(golden_dir, "ref_organizers_2c")
     cfg = {k[4:]: z[k] for k in z.files if k.startswith("cfg_")}
     seq, B, layers = int(cfg["seq_len"]), int(cfg["batch"]), tuple(int(x) for x in cfg["resnet_layers"])
@@ -75,7 +89,7 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
     # ---- the model, from the reference module's state_dict keys
     tc = pkg.TextConfig(vocab_size=tok.vocab_size, hidden=768, layers=int(cfg["text_layers"]), heads=12, intermediate=3072, max_position=512,
                         type_vocab=0)
-    model = pkg.OrganizersMultimodalClassifier(2, text=tc, compute_dtype="fp16", resnet_layers=layers)
+    model = pkg.OrganizersMultimodalClassifier(2, text=tc, compute_dtype=dtype, resnet_layers=layers)
     state = E.organizers_state(tok.vocab_size, int(cfg["text_layers"]), layers, int(cfg["seed"]))
     state.update(E.bn_buffers_from_fixture(z, "resnet."))
     res = model.load_state_dict(state, strict=True)
@@ -99,7 +113,7 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
     model.bert_drop.p = 0.3
     got = torch.stack(seen).numpy()
     seen.clear()
-    err, spread = _report("organizers train logits, 3 batches of 8", got, z["train_logits"])
+    err, spread = _report(f"organizers train logits, 3 batches of 8, {dtype}", got, z["train_logits"])
     # A random-init ResNet-50 with train-mode BatchNorm over 8 images amplifies ANY 16-bit storage of its activations: the yardstick
     # is the fp32 CPU oracle with nothing but the tower's fp16 storage rounding inserted (oracle/resnet_oracle.py, storage=...),
     # pushed through the same three Linear layers.  The HIP path has to stay within 1.5x that inherent deviation (+ 2e-3 for the
@@ -110,13 +124,13 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
     torch.set_num_threads(min(16, os.cpu_count() or 8))
     with torch.no_grad():
         r32 = R.resnet_forward(p_res, R.new_bn_state(p_res), img0, layers, training=True)
-        r16 = R.resnet_forward(p_res, R.new_bn_state(p_res), img0, layers, training=True, storage=torch.float16)
+        r16 = R.resnet_forward(p_res, R.new_bn_state(p_res), img0, layers, training=True, storage=torch.float16 if dtype == "fp16" else torch.bfloat16)
         push = lambda r: (r @ state["resnet_fc.weight"].t()) @ state["fusion_fc.weight"][:, 512:].t() @ state["output_fc.weight"].t()
         inherent = float((push(r16) - push(r32)).abs().max())
     err0 = float(np.abs(got[0] - z["train_logits"][0]).max())
-    print(f"[organizers train logits, batch 1] hip error {err0:.3e}; fp16 activation storage alone moves the fp32 oracle's logits by {inherent:.3e}")
-    assert err0 <= 1.5 * inherent + 2e-3 and err < 4e-2
-    assert abs(train_loss - float(z["train_loss"])) < 5e-3 and abs(acc - float(z["train_acc"])) <= 1 / 24 + 1e-9
+    parity_log(f"[organizers train logits, batch 1, {dtype}] hip error {err0:.3e}; {dtype} activation storage alone moves the fp32 oracle's logits by {inherent:.3e}")
+    assert err0 <= 1.5 * inherent + 2e-3 and err < TOL["err"]
+    assert abs(train_loss - float(z["train_loss"])) < TOL["loss"] and abs(acc - float(z["train_acc"])) <= 1 / 24 + 1e-9
     # ---- step-1 gradients as the reference's optimizer saw them
     names = [str(n) for n in z["param_names"]]
     idx = {n: i for i, n in enumerate(names)}
@@ -133,16 +147,16 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
             worst_r = max(worst_r, (n, rel), key=lambda t: t[1])
         elif ref_norm > 1e-7:
             worst_t = max(worst_t, (n, rel), key=lambda t: t[1])
-    print(f"[organizers step-1 gradient norms] worst deviation: text tower + head {worst_t[1]:.3%} ({worst_t[0]}), ResNet {worst_r[1]:.3%} ({worst_r[0]})")
-    assert worst_t[1] < 0.03
+    parity_log(f"[organizers step-1 gradient norms, {dtype}] worst deviation: text tower + head {worst_t[1]:.3%} ({worst_t[0]}), ResNet {worst_r[1]:.3%} ({worst_r[0]})")
+    assert worst_t[1] < TOL["worst_t"]
     # a random-init train-mode-BatchNorm ResNet's gradients move by tens of percent under 16-bit storage alone (tests/test_resnet_gpu.py)
-    assert worst_r[1] < 0.6
+    assert worst_r[1] < TOL["worst_r"]
     for n in ("bert_fc.weight", "fusion_fc.weight", "output_fc.weight", "resnet_fc.weight", "bert.transformer.layer.5.ffn.lin2.weight",
               "bert.transformer.layer.0.attention.q_lin.weight"):
         ref = z["grad_samples_step1"][idx[n]]
         f = grads[n].reshape(-1)
         s = f[E.sample_index(f.numel())].numpy()
-        assert np.abs(s - ref).max() <= 0.05 * np.abs(ref).max() + 2e-6, (n, s, ref)
+        assert np.abs(s - ref).max() <= TOL["gsample"] * np.abs(ref).max() + 2e-6, (n, s, ref)
     # ---- parameters after the epoch: three Adam steps of 2e-5 each, in the reference's direction
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     lr, steps = float(cfg["lr"]), 3
@@ -157,12 +171,13 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
             moved = np.abs(ref - init) > 0.5 * lr
             agree += int((np.sign(s - init)[moved] == np.sign(ref - init)[moved]).sum())
             total += int(moved.sum())
-    print(f"[organizers parameters after 3 Adam steps] {agree}/{total} sampled text-tower / head elements moved in the reference's direction")
-    assert agree >= 0.97 * total
+    parity_log(f"[organizers parameters after 3 Adam steps, {dtype}] {agree}/{total} sampled text-tower / head elements moved in the reference's direction")
+    assert agree >= TOL["flips"] * total
     rm, rv = sd["resnet.bn1.running_mean"].numpy(), sd["resnet.bn1.running_var"].numpy()
-    assert np.abs(rm - z["bn1_running_mean_after"]).max() < 2e-3 and np.abs(rv - z["bn1_running_var_after"]).max() < 5e-3 * max(1.0, float(z["bn1_running_var_after"].max()))
+    assert np.abs(rm - z["bn1_running_mean_after"]).max() < 2e-3 * TOL["bn"] and \
+        np.abs(rv - z["bn1_running_var_after"]).max() < 5e-3 * TOL["bn"] * max(1.0, float(z["bn1_running_var_after"].max()))
     last = f"resnet.layer4.{layers[3] - 1}.bn3."
-    assert np.abs(sd[last + "running_mean"].numpy() - z["last_bn_running_mean_after"]).max() < 2e-2
+    assert np.abs(sd[last + "running_mean"].numpy() - z["last_bn_running_mean_after"]).max() < 2e-2 * TOL["bn"]
     assert int(sd["resnet.bn1.num_batches_tracked"]) == int(z["bn1_num_batches_tracked_after"]) == 3
     # ---- test() and evaluate() (eval mode; dropout modules as constructed)
     val_loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, drop_last=True)
@@ -170,8 +185,8 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
     got_t = torch.stack(seen).numpy()
     seen.clear()
     err_t, _ = _report("organizers test() logits (eval mode, after the epoch)", got_t, z["test_logits"])
-    assert err_t < 4e-2
-    assert abs(test_loss - float(z["test_loss"])) < 5e-3
+    assert err_t < TOL["err_t"]
+    assert abs(test_loss - float(z["test_loss"])) < TOL["loss"]
     margin = np.abs(z["test_logits"][..., 1] - z["test_logits"][..., 0]).reshape(-1)
     unsure = int((margin < 2 * err_t).sum())
     assert abs(test_acc - float(z["test_acc"])) <= unsure / margin.size + 1e-9
@@ -185,7 +200,7 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
         if g_[1] != r_[1]:
             flips += 1
             assert margin[k] < 2 * err_t, (k, g_, r_, margin[k])
-    print(f"[organizers evaluate()] 24 TSV lines, {flips} label(s) differ (all inside the numerical margin)")
+    parity_log(f"[organizers evaluate(), {dtype}] 24 TSV lines, {flips} label(s) differ (all inside the numerical margin)")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -273,11 +288,11 @@ def test_kevin_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, t
     got0 = torch.stack([o for _, o in fwd]).numpy()
     fwd.clear()
     err0, _ = _report("Kevin test() outputs on the initial state (eval mode)", got0, z["initial_test_outputs"])
-    assert err0 < 0.1 and abs(loss0 - ref_loss0) < 0.03 * ref_loss0 + 1e-3
+    assert err0 < 0.08 and abs(loss0 - ref_loss0) < 0.03 * ref_loss0 + 1e-3          # measured 4.1e-2 (profiles/r04_parity.txt)
     p_ref0 = 1 / (1 + np.exp(-z["initial_test_outputs"].reshape(-1).astype(np.float64)))
     perr0 = float(np.abs(1 / (1 + np.exp(-got0.reshape(-1).astype(np.float64))) - p_ref0).max())
     unsure0 = int((np.abs(p_ref0 - ref_thr0) < 2 * perr0).sum())
-    print(f"[Kevin test(), initial state] loss {loss0:.5f} vs {ref_loss0:.5f}, accuracy {acc0:.4f} vs {ref_acc0:.4f}, macro F1 {f10:.4f} vs {ref_f10:.4f}, "
+    parity_log(f"[Kevin test(), initial state] loss {loss0:.5f} vs {ref_loss0:.5f}, accuracy {acc0:.4f} vs {ref_acc0:.4f}, macro F1 {f10:.4f} vs {ref_f10:.4f}, "
           f"threshold {thr0:.5f} vs {ref_thr0:.5f}; max probability error {perr0:.2e}, {unsure0} probabilities that close to the threshold")
     assert abs(thr0 - ref_thr0) < 2 * perr0 + 1e-6 or unsure0 > 1
     assert abs(acc0 - ref_acc0) <= unsure0 / 24 + 1e-9
@@ -303,18 +318,19 @@ def test_kevin_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, t
     order += [pos, pos + 1]
     tr = [fwd[i] for i in order]
     ref_norms = z["grad_norm_before_clip"]
-    print("   global gradient norm per step (what clip_grad_norm_(.., inf) returns, :728): hip", [f"{n:.2f}" for n in norms], "reference",
+    parity_log("   global gradient norm per step (what clip_grad_norm_(.., inf) returns, :728): hip", [f"{n:.2f}" for n in norms], "reference",
           [f"{n:.2f}" for n in ref_norms])
-    assert all(abs(a - b) < (0.05 if i < 2 else 0.12) * b for i, (a, b) in enumerate(zip(norms, ref_norms)))
+    # measured relative errors 2.2 % / 0.14 % / 1.5 % / 2.7 % (profiles/r04_parity.txt)
+    assert all(abs(a - b) < tol * b for a, b, tol in zip(norms, ref_norms, (0.045, 0.01, 0.03, 0.055)))
     # the first mid-epoch check (after batch 2): test(test_df) in eval mode, before any eval-mode update
     mid = torch.stack([fwd[i][1] for i in range(2, 6)]).numpy()
     err_mid, _ = _report("Kevin mid-epoch test() outputs after 2 train-mode steps", mid, z["mid_epoch_test_outputs"][:4])
-    assert err_mid < 0.15
+    assert err_mid < 0.14          # measured 7.2e-2
     assert [int(t) for t, _ in tr] == [int(x) for x in z["train_mode_flags"]] == [1, 1, 0, 0]      # the reference trains on in eval mode
-    print(f"   optimizer.skipped_steps = {optimizer.skipped_steps}")
+    parity_log(f"   optimizer.skipped_steps = {optimizer.skipped_steps}")
     got = torch.stack([o for _, o in tr]).numpy()
     for b_ in range(4):
-        print(f"   batch {b_ + 1}: max err {np.abs(got[b_] - z['train_outputs'][b_]).max():.3e}  hip {got[b_][:3]} ref {z['train_outputs'][b_][:3]}")
+        parity_log(f"   batch {b_ + 1}: max err {np.abs(got[b_] - z['train_outputs'][b_]).max():.3e}  hip {got[b_][:3]} ref {z['train_outputs'][b_][:3]}")
     err, spread = _report("Kevin train-loop outputs, 4 batches of 6 (BatchNorm1d(1) output: unit variance)", got, z["train_outputs"])
     errs = [float(np.abs(got[b_] - z["train_outputs"][b_]).max()) for b_ in range(4)]
     # Five BatchNorm layers over 6 samples (the last one normalises the single logit to unit variance) amplify any error of the
@@ -322,7 +338,12 @@ def test_kevin_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, t
     # per 1e-5-sized Adam step (BatchNorm on running statistics no longer renormalises): the trajectory is followed, not reproduced
     # digit by digit.  Train-mode batches: 0.1; first eval-mode batch: 0.15; after an eval-mode update: the reference's own shift
     # (-1.5 -> -3.9) has to show.
-    assert errs[0] < 0.1 and errs[1] < 0.1 and errs[2] < 0.15 and errs[3] < 1.0, errs
+    # Measured (profiles/r04_parity.txt): 3.95e-2 / 2.21e-2 / 5.80e-2 on batches 1-3.  Batch 4 follows an eval-mode update; the reference's own
+    # outputs move by `shift` (mean of batch 3 -> mean of batch 4, ~2.4) between the two, and the HIP path has to follow that move: measured
+    # error 0.595 = 0.25 of it, held to 0.5 of it.
+    shift = abs(float(z["train_outputs"][3].mean()) - float(z["train_outputs"][2].mean()))
+    parity_log(f"[Kevin train loop] batch-4 error {errs[3]:.3f} = {errs[3] / shift:.3f} of the reference's own batch 3 -> 4 shift {shift:.3f}")
+    assert errs[0] < 0.08 and errs[1] < 0.045 and errs[2] < 0.12 and errs[3] < 0.5 * shift, errs
     assert float(got[3].mean()) < -1.5 and float(z["train_outputs"][3].mean()) < -1.5
     assert optimizer.skipped_steps == 0
     assert abs(train_loss - float(z["train_loss"])) < 2e-2 and abs(acc - float(z["train_acc"])) <= 2 / 24 + 1e-9
@@ -340,7 +361,7 @@ def test_kevin_train_test_evaluate_match_the_reference_run(pkg, E, golden_dir, t
         moved = np.abs(ref - init) > 0.5 * lr
         agree += int((np.sign(s - init)[moved] == np.sign(ref - init)[moved]).sum())
         total += int(moved.sum())
-    print(f"[Kevin parameters after 4 Adam steps] {agree}/{total} sampled elements moved in the reference's direction")
+    parity_log(f"[Kevin parameters after 4 Adam steps] {agree}/{total} sampled elements moved in the reference's direction")
     assert agree >= 0.95 * total
     for k in ("text_fc.1", "caption_text_fc.1", "fusion_layer.attention_layer.1", "fusion_layer.reduce.1", "output_fc.1"):
         ref_m, ref_v = z[f"bn_{k}_running_mean_after"], z[f"bn_{k}_running_var_after"]
@@ -392,12 +413,12 @@ def test_kevin_forward_decomposed_towers_then_head(pkg, E, golden_dir, tmp_path)
     worst_feat = 0.0
     for nm, got, ref in (("text", t_hip, t_ref), ("image", v_hip, v_ref), ("caption", c_hip, c_ref)):
         e, s_ = float((got - ref).abs().max()), float(ref.abs().max())
-        print(f"[Kevin towers] {nm}: max |hip - oracle| = {e:.3e} on features of magnitude {s_:.2f} ({e / s_:.2e} relative)")
+        parity_log(f"[Kevin towers] {nm}: max |hip - oracle| = {e:.3e} on features of magnitude {s_:.2f} ({e / s_:.2e} relative)")
         assert e < 3e-3 * s_, nm
         worst_feat = max(worst_feat, e)
     e_head = float((out_hip - out_mixed).abs().max())
     e_all = float((out_hip - out_ref).abs().max())
-    print(f"[Kevin head] fp32 HIP head vs torch fp32 head on the same (HIP) features: {e_head:.3e}; end to end {e_all:.3e} = "
+    parity_log(f"[Kevin head] fp32 HIP head vs torch fp32 head on the same (HIP) features: {e_head:.3e}; end to end {e_all:.3e} = "
           f"{e_all / worst_feat:.0f}x the worst feature error (the conditioning of five BatchNorm layers over 6 samples)")
     assert e_head < 2e-4
 
@@ -422,7 +443,6 @@ def test_kevin_default_fp16_branch_clips_the_scaled_gradients(pkg, E, golden_dir
     (memehip.Adam(clip_scaled_gradients=True), set by train() when a scaler is passed); clip_scaled_gradients=False is the corrected order.
     bf16 build: the scale of 65536 on fp16 gradient streams overflows in the reference loop's eval-mode steps 3-4 (real fp16 hardware
     would skip them too; the fixture's CPU arithmetic is fp32 and cannot)."""
-    from conftest import parity_log
     kv = pkg.kevin
     z = _z(golden_dir, "ref_kevin_2c_fp16")
     z32 = _z(golden_dir, "ref_kevin_2c")

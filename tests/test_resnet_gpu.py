@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+from conftest import parity_log
 
 pytestmark = pytest.mark.gpu
 F16, BF16, F32 = torch.float16, torch.bfloat16, torch.float32
@@ -158,7 +159,7 @@ def test_resnet_tower_forward_backward_matches_the_oracle(pkg, dtype, ftol, gtol
     torch.cuda.synchronize()
     err = float((logits.detach().float().cpu() - ref_logits).abs().max())
     errq = float((logits.detach().float().cpu() - q_logits).abs().max())
-    print(f"[resnet {dtype}] max |logit - fp32 oracle| = {err:.3e} (vs the storage-rounded oracle {errq:.3e}), loss {float(loss):.5f} vs {float(ref_loss):.5f}")
+    parity_log(f"[resnet {dtype}] max |logit - fp32 oracle| = {err:.3e} (vs the storage-rounded oracle {errq:.3e}), loss {float(loss):.5f} vs {float(ref_loss):.5f}")
     assert err < ftol * max(1.0, float(ref_logits.abs().max())) and errq < 0.5 * ftol
     # gradients: a random-init train-mode-BatchNorm network is ill-conditioned -- merely storing the weights / activations in
     # the 16-bit type moves its fp32 gradients by `sens` (6-50 %, measured here on the CPU with the storage-rounded oracle).
@@ -174,7 +175,7 @@ def test_resnet_tower_forward_backward_matches_the_oracle(pkg, dtype, ftol, gtol
         assert rel32 <= 1.5 * sens + 0.01, f"{name}: |hip - fp32| / |fp32| = {rel32:.3f}, storage rounding alone gives {sens:.3f}"
         nq = float(q_grads[name].norm())
         assert abs(float(got.norm()) - nq) <= gtol * nq + 1e-7, name
-    print(f"[resnet {dtype}] worst gradient deviation from the fp32 oracle {worst[1]:.3f} ({worst[0]}; 16-bit storage alone: {worst[2]:.3f})")
+    parity_log(f"[resnet {dtype}] worst gradient deviation from the fp32 oracle {worst[1]:.3f} ({worst[0]}; 16-bit storage alone: {worst[2]:.3f})")
     sd = net.state_dict()
     assert float((sd["bn1.running_mean"].cpu() - st["bn1.running_mean"]).abs().max()) < 2e-3
     assert float((sd["layer4.0.bn3.running_var"].cpu() - st["layer4.0.bn3.running_var"]).abs().max()) < 2e-2
@@ -318,7 +319,7 @@ def test_organizers_exact_model_distilbert_plus_resnet50(pkg):
     ref = F.linear(f, sd["output_fc.weight"], sd["output_fc.bias"])
     out = model(text.cuda(), image.cuda(), mask.cuda())
     err = float((out.detach().float().cpu() - ref).abs().max())
-    print(f"[organizers' model] max |logit - CPU composition| = {err:.3e} (|logit| max {float(ref.abs().max()):.3f})")
+    parity_log(f"[organizers' model] max |logit - CPU composition| = {err:.3e} (|logit| max {float(ref.abs().max()):.3f})")
     assert err < 1e-2
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)          # optimizer = optim.Adam(model.parameters(), lr=...), ...task2C.txt:249
     crit = pkg.CrossEntropyLoss()
@@ -366,7 +367,7 @@ def test_resnet50_full_size_batch32_config2(pkg):
 
     m1, l1, p1 = run()
     m2, l2, p2 = run()
-    print("[ResNet-50 224x224 batch 32] losses over 3 fused-Adam steps:", [round(x, 5) for x in l1])
+    parity_log("[ResNet-50 224x224 batch 32] losses over 3 fused-Adam steps:", [round(x, 5) for x in l1])
     assert np.isfinite(l1).all() and l1[-1] < l1[0]
     assert l1 == l2 and torch.equal(p1, p2)                               # run-to-run bit-identical
     sd = m1.state_dict()
@@ -383,5 +384,5 @@ def test_resnet50_full_size_batch32_config2(pkg):
     _, _, g_a = run(steps=1, half=0)
     _, _, g_b = run(steps=1, half=1)
     rel = float((g_all - 0.5 * (g_a + g_b)).norm() / g_all.norm())
-    print(f"[ResNet-50] ||grad(batch 32) - mean of the two half-batch grads|| / ||grad(batch 32)|| = {rel:.3f} (train-mode BatchNorm: not additive)")
+    parity_log(f"[ResNet-50] ||grad(batch 32) - mean of the two half-batch grads|| / ||grad(batch 32)|| = {rel:.3f} (train-mode BatchNorm: not additive)")
     assert rel > 0.05

@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from conftest import parity_log
 
 pytestmark = pytest.mark.gpu
 
@@ -60,7 +61,7 @@ def test_config3_batch32_matches_the_fixture(pkg, golden_dir, dtype):
     loss.backward()
     torch.cuda.synchronize()
     err = float(np.abs(logits.detach().float().cpu().numpy() - z["logits"]).max())
-    print(f"[{dtype}] config 3, batch 32: max |logit - fixture| = {err:.3e}  (tolerance {LOGIT_TOL[dtype]:.0e})")
+    parity_log(f"[{dtype}] config 3, batch 32: max |logit - fixture| = {err:.3e}  (tolerance {LOGIT_TOL[dtype]:.0e})")
     assert err < LOGIT_TOL[dtype]
     assert abs(float(loss.detach()) - float(z["loss"])) < LOGIT_TOL[dtype]
     # gradients: every tensor's norm and the stored samples of it
@@ -82,7 +83,7 @@ def test_config3_batch32_matches_the_fixture(pkg, golden_dir, dtype):
         s_err = float((f[idx] - torch.from_numpy(ref_s)).abs().max())
         assert s_err <= GRAD_REL_TOL[dtype] * 4 * ref_norm / np.sqrt(f.numel()) + GRAD_REL_TOL[dtype] * float(np.abs(ref_s).max()) + 1e-7, \
             (name, s_err)
-    print(f"[{dtype}] worst gradient-norm deviation {worst[1]:.3%} ({worst[0]})")
+    parity_log(f"[{dtype}] worst gradient-norm deviation {worst[1]:.3%} ({worst[0]})")
 
 
 def test_config3_batch32_full_gradient_tensors_and_signal_relative_error(pkg, golden_dir):
@@ -120,7 +121,7 @@ def test_config3_batch32_full_gradient_tensors_and_signal_relative_error(pkg, go
         spread = float(ref.std(dim=0).mean())            # per-feature standard deviation over the 32 memes, averaged
         err = float((got - ref).abs().max())
         rms = float((got - ref).pow(2).mean().sqrt())
-        print(f"[fp16, batch 32] {nm}: max error {err:.3e}, rms error {rms:.3e}, batch spread {spread:.3e} -> rms error / spread = {rms / spread:.3e}")
+        parity_log(f"[fp16, batch 32] {nm}: max error {err:.3e}, rms error {rms:.3e}, batch spread {spread:.3e} -> rms error / spread = {rms / spread:.3e}")
         assert rms < 0.02 * spread, nm
     # (a) full gradient tensors
     got = dict(model.named_parameters())
@@ -134,7 +135,7 @@ def test_config3_batch32_full_gradient_tensors_and_signal_relative_error(pkg, go
         if rel > worst[1]:
             worst = (name, rel)
         assert rel < 1e-2, f"{name}: ||hip - ref|| / ||ref|| = {rel:.3e}"
-    print(f"[fp16, batch 32] {n_mat} gradient matrices compared element for element; worst ||hip - ref||_F / ||ref||_F = {worst[1]:.3e} ({worst[0]})")
+    parity_log(f"[fp16, batch 32] {n_mat} gradient matrices compared element for element; worst ||hip - ref||_F / ||ref||_F = {worst[1]:.3e} ({worst[0]})")
     assert n_mat >= 148
 
 
