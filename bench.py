@@ -63,10 +63,11 @@ def parse():
     ap.add_argument("--ddp-mode", choices=("stream", "segments", "graph"), default=None,
                     help="data-parallel schedule (default: MEMEHIP_DDP_MODE or 'segments'): one hipGraph per backward segment, or forward "
                          "graph + stream-ordered eager backward with the all-reduces behind a fence stream")
-    ap.add_argument("--ddp-compress", choices=("auto", "none", "bf16"), default="auto",
-                    help="wire format of the gradient exchange: fp32 all-reduce, or bf16 with fp32 accumulation on receipt (all-to-all + "
-                         "all-gather, half the bytes).  auto = bf16 when more than one rank exchanges gradients (xGMI's per-link rate is what "
-                         "a ring is bound by), fp32 on a 1-rank group (nothing crosses a link, the casts would only cost)")
+    ap.add_argument("--ddp-compress", choices=("none", "bf16"), default="none",
+                    help="wire format of the gradient exchange.  none (default): fp32 RCCL all-reduce -- the exact sum, what the headline and the "
+                         "scaling numbers are quoted on.  bf16: all-to-all + all-gather in bf16 with fp32 accumulation on receipt (half the bytes "
+                         "per link, every gradient element rounded twice): an option for link-bound runs, reported as such in the JSON line "
+                         "(`ddp_wire`)")
     ap.add_argument("--dense-text", action="store_true",
                     help="A/B: compute every padded text position like the reference does (default: padding-free text tower)")
     ap.add_argument("--full-masks", action="store_true", help="all-ones attention masks (SURVEY 8d's second input variant)")
@@ -324,7 +325,11 @@ def main():
     if world > 1 or args.force_ddp:
         ddp.broadcast_parameters(model.flat_params)
         model.mark_weights_changed()
-        compress = ("bf16" if world > 1 else None) if args.ddp_compress == "auto" else (None if args.ddp_compress == "none" else args.ddp_compress)
+        compress = None if args.ddp_compress == "none" else args.ddp_compress
+        if compress and world > 1 and (args.ddp_mode or os.environ.get("MEMEHIP_DDP_MODE", "segments")) == "graph":
+            #  the captured form of the compressed exchange -- private comm stream, staging buffers, all_to_all inside a hipGraph --
+            # has only ever run on a 1-rank group, where nothing is compressed, and cannot be rehearsed on a 1-GPU box: refuse it
+            raise SystemExit("--ddp-mode graph with --ddp-compress bf16 is not supported on more than one rank (never exercised at W > 1)")
         reducer = ddp.GradientReducer(model.flat_grads, compress=compress)
     opt = pkg.Adam(model.parameters(), lr=2e-5, model=model, **opt_kwargs(args))
     step = pkg.GraphedStep(model, opt, args.batch, args.seq, use_graph=not args.no_graph, reducer=reducer,
@@ -401,6 +406,8 @@ def main():
             "value": round(value, 2), "unit": "memes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            # wire format of the data-parallel gradient exchange, next to `value`: fp32 = exact RCCL all-reduce (default)
+            "ddp_wire": (None if reducer is None else ("bf16 all-to-all + fp32 accumulation + bf16 all-gather" if reducer.compress else "fp32 all-reduce")),
             "config": {"workload": ("Subtask-2C fine-tune step: ViT-B/16 (224x224, 197 tokens) + BERT-base (V=64000, "
                                     if args.config == 3 else
                                     "Subtask-2C fine-tune step: CLIP ViT-L/14 (336x336, 577 tokens, quick-GELU, pre-LN) + "

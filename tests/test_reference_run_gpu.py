@@ -67,7 +67,7 @@ def _tsv_rows(lines):
 #            (measured bf16 31 % on fusion_fc.weight: the ResNet half of its input carries the tower's BatchNorm-amplified noise)
 #   bf16: err 3.32e-2, worst_t 2.26 %, worst_r 24.4 %
 ORG_TOL = {"fp16": dict(err=4e-2, worst_t=0.01, worst_r=0.33, err_t=4.5e-2, loss=5e-3, flips=0.97, gsample=0.05, bn=1.0),
-           "bf16": dict(err=6.5e-2, worst_t=0.045, worst_r=0.49, err_t=0.1, loss=2e-2, flips=0.9, gsample=0.6, bn=8.0)}
+           "bf16": dict(err=6.5e-2, worst_t=0.045, worst_r=0.49, err_t=7e-2, loss=1e-2, flips=0.97, gsample=0.6, bn=8.0)}      # err_t 3.52e-2, 406/409
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
@@ -184,7 +184,7 @@ def test_organizers_train_test_evaluate_match_the_reference_run(pkg, E, golden_d
     test_loss, test_acc = pkg.test(model, val_loader, criterion, device)
     got_t = torch.stack(seen).numpy()
     seen.clear()
-    err_t, _ = _report("organizers test() logits (eval mode, after the epoch)", got_t, z["test_logits"])
+    err_t, _ = _report(f"organizers test() logits (eval mode, after the epoch), {dtype}", got_t, z["test_logits"])
     assert err_t < TOL["err_t"]
     assert abs(test_loss - float(z["test_loss"])) < TOL["loss"]
     margin = np.abs(z["test_logits"][..., 1] - z["test_logits"][..., 0]).reshape(-1)
