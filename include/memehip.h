@@ -534,6 +534,13 @@ typedef struct MhConvBnBwd {
     const float *mean, *rstd, *gamma, *beta;     /* f32 [C] */
     float* part;                                 /* f32 [2][C][ceil(B*H*W / 128)] */
     int32_t relu, reserved_;
+    /* round 4: the gradient of a residual block's OUTPUT in the same epilogue.  `addend` (16-bit [B*H*W][C] or NULL) is the gradient
+     * that reaches the block input through the other branch (the identity, or the downsample convolution's input gradient): it is
+     * added to this convolution's (16-bit rounded) input gradient first -- the separate mh_add_h16 pass disappears.  `y_mask`
+     * (16-bit [B*H*W][C] or NULL): the BatchNorm's ReLU came AFTER a residual add, so its mask is y > 0 of the block's stored output
+     * (= this convolution's input activations), not recomputable from z alone. */
+    const void* addend;
+    const void* y_mask;
 } MhConvBnBwd;
 int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* workspace, const MhConvGeom* g, const MhConvBnBwd* bn,
                   mh_stream_t stream);

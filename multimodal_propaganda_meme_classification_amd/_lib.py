@@ -55,7 +55,8 @@ class MhConvGeom(C.Structure):
 
 
 class MhConvBnBwd(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("z", "mean", "rstd", "gamma", "beta", "part")] + [("relu", C.c_int32), ("reserved_", C.c_int32)]
+    _fields_ = [(n, c_void_p) for n in ("z", "mean", "rstd", "gamma", "beta", "part")] + [("relu", C.c_int32), ("reserved_", C.c_int32),
+                                                                                          ("addend", c_void_p), ("y_mask", c_void_p)]
 
 
 class MhConvWgradProblem(C.Structure):

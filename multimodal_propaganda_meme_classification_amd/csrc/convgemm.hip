@@ -48,6 +48,8 @@ struct ConvArgs {
     const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta;
     float* bn_part;                        // [2][N][tiles_m]: sum g', sum g' xhat per 128-row tile
     int bn_relu;
+    const h16* bn_add;                     // gradient arriving at the same tensor through the other branch of a residual block, or NULL
+    const h16* bn_y;                       // ReLU mask source when the ReLU followed a residual add (y > 0), or NULL (recompute from z)
 };
 
 // m -> (image, row, column) of the anchored pixel grid.  m < 2^24 (checked on the host): the float quotient is off by at
@@ -313,12 +315,20 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
             if (gm >= a.M || gn >= a.N) continue;
             const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
             const f32x4 x1 = *(const f32x4*)(cs + cs_index(row, cc * 8 + 4));
-            Pack8 zv, u;
+            Pack8 zv, u, av, yv;
             zv.v = *(const i32x4*)(a.bn_z + (size_t)gm * a.ldc + gn);
+            av.v = i32x4{0, 0, 0, 0};
+            yv.v = i32x4{0, 0, 0, 0};
+            if (a.bn_add) av.v = *(const i32x4*)(a.bn_add + (size_t)gm * a.ldc + gn);
+            if (a.bn_y) yv.v = *(const i32x4*)(a.bn_y + (size_t)gm * a.ldc + gn);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float g = mh_bf2f(mh_f2bf((e < 4 ? x0[e] : x1[e - 4]) * alpha));
+                if (a.bn_add) g = mh_bf2f(mh_f2bf(g + mh_bf2f(av.e[e])));       // (the rounding mh_add_h16 applied to the sum)
                 const float xh = (mh_bf2f(zv.e[e]) - mu[e]) * rs[e];
+                if (a.bn_relu && a.bn_y) {
+                    if (!(mh_bf2f(yv.e[e]) > 0.f)) g = 0.f;
+                } else
                 if (a.bn_relu && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) g = 0.f;
                 u.e[e] = mh_f2bf(g);
                 s[e] += g;
@@ -397,6 +407,8 @@ struct BnFuse {       // dgrad: see conv_gemm_kernel's dgrad epilogue
     const h16* z;
     const float *mean, *rstd, *gamma, *beta;
     int relu;
+    const h16* add;
+    const h16* ymask;
 };
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ slabs, int nsplit, h16* __restrict__ y,
                                                                  float* __restrict__ part, int M, int N, int tiles_m, const BnFuse bf) {
@@ -426,12 +438,20 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o.e[e] = mh_f2bf(a0[e]); o.e[4 + e] = mh_f2bf(a1[e]); }
             if (bf.z) {       // dgrad feeding a BatchNorm (+ReLU) backward: masked gradient + its two column sums
-                Pack8 zv;
+                Pack8 zv, av, yv;
                 zv.v = *(const i32x4*)(bf.z + (size_t)r * N + col);
+                av.v = i32x4{0, 0, 0, 0};
+                yv.v = i32x4{0, 0, 0, 0};
+                if (bf.add) av.v = *(const i32x4*)(bf.add + (size_t)r * N + col);
+                if (bf.ymask) yv.v = *(const i32x4*)(bf.ymask + (size_t)r * N + col);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float g = mh_bf2f(o.e[e]);
+                    if (bf.add) g = mh_bf2f(mh_f2bf(g + mh_bf2f(av.e[e])));
                     const float xh = (mh_bf2f(zv.e[e]) - mu[e]) * rs[e];
+                    if (bf.relu && bf.ymask) {
+                        if (!(mh_bf2f(yv.e[e]) > 0.f)) g = 0.f;
+                    } else
                     if (bf.relu && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) g = 0.f;
                     o.e[e] = mh_f2bf(g);
                     s[e] += g;
@@ -627,7 +647,7 @@ extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* wo
         const int st2 = conv_launch<MODE_DGRAD, true>(a, (hipStream_t)stream);
         if (st2 != MH_OK) return st2;
         if (bn) {
-            const BnFuse f = {(const h16*)bn->z, bn->mean, bn->rstd, bn->gamma, bn->beta, bn->relu};
+            const BnFuse f = {(const h16*)bn->z, bn->mean, bn->rstd, bn->gamma, bn->beta, bn->relu, (const h16*)bn->addend, (const h16*)bn->y_mask};
             return finish_split(a, dx, bn->part, (hipStream_t)stream, &f);
         }
         return finish_split(a, dx, nullptr, (hipStream_t)stream);
@@ -635,6 +655,7 @@ extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* wo
     if (bn) {
         a.bn_z = (const h16*)bn->z; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
         a.bn_part = bn->part; a.bn_relu = bn->relu;
+        a.bn_add = (const h16*)bn->addend; a.bn_y = (const h16*)bn->y_mask;
     }
     return conv_launch<MODE_DGRAD, true>(a, (hipStream_t)stream);
 }

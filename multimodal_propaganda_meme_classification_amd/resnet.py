@@ -133,11 +133,14 @@ class _Conv:
             ws = torch.empty((sp, B * H * W, self.cp), dtype=F32, device=dev) if sp > 1 else None
             fuse, part = None, None
             if bnb is not None:      # dx is the dy of the BatchNorm (+ReLU) that produced x: mask it and sum its statistics right here
-                z_prev, bn_mod, sm_prev, sr_prev, relu_prev = bnb
+                z_prev, bn_mod, sm_prev, sr_prev, relu_prev = bnb[:5]
+                addend, y_mask = (bnb[5], bnb[6]) if len(bnb) > 5 else (None, None)
                 part = torch.empty((2, self.cp, (B * H * W + 127) // 128), dtype=F32, device=dev)
                 fuse = _lib.MhConvBnBwd()
                 fuse.z, fuse.mean, fuse.rstd = z_prev.data_ptr(), sm_prev.data_ptr(), sr_prev.data_ptr()
                 fuse.gamma, fuse.beta, fuse.part, fuse.relu = bn_mod.weight.data_ptr(), bn_mod.bias.data_ptr(), part.data_ptr(), int(relu_prev)
+                fuse.addend = None if addend is None else addend.data_ptr()
+                fuse.y_mask = None if y_mask is None else y_mask.data_ptr()
             check(lib.mh_conv_dgrad(dy.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, fuse, _stream()),
                   "mh_conv_dgrad")
             return dx, part
@@ -405,25 +408,34 @@ class ResNet50(nn.Module):
 
         fuse_on = os.environ.get("MEMEHIP_BN_BWD_FUSE", "1") != "0"
 
-        def conv_bn_bwd(op, dy, want_dres, need_dx=True, fuse_prev=None, pre_part=None):
+        def conv_bn_bwd(op, dy, want_dres, need_dx=True, fuse_prev=None, pre_part=None, block_out=None):
             """Backward of one conv + BatchNorm (+ReLU).  `pre_part`: dy arrives MASKED with its column sums already taken by the
             dgrad epilogue that produced it; `fuse_prev`: the conv + BatchNorm whose output is this convolution's input -- when its
-            BatchNorm has a ReLU and no residual, this dgrad's epilogue does that BatchNorm's masking and statistics."""
+            BatchNorm has a ReLU and no residual, this dgrad's epilogue does that BatchNorm's masking and statistics.
+            `block_out` = (op of the PREVIOUS block's conv3 + bn3, d_ident): this convolution is a block's conv1, its input the previous
+            block's output y = relu(bn3(z) + residual): the epilogue adds the gradient arriving through the other branch (d_ident),
+            masks by y > 0 and takes bn3's statistics -- no mh_add_h16 pass, no statistics pass for that bn3 (round 4)."""
             _, cv, bn, A, wk, z, y, sm, sr, hh, ww, ho, wo, relu, has_res = op
             M = B * ho * wo
             if pre_part is not None:
-                dz, dres = _bn_backward_parts(bn, lib, dy, z, sm, sr, pre_part, M, self.gscale, grads), None
+                dz = _bn_backward_parts(bn, lib, dy, z, sm, sr, pre_part, M, self.gscale, grads)
+                dres = dy if want_dres else None          # the masked gradient IS the gradient of the residual branch
             else:
                 # the ReLU mask: from y where a residual was added before the ReLU, recomputed from z otherwise (one tensor less to read)
                 dz, dres = bn.backward(lib, dy, z, y if (relu and has_res) else None, sm, sr, M, relu, want_dres, self.gscale, grads)
             bnb = None
             if fuse_on and fuse_prev is not None and fuse_prev[13] and not fuse_prev[14]:
                 bnb = (fuse_prev[5], fuse_prev[2].mod, fuse_prev[7], fuse_prev[8], True)
+            if block_out is not None:
+                pv, d_ident_in = block_out
+                bnb = (pv[5], pv[2].mod, pv[7], pv[8], True, d_ident_in, pv[6])
             dxin, part = cv.backward(lib, dz, A, wk, B, hh, ww, ho, wo, self.gscale, wjobs, need_dx, side=side, wq=wq, bnb=bnb)
             if wq is not None and len(wq) >= group:
                 flush_wgrads(lib, wq, wjobs, self.gscale)
             return dxin, dres, part
 
+        fuse_out = fuse_on and os.environ.get("MEMEHIP_BN_BWD_FUSE_OUT", "1") != "0"
+        dx_part = None       # statistics partials of the gradient in `dx` when a block's conv1 epilogue already masked it for the bn3 below
         while i >= 0:
             op = ops_[i]
             kind = op[0]
@@ -432,7 +444,8 @@ class ResNet50(nn.Module):
                 # conv3 + bn3 (+ residual + relu): dres is the gradient of the identity branch; its dgrad epilogue already does
                 # bn2's masking + statistics, conv2's does bn1's
                 jc2 = i - 4 if has_ds else i - 2
-                d_o, dres, part2 = conv_bn_bwd(ops_[i - 1], dx, want_dres=True, fuse_prev=ops_[jc2])
+                d_o, dres, part2 = conv_bn_bwd(ops_[i - 1], dx, want_dres=True, fuse_prev=ops_[jc2], pre_part=dx_part)
+                dx_part = None
                 j = i - 2
                 d_ident = dres
                 if has_ds:
@@ -441,11 +454,18 @@ class ResNet50(nn.Module):
                     d_ident = d_branch_in
                     j -= 2
                 d_o, _, part1 = conv_bn_bwd(ops_[j], d_o, want_dres=False, fuse_prev=ops_[j - 1], pre_part=part2)        # conv2
-                d_o, _, _ = conv_bn_bwd(ops_[j - 1], d_o, want_dres=False, pre_part=part1)    # conv1
                 assert ops_[j - 2][0] == "block_begin"
-                merged = torch.empty_like(d_o)
-                check(lib.mh_add_h16(d_o.data_ptr(), d_ident.data_ptr(), merged.data_ptr(), d_o.numel(), _stream()), "mh_add_h16")
-                dx = merged
+                below = ops_[j - 3] if j - 3 >= 0 else None
+                cv1 = ops_[j - 1][1]
+                if fuse_out and below is not None and below[0] == "block_end" and cv1.stride == 1 and cv1.kh == 1 and cv1.cout % 64 == 0:
+                    # conv1's dgrad epilogue = + d_ident, the ReLU mask of the block below (its stored output is conv1's input), bn3's statistics
+                    dx, _, dx_part = conv_bn_bwd(ops_[j - 1], d_o, want_dres=False, pre_part=part1, block_out=(ops_[j - 4], d_ident))
+                    assert dx_part is not None
+                else:
+                    d_o, _, _ = conv_bn_bwd(ops_[j - 1], d_o, want_dres=False, pre_part=part1)    # conv1
+                    merged = torch.empty_like(d_o)
+                    check(lib.mh_add_h16(d_o.data_ptr(), d_ident.data_ptr(), merged.data_ptr(), d_o.numel(), _stream()), "mh_add_h16")
+                    dx = merged
                 i = j - 3
                 continue
             if kind == "maxpool":
