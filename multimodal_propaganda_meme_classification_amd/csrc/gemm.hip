@@ -206,7 +206,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
 // each other, and every launch pays ~4 us of fill + epilogue per round of 512 workgroups -- a burst of 16 MB of loads / stores
 // that all workgroups issue at the same moment.
 // Round 4 built the alternatives the last review asked for and measured them in the step against this kernel on one box
-// (tools/lab/exp_r4c.sh .. exp_r4g.sh; profiles/r04_gemm_shapes.csv; all in lab/gemm_lab.inc now): the epilogue stored STRAIGHT from
+// (tools/lab/RESULTS.md (r4c) .. exp_r4g.sh; profiles/r04_gemm_shapes.csv; all in lab/gemm_lab.inc now): the epilogue stored STRAIGHT from
 // transposed accumulators (weights in the MFMA's A slot, v_permlane16_swap pairing, no staging tile) is 1-4 us faster on the
 // store-only launches standalone and 3-5 us slower where a 16-bit operand is read back (64-byte row segments per wave instead of
 // 256-byte ones) -- in the step: 9.75-9.84 ms against 9.66-9.72; the same kernel with 4 x 2 waves of 32x64 wins the weight-gradient

@@ -716,7 +716,7 @@ class Engine:
                                  b_["r1"], dXi[(ci + 1) % 3], Ti, Di, dx_add=i_dxp) if has_i else None])
             # weight gradients (+ bias gradients as row sums): one grouped launch per tower.  The 4+4 problems in ONE launch (864 tiles)
             # measured 254 us against 215 us for the two 432-tile launches back to back (round 1), and in the step 11.2 ms against 10.2 ms
-            # (round 3, with or without a tile order giving every XCD its share of every problem, tools/lab/exp_r3k.sh): the side stream must not hold every workgroup
+            # (round 3, with or without a tile order giving every XCD its share of every problem, tools/lab/RESULTS.md (r3k)): the side stream must not hold every workgroup
             # slot -- two 432-tile launches leave 80 of the 512 slots to the main chain.  MEMEHIP_WGRAD_ONE_LAUNCH=1 keeps the form for A/B.
             wg_t = [
                     self._wgrad_prob(t_dfm, a["g"], self.g(LT + "output.dense.weight"), self.g(LT + "output.dense.bias"), Tt, Dt, It, **tp),

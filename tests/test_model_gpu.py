@@ -252,7 +252,7 @@ def rccl_world1():
 
     Why one: five create / destroy cycles of an RCCL process group in one process (a communicator per test), next to the 12-GB
     config-5 tests, make a LATER, unrelated multi-stream hipGraphLaunch segfault inside the HIP runtime, deterministically
-    (round 2).  Round 3 took the candidates apart, one run each (tools/lab/exp_r3a.sh, tools/lab/exp_r3b.sh, summary in
+    (round 2).  Round 3 took the candidates apart, one run each (tools/lab/RESULTS.md (r3a), tools/lab/RESULTS.md (r3b), summary in
     profiles/r03_segfault_experiments.md): the crash follows the create / destroy cycles alone -- it is there with a single pinned
     ring per optimizer, absent with 64 pinned blocks and one communicator, and still there when every GraphedStep / GradientReducer
     is closed (graphs reset, pool released, streams dropped, gc) BEFORE the group is destroyed.  So it is not an object of this
