@@ -34,10 +34,16 @@ def note_process_group() -> None:
         _SEEN_GROUP = True
 
 
+_SAFE_CYCLES = 1      # one create / destroy cycle has never faulted (every full GPU suite of rounds 3-4 does exactly that); the recorded crash needs several
+
+
 def communicator_was_destroyed() -> bool:
-    """True once an RCCL process group has been destroyed in this process -- by shutdown() or behind this module's back
-    (a group a GradientReducer / GraphedStep saw is gone)."""
-    return _DESTROYED > 0 or (_SEEN_GROUP and not (dist.is_available() and dist.is_initialized()))
+    """True once MORE THAN ONE RCCL process group has been destroyed in this process -- by shutdown() or behind this module's back
+    (a group a GradientReducer / GraphedStep saw is gone, and another one has been created since).  One communicator per process, torn
+    down once at the end, is the supported life cycle and leaves hipGraphs usable; repeated create / destroy cycles are the recorded
+    crash configuration (profiles/r04_segfault_record.md)."""
+    gone_behind_our_back = 1 if (_SEEN_GROUP and _DESTROYED == 0 and not (dist.is_available() and dist.is_initialized())) else 0
+    return _DESTROYED + gone_behind_our_back > _SAFE_CYCLES
 
 
 class _EventWork:

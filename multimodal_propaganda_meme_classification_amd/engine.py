@@ -717,7 +717,7 @@ class Engine:
             # weight gradients (+ bias gradients as row sums): one grouped launch per tower.  The 4+4 problems in ONE launch (864 tiles)
             # measured 254 us against 215 us for the two 432-tile launches back to back (round 1), and in the step 11.2 ms against 10.2 ms
             # (round 3, with or without a tile order giving every XCD its share of every problem, tools/lab/RESULTS.md (r3k)): the side stream must not hold every workgroup
-            # slot -- two 432-tile launches leave 80 of the 512 slots to the main chain.  MEMEHIP_WGRAD_ONE_LAUNCH=1 keeps the form for A/B.
+            # slot -- two 432-tile launches leave 80 of the 512 slots to the main chain.
             wg_t = [
                     self._wgrad_prob(t_dfm, a["g"], self.g(LT + "output.dense.weight"), self.g(LT + "output.dense.bias"), Tt, Dt, It, **tp),
                     self._wgrad_prob(t_dh, a["y"], self.g(LT + "intermediate.dense.weight"), self.g(LT + "intermediate.dense.bias"), Tt, It, Dt, **tp),
@@ -728,12 +728,8 @@ class Engine:
                     self._wgrad_prob(i_dh, b_["w"], self.g(LI + "intermediate.dense.weight"), self.g(LI + "intermediate.dense.bias"), Ti, Ii, Di),
                     self._wgrad_prob(i_dxp, b_["ctx"], self.g(LI + "attention.output.dense.weight"), self.g(LI + "attention.output.dense.bias"), Ti, Di, Di),
                     self._wgrad_prob(i_dqkv, b_["u"], self.g(LI + "attention.attention.query.weight", 3), self.g(LI + "attention.attention.query.bias", 3), Ti, 3 * Di, Di)] if has_i else []
-            if _os.environ.get("MEMEHIP_WGRAD_ONE_LAUNCH", "0") == "1" and len(wg_t) + len(wg_i) <= _lib.MH_GEMM_MAX_GROUP:
-                long_first = (wg_i + wg_t) if Ti >= Tt else (wg_t + wg_i)
-                self._gemm(pl, s, long_first, True, True, lane=1)
-            else:
-                self._gemm(pl, s, wg_t, True, True, lane=1)
-                self._gemm(pl, s, wg_i, True, True, lane=1)
+            self._gemm(pl, s, wg_t, True, True, lane=1)
+            self._gemm(pl, s, wg_i, True, True, lane=1)
             if has_t:
                 ct = (ct + 1) % 3
             if has_i:

@@ -1427,8 +1427,7 @@ class GraphedStep:
                             e.record(main)
                             self.side.wait_event(e)
                         with torch.cuda.stream(self.side):
-                            if os.environ.get("MEMEHIP_PROBE_SKIP_SLICE_ADAM") != "1":      # (timing probe only: the slices are NOT updated)
-                                self.opt.launch(only=rng, guarded=True)
+                            self.opt.launch(only=rng, guarded=True)
                         ev = torch.cuda.Event()
                         ev.record(self.side)
                         events[seg.name] = ev

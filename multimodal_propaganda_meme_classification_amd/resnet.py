@@ -394,13 +394,7 @@ class ResNet50(nn.Module):
         i = len(ops_) - 1
         grads = {}      # id(parameter) -> gradient tensor for autograd, or None when it was accumulated into .grad in place
         wjobs = []      # (conv, split-K slabs of its weight gradient, nsplit, operands kept alive): finished in one launch at the end
-        side = None
-        # weight-gradient GEMMs on a second stream: measured SLOWER (9.39 vs 8.76 ms/step -- 53 cross-stream edges of ~10 us for
-        # 26-us GEMMs), so off unless MEMEHIP_RESNET_WGRAD_SIDE=1
-        if os.environ.get("MEMEHIP_RESNET_WGRAD_SIDE", "0") == "1":
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream()
-            side = self._side
+        side = None      # (weight-gradient GEMMs on a second stream: measured SLOWER, 9.39 vs 8.76 ms/step -- 53 cross-stream edges of ~10 us for 26-us GEMMs)
 
         group = int(os.environ.get("MEMEHIP_WGRAD_GROUP", "4"))       # weight gradients launched together (1: one launch each)
         group = max(1, min(group, _lib.MH_CONV_MAX_GROUP))

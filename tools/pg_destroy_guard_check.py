@@ -3,7 +3,8 @@ in a process of its own (it destroys a communicator, which must not happen insid
 
     python tools/pg_destroy_guard_check.py
 
-creates a 1-rank RCCL process group, runs a data-parallel GraphedStep on it, tears everything down through ddp.shutdown(), then builds a
+creates a 1-rank RCCL process group, runs a data-parallel GraphedStep on it, tears everything down through ddp.shutdown() (one cycle: still
+fine), creates and destroys a SECOND communicator, then builds a
 NEW GraphedStep: it must warn (RuntimeWarning), run with eager launches (use_graph False) and give the same losses and parameters as a
 graph-replayed step of a fresh process would -- checked here against the first, graphed, phase on the same inputs."""
 import os
@@ -50,6 +51,14 @@ red = ddp.GradientReducer(m1.flat_grads)
 s1 = pkg.GraphedStep(m1, pkg.Adam(m1.parameters(), lr=1e-3, model=m1), b, S, reducer=red)
 assert s1.use_graph and not ddp.communicator_was_destroyed()
 l1, p1 = run(s1, m1)
+ddp.shutdown()
+assert not ddp.communicator_was_destroyed(), "ONE create / destroy cycle is the supported life cycle: graphs stay on"
+# a second communicator, created and destroyed: from here on the recorded crash configuration
+os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+ddp.note_process_group()
+dist.all_reduce(torch.ones(8, device="cuda"))
+torch.cuda.synchronize()
 ddp.shutdown()
 assert ddp.communicator_was_destroyed()
 # phase 2: the configuration that faults -- a fresh multi-stream graph after the destroy.  The guard must turn it into eager launches.
