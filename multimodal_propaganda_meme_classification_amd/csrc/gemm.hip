@@ -283,6 +283,8 @@ __global__ __launch_bounds__(512, 4) void gemm_kernel(const GemmGroup g) {
     for (int j = 0; j < 8; ++j) ones[j] = (h16)1.0f;
 
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    // (static s_setprio(1) for waves 4-7 -- the younger half of the workgroup, MI355X_MICROARCH.md "two waves per SIMD" item 4 -- measured:
+    //  10.12-10.18 ms per step against 10.09-10.11, same box, three alternations: nothing)
     dma_tile<LA, 16 / NW>(ra, P.lda, m0, kbeg, wave, lane, smem);
     dma_tile<LB, 16 / NW>(rb, P.ldb, n0, kbeg, wave, lane, smem + BM * BK * 2);
     __syncthreads();
