@@ -190,9 +190,14 @@ def timed_variant(pkg, args, device, dtype=None, full_masks=None, dense_text=Non
     run_steps(step, batches, max(args.warmup, 1))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(step, batches, args.steps, start=max(args.warmup, 1))
+    loss, _ = run_steps(step, batches, args.steps, start=max(args.warmup, 1))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the variant has to be TRAINING, not just running: a finite loss in the range a 2-class cross-entropy of a freshly initialised
+    # model under a handful of Adam steps can have, finite weights, no step skipped by the overflow guard on these inputs
+    final = float(loss)
+    if not (0.0 < final < 3.0) or not bool(torch.isfinite(model.flat_params).all()):
+        raise SystemExit(f"bench variant {dict(dtype=dtype, config=config, clip=clip)}: loss {final} / non-finite weights -- not a valid measurement")
     step.close()
     del step, opt, model, batches
     torch.cuda.empty_cache()

@@ -145,3 +145,31 @@ def test_config5_full_depth_smoke(pkg):
         loss, _ = step.step()
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 1e-3), ("bf16", 4e-3)])
+def test_config5_two_layers_at_the_benchmarked_batch(pkg, dtype, tol):
+    """config 5 was checked at batch 2-3 only while bench.py runs it at batch 32.  The same 2 + 2-layer model at the true
+    widths, 577 image tokens and 256 text tokens, BATCH 32 with ragged masks: logits and loss of the HIP path against the CPU oracle, and one
+    graphed step (the schedule bench.py times) reproduces the eager step's loss and leaves finite weights."""
+    O = _oracle()
+    torch.set_num_threads(16)
+    cfg = O.config5("cls", layers=2)
+    params, model = _build(pkg, O, cfg, 23, dtype)
+    text, image, mask, labels = O.synthetic_batch(cfg, 32, 256, seed=79)
+    with torch.no_grad():
+        ref_logits = O.forward(params, text, image, mask, cfg)
+        ref_loss = O.cross_entropy(ref_logits, labels)
+    dev = [t_.cuda() for t_ in (text, image, mask, labels)]
+    loss, _, logits = model.forward_backward(*dev)
+    torch.cuda.synchronize()
+    err = float((logits.detach().float().cpu() - ref_logits).abs().max())
+    parity_log(f"[config 5, 2 layers, batch 32, {dtype}] max |logit - oracle| = {err:.3e}; loss {float(loss):.6f} vs {float(ref_loss):.6f}")
+    assert err < tol and abs(float(loss) - float(ref_loss)) < tol
+    opt = pkg.Adam(model.parameters(), lr=2e-5, model=model)
+    gs = pkg.GraphedStep(model, opt, 32, 256)
+    gs.load_batch(*dev)
+    gl, _ = gs.step()
+    torch.cuda.synchronize()
+    assert abs(float(gl) - float(loss)) < 1e-6 and bool(torch.isfinite(model.flat_params).all())
+    gs.close()

@@ -25,13 +25,17 @@ ap.add_argument("--cands", default="product,torch")
 ap.add_argument("--csv", default="")
 ap.add_argument("--dtype", default="fp16")
 ap.add_argument("--rounds", type=int, default=7)
-ap.add_argument("--live", type=int, default=2096)
+ap.add_argument("--live", type=int, default=0)
+ap.add_argument("--config", type=int, default=3, help="3: ViT-B/16 + BERT-base rows / widths; 5: CLIP ViT-L/14@336 + BERT-large (S = 256)")
 args = ap.parse_args()
 
 dev = torch.device("cuda")
 T16 = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-Tt_alloc, Ti, D, I = 4096, 6304, 768, 3072
-live = args.live
+if args.config == 5:
+    Tt_alloc, Ti, D, I = 8192, 18464, 1024, 4096
+else:
+    Tt_alloc, Ti, D, I = 4096, 6304, 768, 3072
+live = args.live or (4224 if args.config == 5 else 2096)
 rows_dev = torch.tensor([live], dtype=torch.int32, device=dev)
 
 
@@ -96,14 +100,14 @@ def wgrad(T, packed):
 
 
 cases = {
-    "fwd_qkv   N2304 K768 ": fwd(3 * D, D),
-    "fwd_out   N768  K768 ": fwd(D, D, residual=True),
-    "fwd_ffn1  N3072 K768 ": fwd(I, D, gelu=True),
-    "fwd_ffn2  N768  K3072": fwd(D, I, residual=True),
-    "dgrad_ffn2 N3072 K768 ": dgrad(D, I, mul=True),
-    "dgrad_ffn1 N768  K3072": dgrad(I, D, residual=True),
-    "dgrad_out  N768  K768 ": dgrad(D, D),
-    "dgrad_qkv  N768  K2304": dgrad(3 * D, D, residual=True),
+    f"fwd_qkv   N{3 * D} K{D}": fwd(3 * D, D),
+    f"fwd_out   N{D} K{D}": fwd(D, D, residual=True),
+    f"fwd_ffn1  N{I} K{D}": fwd(I, D, gelu=True),
+    f"fwd_ffn2  N{D} K{I}": fwd(D, I, residual=True),
+    f"dgrad_ffn2 N{I} K{D}": dgrad(D, I, mul=True),
+    f"dgrad_ffn1 N{D} K{I}": dgrad(I, D, residual=True),
+    f"dgrad_out  N{D} K{D}": dgrad(D, D),
+    f"dgrad_qkv  N{D} K{3 * D}": dgrad(3 * D, D, residual=True),
     "wgrad_text  4 problems": wgrad(Tt_alloc, True),
     "wgrad_image 4 problems": wgrad(Ti, False),
 }
