@@ -82,41 +82,53 @@ MH_DEV void epilogue_prefetch(const MhGemmProblem& P, int m0, int n0, int tid, i
     }
 }
 
-template <int TM, int NTHR = TM * 2, bool DROP = true, bool PREF = false>
+// (Everything the loop needs from the problem descriptor is copied to locals first, and the bias -- a function of the thread's column
+//  only -- is loaded once: the descriptor lives in kernel-argument memory, which the compiler must assume the stores alias, so it
+//  re-read every field after every store (a chain of dependent scalar loads per iteration), and the per-iteration bias load sat behind
+//  the previous iteration's store on the in-order vmcnt counter -- each iteration waited for a store to COMPLETE.)
+template <int TM, int NTHR = TM * 2, bool DROP = true, int PREF = 0>
 MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n0, int tid, int M,
-                          const EpiPrefetch<TM, NTHR>* pf = nullptr) {
+                          const EpiPrefetch<TM, NTHR>* pf = nullptr, const f32x4* bias_pre = nullptr) {
     const int flags = P.flags;
-    const int ldc = P.ldc;
+    const int ldc = P.ldc, N = P.N;
     const float alpha = P.alpha == 0.f ? 1.0f : P.alpha;
+    const h16* const p_mul = (const h16*)P.mul;
+    const h16* const p_res = (const h16*)P.residual;
+    h16* const p_aux = (h16*)P.aux;
+    void* const p_c = P.C;
+    const int* const drop_rows = P.drop_rows;
     const DropCtx drop = mh_drop_ctx(DROP ? P.drop_rng : nullptr, P.drop_p, P.drop_stream);
     constexpr int nthreads = NTHR;
     constexpr int iters = TM * 16 / NTHR;
+    static_assert(NTHR % 16 == 0, "a thread keeps its column block across iterations");
+    const int cc = tid & 15, gn = n0 + cc * 8;
+    f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (bias_pre) {
+        b0 = bias_pre[0];
+        b1 = bias_pre[1];
+    } else if (P.bias && gn < N) {
+        b0 = *(const f32x4*)(P.bias + gn);
+        b1 = *(const f32x4*)(P.bias + gn + 4);
+    }
 #pragma unroll
     for (int it = 0; it < iters; ++it) {
-        const int q = it * nthreads + tid;
-        const int row = q >> 4, cc = q & 15;
-        const int gm = m0 + row, gn = n0 + cc * 8;
-        if (gm >= M || gn >= P.N) continue;      // ragged M; N need not fill the last 128-column tile (conv layers with 64 filters)
+        const int row = (it * nthreads + tid) >> 4;
+        const int gm = m0 + row;
+        if (gm >= M || gn >= N) continue;      // ragged M; N need not fill the last 128-column tile (conv layers with 64 filters)
         float v[8];
         {
             const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
             const f32x4 x1 = *(const f32x4*)(cs + cs_index(row, cc * 8 + 4));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = x0[e] * alpha; v[4 + e] = x1[e] * alpha; }
-        }
-        if (P.bias) {
-            const f32x4 b0 = *(const f32x4*)(P.bias + gn);
-            const f32x4 b1 = *(const f32x4*)(P.bias + gn + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            for (int e = 0; e < 4; ++e) { v[e] = x0[e] * alpha + b0[e]; v[4 + e] = x1[e] * alpha + b1[e]; }
         }
         const size_t o = (size_t)gm * ldc + gn;
         if (DROP && drop.on) {     // nn.Dropout on the Linear output (BertSelfOutput / BertOutput), before the residual add
-            const uint64_t dr = P.drop_rows ? (uint64_t)P.drop_rows[gm] : (uint64_t)gm;   // row in the unpacked tensor
+            const uint64_t dr = drop_rows ? (uint64_t)drop_rows[gm] : (uint64_t)gm;   // row in the unpacked tensor
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= mh_drop_mul(drop, dr * (uint64_t)P.N + (uint64_t)(gn + e));
+            for (int e = 0; e < 8; ++e) v[e] *= mh_drop_mul(drop, dr * (uint64_t)N + (uint64_t)(gn + e));
         }
-        if ((flags & MH_GEMM_GELU) && (flags & MH_GEMM_DERIV_AUX) && P.aux) {
+        if ((flags & MH_GEMM_GELU) && (flags & MH_GEMM_DERIV_AUX) && p_aux) {
             // activation and its derivative from the same exponential: aux receives act'(v), which the dgrad launch multiplies
             // by as it is (no transcendental math in the backward epilogue)
             Pack8 u;
@@ -135,13 +147,13 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
                     v[e] *= gp.cdf;
                 }
             }
-            *(i32x4*)((h16*)P.aux + o) = u.v;
+            *(i32x4*)(p_aux + o) = u.v;
         } else {
-            if (P.aux) {
+            if (p_aux) {
                 Pack8 u;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) u.e[e] = mh_f2bf(v[e]);
-                *(i32x4*)((h16*)P.aux + o) = u.v;
+                *(i32x4*)(p_aux + o) = u.v;
             }
             if (flags & MH_GEMM_GELU) {
                 if (flags & MH_GEMM_QUICK_GELU) {
@@ -153,10 +165,11 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
                 }
             }
         }
-        if (P.mul) {
+        if (p_mul) {
             Pack8 u;
-            if (PREF) u.v = pf->mul[it];
-            else u.v = *(const i32x4*)((const h16*)P.mul + o);
+            if (PREF == 1) u.v = pf->mul[it];
+            else if (PREF == 2 && !p_res) u.v = pf->res[it];
+            else u.v = *(const i32x4*)(p_mul + o);
             if (flags & MH_GEMM_DERIV_AUX) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= mh_bf2f(u.e[e]);
@@ -168,15 +181,15 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
                 for (int e = 0; e < 8; ++e) v[e] *= dgelu_f(mh_bf2f(u.e[e]));
             }
         }
-        if (P.residual) {
+        if (p_res) {
             Pack8 u;
             if (PREF) u.v = pf->res[it];
-            else u.v = *(const i32x4*)((const h16*)P.residual + o);
+            else u.v = *(const i32x4*)(p_res + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += mh_bf2f(u.e[e]);
         }
         if (flags & MH_GEMM_OUT_F32) {
-            float* c = (float*)P.C + o;
+            float* c = (float*)p_c + o;
             if (flags & MH_GEMM_ACCUM) {
                 const f32x4 c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + 4);
 #pragma unroll
@@ -188,7 +201,7 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
             Pack8 u;
 #pragma unroll
             for (int e = 0; e < 8; ++e) u.e[e] = mh_f2bf(v[e]);
-            *(i32x4*)((h16*)P.C + o) = u.v;
+            *(i32x4*)((h16*)p_c + o) = u.v;
         }
     }
 }
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(512, 4) void gemm_kernel(const GemmGroup g) {
     epilogue_prefetch<BM, NW * 64>(P, m0, n0, tid, M, pf);
     stage_acc();
     __syncthreads();
-    epilogue_rows<BM, NW * 64, DROP, true>(P, cs, m0, n0, tid, M, &pf);
+    epilogue_rows<BM, NW * 64, DROP, 1>(P, cs, m0, n0, tid, M, &pf);
     trace_stamp(g, 3);
 }
 
@@ -403,9 +416,12 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     if (g_variant < 0) {
         const char* e = getenv("MEMEHIP_GEMM_VARIANT");
         g_variant = e ? atoi(e) : -2;
-        if (g_variant < 0 || g_variant > 12) g_variant = -2;
+        if (g_variant < 0 || g_variant > 13) g_variant = -2;
     }
-    if (g_variant >= 0) return lab_gemm_grouped(problems, n_problems, a_kmajor, b_kmajor, stream);      // -2: the product's kernel
+    if (g_variant >= 0) {      // -2: the product's kernel
+        const int rc = lab_gemm_grouped(problems, n_problems, a_kmajor, b_kmajor, stream);
+        if (rc != LAB_NOT_MINE) return rc;
+    }
 #endif
     if (g_group_m < 0) {
         const char* e = getenv("MEMEHIP_GEMM_GROUP_M");
@@ -481,9 +497,9 @@ extern "C" int mh_gemm_set_streamk(void* workspace, int mode) {
     g_sk_force = mode == 2;
     return MH_OK;
 }
-// -2 = the product's kernel (default); 0-12 = the lab kernels (csrc/lab/memehip_lab.h)
+// -2 = the product's kernel (default); 0-13 = the lab kernels (csrc/lab/memehip_lab.h)
 extern "C" int mh_gemm_set_variant(int v) {
-    if (v != -2 && (v < 0 || v > 12)) return MH_EINVAL;
+    if (v != -2 && (v < 0 || v > 13)) return MH_EINVAL;
     g_variant = v;
     return MH_OK;
 }

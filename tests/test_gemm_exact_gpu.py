@@ -120,3 +120,72 @@ def test_split_k_slabs_are_exact(ops):
     slabs = torch.full((sp, M, N), 9.0, dtype=F32, device=dev())
     ops.gemm_grouped([ops.Gemm(A, B, slabs, M, N, K, lda, ldb, N, ksplit=sp)], True, True)
     assert torch.equal(slabs.sum(0), ref)
+
+
+# ---- launches of >= 512 tiles of 256x256 (config 5's forward / dgrad sizes).  With the product library these run gemm_kernel over several
+# rounds of resident workgroups; with the lab library (MEMEHIP_LIB / MEMEHIP_LIB_F16 -> libmemehip_lab*.so) they also run the 256x256
+# eight-phase kernel (lab variant 13, csrc/lab/gemm_lab.inc) -- the tests that found its epilogue-prefetch bug ----------------------
+def _variants(T16):
+    from multimodal_propaganda_meme_classification_amd import _lib
+    lib = _lib.load("bf16" if T16 == torch.bfloat16 else "fp16")
+    return lib, ([-2, 13] if hasattr(lib, "mh_gemm_set_variant") else [None])
+
+
+@BOTH
+@pytest.mark.parametrize("layout", [(0, 0), (0, 1)], ids=["fwd", "dgrad"])
+@pytest.mark.parametrize("M,N,K", [(4000, 8200, 64), (4000, 8200, 192), (8192, 4096, 128)])
+def test_large_launch_16bit_output_is_exact(ops, layout, M, N, K, T16):
+    """ragged M, a partial last column tile, odd and even K-tile counts, every 16-bit epilogue operand"""
+    assert ((M + 255) // 256) * ((N + 255) // 256) >= 512
+    lib, variants = _variants(T16)
+    A, B, ref, (lda, ldb) = _operands(layout, M, N, K, T16)
+    bias = ints(N, lo=-3, hi=4, seed=3, dtype=F32)
+    res = ints(M, N, lo=-8, hi=9, seed=4, dtype=T16)
+    mul = ints(M, N, lo=-1, hi=2, seed=5, dtype=T16)
+    try:
+        for v in variants:
+            if v is not None:
+                assert lib.mh_gemm_set_variant(v) == 0
+            out = torch.full((M, N), 7.0, dtype=T16, device=dev())
+            ops.gemm_grouped([ops.Gemm(A, B, out, M, N, K, lda, ldb, N)], False, bool(layout[1]))
+            assert torch.equal(out.float(), ref), f"plain store (variant {v})"
+            aux = torch.full((M, N), 5.0, dtype=T16, device=dev())
+            ops.gemm_grouped([ops.Gemm(A, B, out, M, N, K, lda, ldb, N, bias=bias, residual=res, aux=aux)], False, bool(layout[1]))
+            assert torch.equal(aux.float(), ref + bias) and torch.equal(out.float(), ref + bias + res.float()), f"variant {v}"
+            ops.gemm_grouped([ops.Gemm(A, B, out, M, N, K, lda, ldb, N, bias=bias, mul=mul, residual=res, deriv_aux=True)], False, bool(layout[1]))
+            assert torch.equal(out.float(), (ref + bias) * mul.float() + res.float()), f"variant {v}"
+    finally:
+        if variants[0] is not None:
+            lib.mh_gemm_set_variant(-2)
+
+
+@BOTH
+@pytest.mark.parametrize("layout", [(0, 0), (0, 1)], ids=["fwd", "dgrad"])
+def test_large_launch_long_k_grouped_and_packed_rows(ops, layout, T16):
+    """Two problems in one launch at K = 2048 (32 K tiles through the LDS stages: a tile restaged early or read before it landed shows
+    as a wrong sum), f32 output so the sums stay exact, one problem with a device-side live row count; run several times -- the result
+    must be the same bits every time."""
+    K, N = 2048, 4096
+    M1, M2, live = 8192, 4104, 5000
+    lib, variants = _variants(T16)
+    A1, B1, ref1, (lda, ldb) = _operands(layout, M1, N, K, T16)
+    A2 = ints(M2, K, seed=7, dtype=T16)
+    ref2 = A2.float() @ (B1.float().t() if layout == (0, 0) else B1.float())
+    o1 = torch.full((M1, N), 3.0, dtype=F32, device=dev())
+    o2 = torch.full((M2, N), 3.0, dtype=F32, device=dev())
+    rows = torch.tensor([live], dtype=torch.int32, device=dev())
+    try:
+        for v in variants:
+            if v is not None:
+                assert lib.mh_gemm_set_variant(v) == 0
+            for _ in range(5):
+                o1.fill_(3.0)
+                o2.fill_(3.0)
+                ops.gemm_grouped([ops.Gemm(A1, B1, o1, M1, N, K, lda, ldb, N, rows_dev=rows), ops.Gemm(A2, B1, o2, M2, N, K, lda, ldb, N)],
+                                 False, bool(layout[1]))
+                assert torch.equal(o1[:live], ref1[:live]), f"variant {v}"
+                assert torch.equal(o1[live:], torch.full((M1 - live, N), 3.0, device=dev())), "rows past the live count are not stored"
+                assert torch.equal(o2, ref2), f"variant {v}"
+    finally:
+        if variants[0] is not None:
+            lib.mh_gemm_set_variant(-2)
