@@ -392,7 +392,7 @@ def main():
         traffic = None
         traffic_src = None
         try:
-            tpath = next(pth for pth in (os.path.join(ROOT, "profiles", f) for f in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"))
+            tpath = next(pth for pth in (os.path.join(ROOT, "profiles", f) for f in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"))
                          if os.path.exists(pth))
             traffic_src = os.path.relpath(tpath, ROOT)
             tj = json.load(open(tpath))["kernels"]
