@@ -573,6 +573,19 @@ int mh_avgpool_bwd(const float* dy, void* dx, int B, int HW, int C, float scale,
 int mh_add_h16(const void* a, const void* b, void* y, int64_t n, mh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Depthwise convolution (ConvNeXt-tiny, the SVM baseline's image features: baselines/extract_feat.py:52-60 calls
+ * img_model.avgpool(img_model.features(images)) on torchvision convnext_tiny; CNBlock's Conv2d(dim, dim, 7, padding=3, groups=dim)).
+ * Forward only (the extractor runs under torch.no_grad()).
+ *   mh_dwconv_weight_pack: torch weight f32 [C][1][K][K] -> tap-major f32 [K*K][C]
+ *   mh_dwconv_nhwc: y[b][h][w][c] = bias[c] + sum_{i,j} wt[i*K+j][c] * x[b][h+i-K/2][w+j-K/2][c] (zero outside), 16-bit NHWC in / out,
+ *                   f32 accumulation; C % 8 == 0, K == 7, stride 1.
+ * The block's LayerNorm / Linear / GELU / Linear + residual run on mh_layernorm_fwd and mh_gemm_bf16_grouped; the patchify
+ * stem and the 2x2 / stride-2 downsampling convolutions on mh_im2col_nhwc + mh_gemm_bf16_grouped (bias in the epilogue).
+ * ------------------------------------------------------------------------------------------ */
+int mh_dwconv_weight_pack(const float* w, float* wt, int C, int K, mh_stream_t stream);
+int mh_dwconv_nhwc(const void* x, const float* wt, const float* bias, void* y, int B, int H, int W, int C, int K, mh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam / AdamW, Multimodal_example_task2C.txt:249,217; HF Trainer
  * adamw_torch + max_grad_norm, DistilBERT_example_task2A.ipynb:3211-3213,3280):
  *   mh_sumsq_f32: out[0] = sum g^2 over n elements (two-pass deterministic; workspace >= 1024 f32)

@@ -16,4 +16,5 @@ from .train import evaluate, test, train  # noqa: F401
 from . import kevin  # noqa: F401
 from .kevin import KevinMultimodalDataset, kevin_collate  # noqa: F401
 from .resnet import Bottleneck, ResNet50, ResNetClassifier  # noqa: F401
+from .convnext import CNBlock, ConvNeXtTiny  # noqa: F401
 from .features import dump_features, get_features  # noqa: F401

@@ -198,6 +198,8 @@ _PROTOS = {
     "mh_avgpool_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mh_avgpool_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     "mh_add_h16": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+    "mh_dwconv_weight_pack": [c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "mh_dwconv_nhwc": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
     "mh_ce_fwd_bwd": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p, c_void_p],
     "mh_focal_fwd_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p],
     "mh_adam_skip_account": [C.POINTER(MhAdamSkipGroups), c_void_p, c_void_p, c_void_p, C.POINTER(MhLossScale), c_void_p],
