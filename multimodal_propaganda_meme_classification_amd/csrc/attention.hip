@@ -33,21 +33,7 @@ constexpr float LN2 = 0.6931471805599453f;
 MH_DEV int row_img_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row ^ (row >> 3)) & 7)) << 4); }
 MH_DEV int tr_img_off(int row, int unit) { return row * 128 + ((unit ^ (((row >> 1) & 1) << 1)) << 5); }
 
-// stage one [64][64] h16 tile (rows row0.., clipped at nrows -> zeros) into a row image and/or tr image
-template <int NT>
-MH_DEV void stage_tile(const h16* __restrict__ base, size_t pitch, int row0, int nrows, int tid,
-                       char* row_img, char* tr_img) {
-#pragma unroll
-    for (int q = tid; q < TILE * 8; q += NT) {
-        const int r = q >> 3, c = q & 7;
-        i32x4 v = {0, 0, 0, 0};
-        if (row0 + r < nrows) v = *(const i32x4*)(base + (size_t)(row0 + r) * pitch + c * 8);
-        if (row_img) *(i32x4*)(row_img + row_img_off(r, c)) = v;
-        if (tr_img) *(i32x4*)(tr_img + tr_img_off(r, c >> 1) + ((c & 1) << 4)) = v;
-    }
-}
-
-// the same in two halves for the streaming kernels: the global loads of tile t+1 are issued before the products of tile t and
+// streaming kernels: one [64][64] h16 tile at a time, in two halves: the global loads of tile t+1 are issued before the products of tile t and
 // land in registers while they run; the LDS images are written once every wave has left tile t (one LDS slot, no exposed
 // load latency per tile).  TILE * 8 = 512 16-B chunks per tile: two per thread at 256 or 448 threads.
 template <int NT>
@@ -74,6 +60,37 @@ MH_DEV void tile_store(const TileRegs<NT>& R, int tid, char* row_img, char* tr_i
         const int r = q >> 3, c = q & 7;
         if (row_img) *(i32x4*)(row_img + row_img_off(r, c)) = R.v[i];
         if (tr_img) *(i32x4*)(tr_img + tr_img_off(r, c >> 1) + ((c & 1) << 4)) = R.v[i];
+    }
+}
+
+// Resident operands (a head's whole K / V / Q / dO: NTL tiles of 64 rows) go global -> LDS by LDS-DMA, every piece in flight at
+// once.  (Round 4, second session: the register path of stage_tile -- load 16 B, s_waitcnt vmcnt(0), ds_write, next chunk; the loads
+// are predicated per row, which kept the compiler from batching them -- was 16 dependent memory round trips for wave 0 of a
+// 197-token forward head (8 for the other waves) ahead of the barrier: ~9 of the ~12 us such a workgroup lived.)  One
+// wave-instruction fills 1 KiB = 8 rows x 8 chunks of an image linearly (LDS base + 16 lane), so both swizzles move to the SOURCE
+// side: lane (row r, position c') fetches the chunk that lives at position c' of row r.  Rows past nrows read as zeros through the
+// buffer resource's bound, as the register path wrote them.  Piece p (rows 8p..8p+7) of an image sits at image + 1024 p (tile p / 8
+// at image + (p / 8) IMG); the pieces of the ntiles live tiles are dealt round-robin to the NW waves.  wave_u must be wave-uniform.
+template <int NW, int NTL>
+MH_DEV void dma_resident(const h16* __restrict__ base, size_t pitch, int nrows, int ntiles, int wave_u, int lane, char* row_img,
+                         char* tr_img) {
+    const __amdgpu_buffer_rsrc_t rs = mh_rsrc(base, (uint32_t)(((size_t)(nrows - 1) * pitch + HD) * 2));
+    const int npieces = ntiles * 8;
+#pragma unroll
+    for (int i = 0; i < (NTL * 8 + NW - 1) / NW; ++i) {
+        const int p = wave_u + i * NW;
+        if (p < npieces) {
+            const int r = p * 8 + (lane >> 3), rl = r & (TILE - 1), cp = lane & 7;
+            const uint32_t rowoff = (uint32_t)r * (uint32_t)pitch * 2u;
+            if (row_img) {
+                const int ck = cp ^ ((rl ^ (rl >> 3)) & 7);                               // row_img_off
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, row_img + p * 1024), 16, rowoff + ck * 16, 0, 0, 0);
+            }
+            if (tr_img) {
+                const int cv = ((((cp >> 1) ^ (((rl >> 1) & 1) << 1)) << 1) | (cp & 1));  // tr_img_off
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, tr_img + p * 1024), 16, rowoff + cv * 16, 0, 0, 0);
+            }
+        }
     }
 }
 
@@ -198,31 +215,39 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
     constexpr float LAZY_LOG2 = 6.0f;
     const int ntiles = (Sb + TILE - 1) / TILE;
 
-    auto stage = [&](int t, int slot) {
-        stage_tile<NT>(kb, pitch, t * TILE, Sb, tid, k_img + slot * IMG, nullptr);
-        stage_tile<NT>(vb, pitch, t * TILE, Sb, tid, nullptr, v_img + slot * IMG);
-        if (tid < TILE) {   // wave 0, all 64 lanes
-            const int key = t * TILE + tid;
-            float bias = NEG_BIG;
-            if (key < Sb && (!key_mask || key_mask[r0 + key] != 0)) bias = 0.f;
-            kbias[slot * TILE + tid] = bias;
-            const unsigned long long bal = __ballot(bias == 0.f);
-            if (tid == 0) {
-                kany[slot * 2] = (bal & 0xffffffffull) != 0;
-                kany[slot * 2 + 1] = (bal >> 32) != 0;
+    const int qt_first = bx * NW + wave;
+    h16x8 qf[4];
+    if (NT_RES > 0) {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        dma_resident<NW, NTL>(kb, pitch, Sb, ntiles, uw, lane, k_img, nullptr);
+        dma_resident<NW, NTL>(vb, pitch, Sb, ntiles, uw, lane, nullptr, v_img);
+        if (qt_first * 32 < Sb) load_rows_frag(qb, pitch, qt_first * 32, Sb, lane, qf);      // Q of the first block rides the same wait
+        if (tid < TILE) {   // wave 0, all 64 lanes: additive key bias + "any key" flags of every tile
+            int64_t km[NTL];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                const int key = t * TILE + tid;
+                km[t] = (key < Sb) ? 1 : 0;
+                if (key_mask && key < Sb) km[t] = key_mask[r0 + key];
+            }
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                const float bias = km[t] != 0 ? 0.f : NEG_BIG;
+                kbias[t * TILE + tid] = bias;
+                const unsigned long long bal = __ballot(bias == 0.f);
+                if (tid == 0) {
+                    kany[t * 2] = (bal & 0xffffffffull) != 0;
+                    kany[t * 2 + 1] = (bal >> 32) != 0;
+                }
             }
         }
-    };
-    if (NT_RES > 0) {
-        for (int t = 0; t < ntiles; ++t) stage(t, t);
         __syncthreads();
     }
 
-    for (int qt = bx * NW + wave; (NT_RES > 0) ? (qt * 32 < Sb) : (qt == bx * NW + wave); qt += NW * gx) {
+    for (int qt = qt_first; (NT_RES > 0) ? (qt * 32 < Sb) : (qt == bx * NW + wave); qt += NW * gx) {
         const int wq0 = qt * 32;
         const bool active = wq0 < Sb;
-        h16x8 qf[4];
-        load_rows_frag(qb, pitch, wq0, Sb, lane, qf);
+        if (NT_RES == 0 || qt != qt_first) load_rows_frag(qb, pitch, wq0, Sb, lane, qf);
         f32x16 o[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -378,9 +403,7 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
     const float c = 0.125f * LOG2E;
     const int ntiles = (Sb + TILE - 1) / TILE;
 
-    auto stage = [&](int t, int slot) {
-        stage_tile<NT>(kb, pitch, t * TILE, Sb, tid, k_img + slot * IMG, kt_img + slot * IMG);
-        stage_tile<NT>(vb, pitch, t * TILE, Sb, tid, v_img + slot * IMG, nullptr);
+    auto stage = [&](int t, int slot) {      // the key bias + "any key" flags of tile t (the images go by dma_resident)
         if (tid < TILE) {
             const int key = t * TILE + tid;
             float bias = NEG_BIG;
@@ -394,6 +417,9 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
         }
     };
     if (NT_RES > 0) {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        dma_resident<NW, NTL>(kb, pitch, Sb, ntiles, uw, lane, k_img, kt_img);
+        dma_resident<NW, NTL>(vb, pitch, Sb, ntiles, uw, lane, v_img, nullptr);
         for (int t = 0; t < ntiles; ++t) stage(t, t);
         __syncthreads();
     }
@@ -549,9 +575,7 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
     const float c = 0.125f * LOG2E;
     const int ntiles = (Sb + TILE - 1) / TILE;
 
-    auto stage = [&](int t, int slot) {
-        stage_tile<NT>(qb, pitch, t * TILE, Sb, tid, q_img + slot * IMG, qt_img + slot * IMG);
-        stage_tile<NT>(dob, (size_t)H * HD, t * TILE, Sb, tid, do_img + slot * IMG, dot_img + slot * IMG);
+    auto stage = [&](int t, int slot) {      // lse / delta of tile t (the images go by dma_resident)
         for (int i = tid; i < TILE; i += NT) {
             const int qq = t * TILE + i;
             // rows past S: lse = +big makes P = exp2(-big) = 0, so they add nothing
@@ -579,6 +603,9 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
         }
     };
     if (NT_RES > 0) {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        dma_resident<NW, NTL>(qb, pitch, Sb, ntiles, uw, lane, q_img, qt_img);
+        dma_resident<NW, NTL>(dob, (size_t)H * HD, Sb, ntiles, uw, lane, do_img, dot_img);
         for (int t = 0; t < ntiles; ++t) stage(t, t);
         __syncthreads();
     }
@@ -835,20 +862,34 @@ MH_DEV void attn_bwd_onepass_body(const AttnArgs& A, const int bh, char* smem) {
     float* lse_t = (float*)(mbox + OP_NB * OP_MB);
     float* dl_t = lse_t + OP_ROWS;
 
-    for (int q = tid; q < OP_ROWS * 8; q += 448) {
-        const int r = q >> 3, ch = q & 7;
-        i32x4 vq = {0, 0, 0, 0}, vd = {0, 0, 0, 0}, vk = {0, 0, 0, 0};
-        if (r < Sb) {
-            vq = *(const i32x4*)(qb + (size_t)r * pitch + ch * 8);
-            vd = *(const i32x4*)(dob + (size_t)r * H * HD + ch * 8);
-            vk = *(const i32x4*)(kb + (size_t)r * pitch + ch * 8);
+    {   // Q and dO (row + transposed images) and K (transposed image): global -> LDS by LDS-DMA, all 140 one-KiB pieces of the
+        // workgroup in flight at once (20 per wave).  The register path was a rolled loop of {3 loads, wait, 5 LDS writes} x 4:
+        // four dependent memory round trips ahead of the barrier, then the delta loads, then K / V fragments -- ~7 round trips
+        // per workgroup before the first MFMA.  Swizzles on the source side as in the forward; rows past S read as zeros.
+        const uint32_t qk_bytes = (uint32_t)(((size_t)(Sb - 1) * pitch + HD) * 2);
+        const uint32_t do_bytes = (uint32_t)(((size_t)(Sb - 1) * H * HD + HD) * 2);
+        const __amdgpu_buffer_rsrc_t rq = mh_rsrc(qb, qk_bytes), rk = mh_rsrc(kb, qk_bytes), rd = mh_rsrc(dob, do_bytes);
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int i = 0; i < OP_ROWS / 8 / OP_NB; ++i) {      // 28 pieces of 8 rows per image, 4 per wave
+            const int p = uw + i * OP_NB;
+            const int r = p * 8 + (lane >> 3), cp = lane & 7;
+            const int c_row = cp ^ ((r ^ (r >> 3)) & 7);                                  // row_img_off
+            const int c_tr = ((((cp >> 1) ^ (((r >> 1) & 1) << 1)) << 1) | (cp & 1));     // tr_img_off
+            const uint32_t oq = (uint32_t)r * (uint32_t)pitch * 2u, od = (uint32_t)r * (uint32_t)(H * HD) * 2u;
+            char* dst = smem + p * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, LDS_PTR(void, dst), 16, oq + c_row * 16, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, LDS_PTR(void, dst + OP_IMG), 16, oq + c_tr * 16, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(void, dst + 2 * OP_IMG), 16, od + c_row * 16, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(void, dst + 3 * OP_IMG), 16, od + c_tr * 16, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, LDS_PTR(void, dst + 4 * OP_IMG), 16, oq + c_tr * 16, 0, 0, 0);
         }
-        *(i32x4*)(q_img + row_img_off(r, ch)) = vq;
-        *(i32x4*)(qt_img + tr_img_off(r, ch >> 1) + ((ch & 1) << 4)) = vq;
-        *(i32x4*)(do_img + row_img_off(r, ch)) = vd;
-        *(i32x4*)(dot_img + tr_img_off(r, ch >> 1) + ((ch & 1) << 4)) = vd;
-        *(i32x4*)(kt_img + tr_img_off(r, ch >> 1) + ((ch & 1) << 4)) = vk;
     }
+    const int wk0 = wave * 32;
+    const bool mine = wk0 < Sb;                    // this wave's key / query block holds rows (uniform per wave)
+    h16x8 kf[4], vf[4];
+    load_rows_frag(kb, pitch, wk0, Sb, lane, kf);      // (issued with the staging traffic: one wait for everything)
+    load_rows_frag(vb, pitch, wk0, Sb, lane, vf);
     {   // two threads per query row (448 = 2 x 224): dims 16 s + 8 hf + j, s-major, then the two halves added -- the dQ kernel's order
         const int i = tid >> 1, hf = tid & 1;
         float dl = 0.f;
@@ -874,11 +915,6 @@ MH_DEV void attn_bwd_onepass_body(const AttnArgs& A, const int bh, char* smem) {
     }
     __syncthreads();
 
-    const int wk0 = wave * 32;
-    const bool mine = wk0 < Sb;                    // this wave's key / query block holds rows (uniform per wave)
-    h16x8 kf[4], vf[4];
-    load_rows_frag(kb, pitch, wk0, Sb, lane, kf);
-    load_rows_frag(vb, pitch, wk0, Sb, lane, vf);
     const float kbias = (wk0 + (lane & 31)) < Sb ? 0.f : NEG_BIG;
     f32x16 dk[2], dv[2], dq[2];
 #pragma unroll

@@ -51,14 +51,15 @@ MH_DEV void store_row(h16* __restrict__ p, int D, int lane, const float (&v)[NCH
 }
 
 // a row kept in its packed 16-bit form (4 registers per chunk): what a prefetch holds while the previous row computes
+// (buffer loads bounded at the row's D elements: a chunk past the row reads as zeros WITHOUT a branch.  The predicated form
+//  `r = 0; if (c < D) r = load` compiled to load - s_waitcnt vmcnt(0) - select per chunk: the chunks of the rows a wave holds were
+//  fetched one memory round trip after the other -- tools/isa_loadchain.py: L w0 L w0 L w0 -- three of them ahead of the first
+//  reduction at D = 768, RPW = 2.)
 template <int NCH>
 MH_DEV void load_row_raw(const h16* __restrict__ p, int D, int lane, i32x4 (&r)[NCH]) {
+    const __amdgpu_buffer_rsrc_t rs = mh_rsrc(p, (uint32_t)D * 2u);
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = (lane + 64 * i) * 8;
-        r[i] = i32x4{0, 0, 0, 0};
-        if (c < D) r[i] = *(const i32x4*)(p + c);
-    }
+    for (int i = 0; i < NCH; ++i) r[i] = mh_buf_load16(rs, (uint32_t)(lane + 64 * i) * 16u);
 }
 template <int NCH>
 MH_DEV void unpack_row(const i32x4 (&r)[NCH], float (&v)[NCH][8]) {
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdGroup grp, int D
     const int rows = jb.rows_dev ? min(jb.rows, *jb.rows_dev) : jb.rows;
     const float eps = jb.eps;
     const int lane = threadIdx.x & 63;
-    const int row0 = ((int)blockIdx.x - grp.start[j]) * (4 * RPW) + (threadIdx.x >> 6) * RPW;
+    // (wave-uniform by construction; readfirstlane tells the compiler, so that the rows' buffer resources live in SGPRs)
+    const int row0 = ((int)blockIdx.x - grp.start[j]) * (4 * RPW) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * RPW;
     if (row0 >= rows) return;
     i32x4 raw[RPW][NCH];
 #pragma unroll
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LnBwdGroup grp, 
     const int rows = jb.rows_dev ? min(jb.rows, *jb.rows_dev) : jb.rows;
     const int32_t* __restrict__ drop_rows = jb.drop_rows;
     const int blk = (int)blockIdx.x - grp.start[j];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: row buffer resources in SGPRs)
     float g[NCH][8], dg[NCH][8], db[NCH][8];
     load_row_f32<NCH>(gamma, D, lane, g);
 #pragma unroll
