@@ -308,19 +308,32 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
                 ga[e] = a.bn_gamma[gn + e]; be[e] = a.bn_beta[gn + e];
             }
         }
+        // The z / other-branch gradient / mask rows of ALL FOUR iterations are requested before the first is used, with one explicit
+        // wait.  (Inside the loop every iteration was load -> s_waitcnt vmcnt(0) -> compute -> store: four dependent load round trips,
+        // each also waiting for the previous iteration's store to complete -- loads and stores share the counter on gfx9.  Rows past
+        // M / columns past N re-read a valid element and are never stored.)
+        constexpr int EIT = BM * 16 / (NW * 64);
+        Pack8 zs[EIT], as[EIT], ys[EIT];
 #pragma unroll
-        for (int it = 0; it < BM * 16 / (NW * 64); ++it) {
+        for (int it = 0; it < EIT; ++it) {
+            const int gmc = min(m0 + ((it * NW * 64 + tid) >> 4), a.M - 1);
+            const size_t o = (size_t)gmc * a.ldc + (gn < a.N ? gn : 0);
+            zs[it].v = *(const i32x4*)(a.bn_z + o);
+            as[it].v = i32x4{0, 0, 0, 0};
+            ys[it].v = i32x4{0, 0, 0, 0};
+            if (a.bn_add) as[it].v = *(const i32x4*)(a.bn_add + o);
+            if (a.bn_y) ys[it].v = *(const i32x4*)(a.bn_y + o);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
             const int row = (it * NW * 64 + tid) >> 4;
             const int gm = m0 + row;
             if (gm >= a.M || gn >= a.N) continue;
             const f32x4 x0 = *(const f32x4*)(cs + cs_index(row, cc * 8));
             const f32x4 x1 = *(const f32x4*)(cs + cs_index(row, cc * 8 + 4));
-            Pack8 zv, u, av, yv;
-            zv.v = *(const i32x4*)(a.bn_z + (size_t)gm * a.ldc + gn);
-            av.v = i32x4{0, 0, 0, 0};
-            yv.v = i32x4{0, 0, 0, 0};
-            if (a.bn_add) av.v = *(const i32x4*)(a.bn_add + (size_t)gm * a.ldc + gn);
-            if (a.bn_y) yv.v = *(const i32x4*)(a.bn_y + (size_t)gm * a.ldc + gn);
+            Pack8 u;
+            const Pack8 zv = zs[it], av = as[it], yv = ys[it];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float g = mh_bf2f(mh_f2bf((e < 4 ? x0[e] : x1[e - 4]) * alpha));
@@ -424,26 +437,48 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
         for (int e = 0; e < 8; ++e) { mu[e] = bf.mean[col + e]; rs[e] = bf.rstd[col + e]; ga[e] = bf.gamma[col + e]; be[e] = bf.beta[col + e]; }
     }
     if (col < N) {
+        // A thread's four rows go through the slabs TOGETHER: per slab 8 independent 16-byte loads in flight (a row at a time it was
+        // 2, i.e. 4 x nsplit dependent round trips per thread), and the BatchNorm operands of all four rows are requested before
+        // the slab walk.  Every element is still summed in slab order: bit-identical.  Rows past M re-read row M-1 and are not stored.
+        size_t ro[4];
+        bool live[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = blk * 128 + ty + 32 * i;
-            if (r >= M) break;
-            const float* src = slabs + (size_t)r * N + col;
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < nsplit; ++k, src += (size_t)M * N) {
-                a0 += *(const f32x4*)src;
-                a1 += *(const f32x4*)(src + 4);
+            live[i] = r < M;
+            ro[i] = (size_t)min(r, M - 1) * N + col;
+        }
+        Pack8 zs[4], as[4], ys[4];
+        if (bf.z) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                zs[i].v = *(const i32x4*)(bf.z + ro[i]);
+                as[i].v = i32x4{0, 0, 0, 0};
+                ys[i].v = i32x4{0, 0, 0, 0};
+                if (bf.add) as[i].v = *(const i32x4*)(bf.add + ro[i]);
+                if (bf.ymask) ys[i].v = *(const i32x4*)(bf.ymask + ro[i]);
             }
+        }
+        f32x4 a0[4], a1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const float* src = slabs;
+        for (int k = 0; k < nsplit; ++k, src += (size_t)M * N) {
+            f32x4 t0[4], t1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t0[i] = *(const f32x4*)(src + ro[i]); t1[i] = *(const f32x4*)(src + ro[i] + 4); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a0[i] += t0[i]; a1[i] += t1[i]; }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): nothing below waits behind a store
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!live[i]) continue;
             Pack8 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { o.e[e] = mh_f2bf(a0[e]); o.e[4 + e] = mh_f2bf(a1[e]); }
+            for (int e = 0; e < 4; ++e) { o.e[e] = mh_f2bf(a0[i][e]); o.e[4 + e] = mh_f2bf(a1[i][e]); }
             if (bf.z) {       // dgrad feeding a BatchNorm (+ReLU) backward: masked gradient + its two column sums
-                Pack8 zv, av, yv;
-                zv.v = *(const i32x4*)(bf.z + (size_t)r * N + col);
-                av.v = i32x4{0, 0, 0, 0};
-                yv.v = i32x4{0, 0, 0, 0};
-                if (bf.add) av.v = *(const i32x4*)(bf.add + (size_t)r * N + col);
-                if (bf.ymask) yv.v = *(const i32x4*)(bf.ymask + (size_t)r * N + col);
+                const Pack8 zv = zs[i], av = as[i], yv = ys[i];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float g = mh_bf2f(o.e[e]);
@@ -457,10 +492,10 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
                     s[e] += g;
                     q[e] += g * xh;
                 }
-                *(i32x4*)(y + (size_t)r * N + col) = o.v;
+                *(i32x4*)(y + ro[i]) = o.v;
                 continue;
             }
-            *(i32x4*)(y + (size_t)r * N + col) = o.v;
+            *(i32x4*)(y + ro[i]) = o.v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = mh_bf2f(o.e[e]);

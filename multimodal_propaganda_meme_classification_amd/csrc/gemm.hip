@@ -110,6 +110,14 @@ MH_DEV void epilogue_rows(const MhGemmProblem& P, const float* cs, int m0, int n
         b0 = *(const f32x4*)(P.bias + gn);
         b1 = *(const f32x4*)(P.bias + gn + 4);
     }
+    // ONE explicit wait for the bias / prefetched-operand loads, on every path, before the first iteration.  Without it each
+    // iteration of the loop below began with a compiler-inserted s_waitcnt vmcnt(0): an iteration's body -- and the wait inside it --
+    // is skipped when its row is past M, so at the next iteration's entry those loads are still pending on SOME path, and because
+    // the other path has issued stores in between (loads and stores share the one in-order counter on gfx9) the only count the
+    // compiler can prove is zero.  At run time that made iterations 2..4 wait for the previous iteration's global stores to
+    // COMPLETE: three store round trips in every tile's epilogue (tools/isa_loadchain.py shows `S : b w0` per iteration before, none
+    // after; round 4, second session).
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
 #pragma unroll
     for (int it = 0; it < iters; ++it) {
         const int row = (it * nthreads + tid) >> 4;

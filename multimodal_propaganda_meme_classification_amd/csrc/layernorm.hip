@@ -305,15 +305,17 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const ColsumJobs j
     const float* p = jobs.part[job] + (size_t)which * n_part * D;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (col < D) {
-        for (int i0 = wave; i0 < n_part; i0 += 16) {
-            f32x4 v[4];
+        // eight 16-B loads in flight per lane (two of the former iterations per trip, added in the former order: bit-identical)
+        for (int i0 = wave; i0 < n_part; i0 += 32) {
+            f32x4 v[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const int i = i0 + 4 * k;
-                v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i < n_part) v[k] = *(const f32x4*)(p + (size_t)i * D + col);
+                v[k] = *(const f32x4*)(p + (size_t)min(i, n_part - 1) * D + col);      // (unconditional: a predicated load is a dependent one)
+                if (i >= n_part) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             s += (v[0] + v[1]) + (v[2] + v[3]);
+            s += (v[4] + v[5]) + (v[6] + v[7]);
         }
     }
     red[wave][lane] = s;

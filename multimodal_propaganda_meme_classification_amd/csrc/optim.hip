@@ -73,7 +73,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const float l2 = decoupled ? 0.f : wd;
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        // (all four streams requested together: with p / m / v loaded behind the finiteness test of g, every iteration of the guarded
+        //  form was two dependent memory round trips)
         const f32x4 gv = *(const f32x4*)(g + 4 * i);
+        f32x4 pv = *(const f32x4*)(p + 4 * i);
+        f32x4 mv = *(const f32x4*)(m + 4 * i);
+        f32x4 vv = *(const f32x4*)(v + 4 * i);
         if (overflow) {
             // guarded update (optimizer-in-backward: the slice is updated before the global norm can exist): elements whose
             // gradient is not finite keep their parameters and moments, and the step is reported through *overflow so that
@@ -84,9 +89,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                 continue;
             }
         }
-        f32x4 pv = *(const f32x4*)(p + 4 * i);
-        f32x4 mv = *(const f32x4*)(m + 4 * i);
-        f32x4 vv = *(const f32x4*)(v + 4 * i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float w = pv[e] * decay;
