@@ -199,6 +199,7 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
     char* v_img = smem + NTL * IMG;
     float* kbias = (float*)(smem + 2 * NTL * IMG);
     int* kany = (int*)(kbias + NTL * TILE);   // per 32-key sub-tile: any key to attend to?
+    int* pos_t = kany + 16;                   // resident + dropout: position of local row i in the unpacked sequence (see posl)
 
     const int b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -208,6 +209,9 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
     const int Sb = cu ? cu[b + 1] - cu[b] : S;
     // position of local row i in the unpacked sequence (dropout mask index only)
     auto pos = [&](int i) -> uint64_t { return (row_map && i < Sb) ? (uint64_t)(row_map[r0 + i] - b * S) : (uint64_t)i; };
+    // (resident mode reads the positions from an LDS table filled once while staging: pos() is a global load, and the 17 of them per
+    //  32-key sub-tile sat one behind the other in the dropout branch -- tools/isa_loadchain.py showed L w0 x 17 per sub-tile)
+    auto posl = [&](int i) -> uint64_t { return NT_RES > 0 ? (uint64_t)pos_t[i] : pos(i); };
     const h16* qb = qkv + r0 * pitch + hh * HD;
     const h16* kb = qb + (size_t)H * HD;
     const h16* vb = qb + (size_t)2 * H * HD;
@@ -222,6 +226,8 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
         dma_resident<NW, NTL>(kb, pitch, Sb, ntiles, uw, lane, k_img, nullptr);
         dma_resident<NW, NTL>(vb, pitch, Sb, ntiles, uw, lane, nullptr, v_img);
         if (qt_first * 32 < Sb) load_rows_frag(qb, pitch, qt_first * 32, Sb, lane, qf);      // Q of the first block rides the same wait
+        if (DROP)
+            for (int i = tid; i < NTL * TILE; i += NT) pos_t[i] = (int)pos(i);
         if (tid < TILE) {   // wave 0, all 64 lanes: additive key bias + "any key" flags of every tile
             int64_t km[NTL];
 #pragma unroll
@@ -338,10 +344,10 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
                 }
                 l += ps;
                 if (DROP && drop.on) {   // O = drop(P) V: the normaliser l keeps every key, only the PV operand is masked
-                    const uint64_t rowbase = (((uint64_t)bh * S) + pos(wq0 + (lane & 31))) * (uint64_t)S;
+                    const uint64_t rowbase = (((uint64_t)bh * S) + posl(wq0 + (lane & 31))) * (uint64_t)S;
 #pragma unroll
                     for (int g = 0; g < 16; ++g)
-                        st[g] *= mh_drop_mul(drop, rowbase + pos(t * TILE + sub * 32 + acc_row(g, h)));
+                        st[g] *= mh_drop_mul(drop, rowbase + posl(t * TILE + sub * 32 + acc_row(g, h)));
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -387,6 +393,7 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
     char* v_img = smem + 2 * NTL * IMG;
     float* kbias = (float*)(smem + 3 * NTL * IMG);
     int* kany = (int*)(kbias + NTL * TILE);
+    int* pos_t = kany + 16;                   // as in the forward
 
     const int b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -396,6 +403,7 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
     const int Sb = cu ? cu[b + 1] - cu[b] : S;
     // position of local row i in the unpacked sequence (dropout mask index only)
     auto pos = [&](int i) -> uint64_t { return (row_map && i < Sb) ? (uint64_t)(row_map[r0 + i] - b * S) : (uint64_t)i; };
+    auto posl = [&](int i) -> uint64_t { return NT_RES > 0 ? (uint64_t)pos_t[i] : pos(i); };      // resident: LDS table (see the forward)
     const h16* qb = qkv + r0 * pitch + hh * HD;
     const h16* kb = qb + (size_t)H * HD;
     const h16* vb = qb + (size_t)2 * H * HD;
@@ -420,6 +428,8 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
         const int uw = __builtin_amdgcn_readfirstlane(wave);
         dma_resident<NW, NTL>(kb, pitch, Sb, ntiles, uw, lane, k_img, kt_img);
         dma_resident<NW, NTL>(vb, pitch, Sb, ntiles, uw, lane, v_img, nullptr);
+        if (DROP)
+            for (int i = tid; i < NTL * TILE; i += NT) pos_t[i] = (int)pos(i);
         for (int t = 0; t < ntiles; ++t) stage(t, t);
         __syncthreads();
     }
@@ -511,8 +521,8 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
                         const float p = __builtin_amdgcn_exp2f(st[g] * c + kb4[e] - lse2);
                         float dpg = dp[g];
                         if (DROP && drop.on)   // dP = dP_drop * mask / (1 - p)
-                            dpg *= mh_drop_mul(drop, ((uint64_t)bh * S + pos(q)) * (uint64_t)S +
-                                                         pos(t * TILE + sub * 32 + acc_row(g, h)));
+                            dpg *= mh_drop_mul(drop, ((uint64_t)bh * S + posl(q)) * (uint64_t)S +
+                                                         posl(t * TILE + sub * 32 + acc_row(g, h)));
                         st[g] = p * (dpg - dl);  // dS^T (unscaled)
                     }
                 }
@@ -559,6 +569,7 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
     char* dot_img = smem + 3 * NTL * IMG;
     float* lse_t = (float*)(smem + 4 * NTL * IMG);
     float* dl_t = lse_t + NTL * TILE;
+    int* pos_t = (int*)(dl_t + NTL * TILE);   // as in the forward
 
     const int b = bh / H, hh = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -568,6 +579,7 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
     const int Sb = cu ? cu[b + 1] - cu[b] : S;
     // position of local row i in the unpacked sequence (dropout mask index only)
     auto pos = [&](int i) -> uint64_t { return (row_map && i < Sb) ? (uint64_t)(row_map[r0 + i] - b * S) : (uint64_t)i; };
+    auto posl = [&](int i) -> uint64_t { return NT_RES > 0 ? (uint64_t)pos_t[i] : pos(i); };      // resident: LDS table (see the forward)
     const h16* qb = qkv + r0 * pitch + hh * HD;
     const h16* kb = qb + (size_t)H * HD;
     const h16* vb = qb + (size_t)2 * H * HD;
@@ -606,6 +618,8 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
         const int uw = __builtin_amdgcn_readfirstlane(wave);
         dma_resident<NW, NTL>(qb, pitch, Sb, ntiles, uw, lane, q_img, qt_img);
         dma_resident<NW, NTL>(dob, (size_t)H * HD, Sb, ntiles, uw, lane, do_img, dot_img);
+        if (DROP)
+            for (int i = tid; i < NTL * TILE; i += NT) pos_t[i] = (int)pos(i);
         for (int t = 0; t < ntiles; ++t) stage(t, t);
         __syncthreads();
     }
@@ -716,8 +730,8 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
                         const float p = __builtin_amdgcn_exp2f(st[g] * c + kbias - l4[e]);
                         float mul = 1.f;
                         if (DROP && drop.on)
-                            mul = mh_drop_mul(drop, ((uint64_t)bh * S + pos(t * TILE + sub * 32 + 8 * g4 + 4 * h + e)) *
-                                                            (uint64_t)S + pos(key));
+                            mul = mh_drop_mul(drop, ((uint64_t)bh * S + posl(t * TILE + sub * 32 + 8 * g4 + 4 * h + e)) *
+                                                            (uint64_t)S + posl(key));
                         pp[g] = p * mul;                     // drop(P): what multiplied V in the forward
                         st[g] = p * (dp[g] * mul - d4[e]);   // dS (unscaled)
                     }
@@ -1129,9 +1143,9 @@ AttnArgs to_args(const MhAttnProblem& p) {
 bool has_drop(const MhAttnProblem& p) { return p.rng && p.drop_p > 0.f; }
 
 // LDS bytes: forward <NW, NT_RES>, backward dQ (L1) / dK,dV (L2)
-constexpr int lds_fwd(int nt) { return 2 * (nt > 0 ? nt : 1) * IMG + (nt > 0 ? nt : 1) * TILE * 4 + 64; }
-constexpr int lds_dq(int nt) { return 3 * (nt > 0 ? nt : 1) * IMG + (nt > 0 ? nt : 1) * TILE * 4 + 64; }
-constexpr int lds_dkv(int nt) { return 4 * (nt > 0 ? nt : 1) * IMG + 2 * (nt > 0 ? nt : 1) * TILE * 4; }
+constexpr int lds_fwd(int nt) { return 2 * (nt > 0 ? nt : 1) * IMG + 2 * (nt > 0 ? nt : 1) * TILE * 4 + 64; }      // + position table (dropout index)
+constexpr int lds_dq(int nt) { return 3 * (nt > 0 ? nt : 1) * IMG + 2 * (nt > 0 ? nt : 1) * TILE * 4 + 64; }
+constexpr int lds_dkv(int nt) { return 4 * (nt > 0 ? nt : 1) * IMG + 3 * (nt > 0 ? nt : 1) * TILE * 4; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 void launch_fwd(const MhAttnProblem& p, hipStream_t s) {

@@ -51,20 +51,22 @@ __global__ __launch_bounds__(256) void col2im_kernel(const h16* __restrict__ dco
     const size_t p = idx / c8;
     const int w = (int)(p % W), h = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // (every tap's load is issued unconditionally -- an invalid tap re-reads element 0 and is not added -- so that a filter row's
+    //  loads are in flight together; with the loads behind the validity branches each tap was its own memory round trip)
     for (int kh = 0; kh < KH; ++kh) {
         const int th = h + pad - kh;
-        if (th < 0 || th % stride) continue;
         const int ho = th / stride;
-        if (ho >= Ho) continue;
+        const bool okh = th >= 0 && (th % stride) == 0 && ho < Ho;
+#pragma unroll 4
         for (int kw = 0; kw < KW; ++kw) {
             const int tw = w + pad - kw;
-            if (tw < 0 || tw % stride) continue;
             const int wo = tw / stride;
-            if (wo >= Wo) continue;
+            const bool ok = okh && tw >= 0 && (tw % stride) == 0 && wo < Wo;
+            const size_t off = ok ? (((size_t)b * Ho + ho) * Wo + wo) * ldc + (size_t)(kh * KW + kw) * C + cc * 8 : 0;
             Pack8 u;
-            u.v = *(const i32x4*)(dcol + (((size_t)b * Ho + ho) * Wo + wo) * ldc + (size_t)(kh * KW + kw) * C + cc * 8);
+            u.v = *(const i32x4*)(dcol + off);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += mh_bf2f(u.e[e]);
+            for (int e = 0; e < 8; ++e) acc[e] += ok ? mh_bf2f(u.e[e]) : 0.f;
         }
     }
     Pack8 o;
@@ -300,8 +302,14 @@ __global__ __launch_bounds__(256) void bn2d_finish_kernel(const float* __restric
                                                           float* __restrict__ run_mean, float* __restrict__ run_var) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
+    float rm0 = 0.f, rv0 = 0.f;          // the running statistics are requested with the partials, not behind the reduction
+    if (lane == 0) {
+        if (run_mean) rm0 = run_mean[c];
+        if (run_var) rv0 = run_var[c];
+    }
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
+#pragma unroll 4
+    for (int b = lane; b < nblk; b += 64) {      // (8 loads in flight; the 784-tile layers were 13 dependent round trips; same order)
         s += (double)part[(size_t)c * nblk + b];
         q += (double)part[((size_t)C + c) * nblk + b];
     }
@@ -313,8 +321,8 @@ __global__ __launch_bounds__(256) void bn2d_finish_kernel(const float* __restric
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (run_mean) run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mu;
-    if (run_var) run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)(M > 1 ? var * M / (M - 1) : var);
+    if (run_mean) run_mean[c] = (1.0f - momentum) * rm0 + momentum * (float)mu;
+    if (run_var) run_var[c] = (1.0f - momentum) * rv0 + momentum * (float)(M > 1 ? var * M / (M - 1) : var);
 }
 // eval mode: mean / rstd from the running statistics
 __global__ __launch_bounds__(256) void bn2d_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
@@ -370,21 +378,40 @@ __global__ __launch_bounds__(256) void bn2d_bwd_stats_kernel(const h16* __restri
         load8(mean + t * 8, mu);
         load8(rstd + t * 8, rs);
         if (from_x) { load8(gamma + t * 8, ga); load8(beta + t * 8, be); }
-        for (int r = r0 + ty; r < r1; r += nty) {
-            Pack8 d, xv, yv;
-            d.v = *(const i32x4*)(dy + (size_t)r * C + t * 8);
-            xv.v = *(const i32x4*)(x + (size_t)r * C + t * 8);
-            yv.v = d.v;
-            if (from_y) yv.v = *(const i32x4*)(y + (size_t)r * C + t * 8);
+        const h16* ysrc = from_y ? y : dy;      // (always loaded: a load behind the flag is a branch, and a branch splits the rows' loads)
+        auto add_row = [&](const Pack8& d, const Pack8& xv, const Pack8& yv) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float g = mh_bf2f(d.e[e]);
                 const float xh = (mh_bf2f(xv.e[e]) - mu[e]) * rs[e];
-                if (from_y && !(mh_bf2f(yv.e[e]) > 0.f)) g = 0.f;
-                if (from_x && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) g = 0.f;
+                g = (from_y && !(mh_bf2f(yv.e[e]) > 0.f)) ? 0.f : g;
+                g = (from_x && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) ? 0.f : g;
                 s[e] += g;
                 q[e] += g * xh;
             }
+        };
+        // four rows per trip, their 12 loads in flight together, added in row order (a row at a time the loop was one memory round
+        // trip per row: up to 16 of them per thread)
+        int r = r0 + ty;
+        for (; r + 3 * nty < r1; r += 4 * nty) {
+            Pack8 d[4], xv[4], yv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = (size_t)(r + k * nty) * C + t * 8;
+                d[k].v = *(const i32x4*)(dy + o);
+                xv[k].v = *(const i32x4*)(x + o);
+                yv[k].v = *(const i32x4*)(ysrc + o);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) add_row(d[k], xv[k], yv[k]);
+        }
+        for (; r < r1; r += nty) {
+            Pack8 d, xv, yv;
+            const size_t o = (size_t)r * C + t * 8;
+            d.v = *(const i32x4*)(dy + o);
+            xv.v = *(const i32x4*)(x + o);
+            yv.v = *(const i32x4*)(ysrc + o);
+            add_row(d, xv, yv);
         }
     }
     bn_block_reduce(s, q, part, blk, (int)gridDim.y, C, t < c8 ? t : C, ty, nty, c8w);
@@ -395,8 +422,14 @@ __global__ __launch_bounds__(256) void bn2d_bwd_finish_kernel(const float* __res
                                                               int accumulate) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
+    float db0 = 0.f, dg0 = 0.f;          // the accumulation targets are requested with the partials
+    if (lane == 0 && accumulate) {
+        if (dbeta) db0 = dbeta[c];
+        if (dgamma) dg0 = dgamma[c];
+    }
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
+#pragma unroll 4
+    for (int b = lane; b < nblk; b += 64) {      // (8 loads in flight; the 784-tile layers were 13 dependent round trips; same order)
         s += (double)part[(size_t)c * nblk + b];
         q += (double)part[((size_t)C + c) * nblk + b];
     }
@@ -405,8 +438,8 @@ __global__ __launch_bounds__(256) void bn2d_bwd_finish_kernel(const float* __res
     if (lane != 0) return;
     sums[c] = (float)s;
     sums[C + c] = (float)q;
-    if (dbeta) dbeta[c] = (float)s * scale + (accumulate ? dbeta[c] : 0.f);
-    if (dgamma) dgamma[c] = (float)q * scale + (accumulate ? dgamma[c] : 0.f);
+    if (dbeta) dbeta[c] = (float)s * scale + db0;
+    if (dgamma) dgamma[c] = (float)q * scale + dg0;
 }
 // dx = gamma rstd (dy' - mean(dy') - xhat mean(dy' xhat)) ; dres = dy' (the gradient of the residual branch), optional
 __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const h16* __restrict__ dy, const h16* __restrict__ x,
@@ -460,18 +493,23 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const h16* __restrict_
     uint8_t am[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; am[e] = 255; }
+    // (taps outside the image re-read a clamped pixel and are not compared: the window's loads are in flight together instead of
+    //  one memory round trip per tap; comparison order and tie rule unchanged)
     for (int kh = 0; kh < K; ++kh) {
         const int ih = ho * stride - pad + kh;
-        if (ih < 0 || ih >= H) continue;
+        const bool okh = ih >= 0 && ih < H;
+#pragma unroll 4
         for (int kw = 0; kw < K; ++kw) {
             const int iw = wo * stride - pad + kw;
-            if (iw < 0 || iw >= W) continue;
+            const bool ok = okh && iw >= 0 && iw < W;
             Pack8 u;
-            u.v = *(const i32x4*)(x + (((size_t)b * H + ih) * W + iw) * C + cc * 8);
+            u.v = *(const i32x4*)(x + (((size_t)b * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)) * C + cc * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = mh_bf2f(u.e[e]);
-                if (v > m[e]) { m[e] = v; am[e] = (uint8_t)(kh * K + kw); }
+                const bool take = ok && v > m[e];      // (selects, not branches: the loads of a filter row stay in one block)
+                m[e] = take ? v : m[e];
+                am[e] = take ? (uint8_t)(kh * K + kw) : am[e];
             }
         }
     }
@@ -493,22 +531,23 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const h16* __restrict_
     const size_t p = idx / c8;
     const int w = (int)(p % W), h = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (as in col2im: unconditional loads of dy and of the 8 argmax bytes as ONE 8-byte word, selected afterwards)
     for (int kh = 0; kh < K; ++kh) {
         const int th = h + pad - kh;
-        if (th < 0 || th % stride) continue;
         const int ho = th / stride;
-        if (ho >= Ho) continue;
+        const bool okh = th >= 0 && (th % stride) == 0 && ho < Ho;
+#pragma unroll 4
         for (int kw = 0; kw < K; ++kw) {
             const int tw = w + pad - kw;
-            if (tw < 0 || tw % stride) continue;
             const int wo = tw / stride;
-            if (wo >= Wo) continue;
-            const size_t o = (((size_t)b * Ho + ho) * Wo + wo) * C + cc * 8;
+            const bool ok = okh && tw >= 0 && (tw % stride) == 0 && wo < Wo;
+            const size_t o = ok ? (((size_t)b * Ho + ho) * Wo + wo) * C + cc * 8 : 0;
             Pack8 d;
             d.v = *(const i32x4*)(dy + o);
+            const uint64_t a8 = *(const uint64_t*)(arg + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (arg[o + e] == (uint8_t)(kh * K + kw)) acc[e] += mh_bf2f(d.e[e]);
+                acc[e] += (ok && (uint8_t)(a8 >> (8 * e)) == (uint8_t)(kh * K + kw)) ? mh_bf2f(d.e[e]) : 0.f;
         }
     }
     Pack8 o8;
@@ -522,7 +561,8 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const h16* __restrict_
     if (idx >= B * C) return;
     const int b = idx / C, c = idx % C;
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += mh_bf2f(x[((size_t)b * HW + p) * C + c]);
+#pragma unroll 8
+    for (int p = 0; p < HW; ++p) s += mh_bf2f(x[((size_t)b * HW + p) * C + c]);      // (8 loads in flight; same order)
     y[idx] = s / (float)HW;
 }
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, h16* __restrict__ dx, int B, int HW, int C,
