@@ -51,22 +51,20 @@ __global__ __launch_bounds__(256) void col2im_kernel(const h16* __restrict__ dco
     const size_t p = idx / c8;
     const int w = (int)(p % W), h = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // (every tap's load is issued unconditionally -- an invalid tap re-reads element 0 and is not added -- so that a filter row's
-    //  loads are in flight together; with the loads behind the validity branches each tap was its own memory round trip)
     for (int kh = 0; kh < KH; ++kh) {
         const int th = h + pad - kh;
+        if (th < 0 || th % stride) continue;
         const int ho = th / stride;
-        const bool okh = th >= 0 && (th % stride) == 0 && ho < Ho;
-#pragma unroll 4
+        if (ho >= Ho) continue;
         for (int kw = 0; kw < KW; ++kw) {
             const int tw = w + pad - kw;
+            if (tw < 0 || tw % stride) continue;
             const int wo = tw / stride;
-            const bool ok = okh && tw >= 0 && (tw % stride) == 0 && wo < Wo;
-            const size_t off = ok ? (((size_t)b * Ho + ho) * Wo + wo) * ldc + (size_t)(kh * KW + kw) * C + cc * 8 : 0;
+            if (wo >= Wo) continue;
             Pack8 u;
-            u.v = *(const i32x4*)(dcol + off);
+            u.v = *(const i32x4*)(dcol + (((size_t)b * Ho + ho) * Wo + wo) * ldc + (size_t)(kh * KW + kw) * C + cc * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += ok ? mh_bf2f(u.e[e]) : 0.f;
+            for (int e = 0; e < 8; ++e) acc[e] += mh_bf2f(u.e[e]);
         }
     }
     Pack8 o;
@@ -378,40 +376,21 @@ __global__ __launch_bounds__(256) void bn2d_bwd_stats_kernel(const h16* __restri
         load8(mean + t * 8, mu);
         load8(rstd + t * 8, rs);
         if (from_x) { load8(gamma + t * 8, ga); load8(beta + t * 8, be); }
-        const h16* ysrc = from_y ? y : dy;      // (always loaded: a load behind the flag is a branch, and a branch splits the rows' loads)
-        auto add_row = [&](const Pack8& d, const Pack8& xv, const Pack8& yv) {
+        for (int r = r0 + ty; r < r1; r += nty) {
+            Pack8 d, xv, yv;
+            d.v = *(const i32x4*)(dy + (size_t)r * C + t * 8);
+            xv.v = *(const i32x4*)(x + (size_t)r * C + t * 8);
+            yv.v = d.v;
+            if (from_y) yv.v = *(const i32x4*)(y + (size_t)r * C + t * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float g = mh_bf2f(d.e[e]);
                 const float xh = (mh_bf2f(xv.e[e]) - mu[e]) * rs[e];
-                g = (from_y && !(mh_bf2f(yv.e[e]) > 0.f)) ? 0.f : g;
-                g = (from_x && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) ? 0.f : g;
+                if (from_y && !(mh_bf2f(yv.e[e]) > 0.f)) g = 0.f;
+                if (from_x && !(mh_bf2f(mh_f2bf(xh * ga[e] + be[e])) > 0.f)) g = 0.f;
                 s[e] += g;
                 q[e] += g * xh;
             }
-        };
-        // four rows per trip, their 12 loads in flight together, added in row order (a row at a time the loop was one memory round
-        // trip per row: up to 16 of them per thread)
-        int r = r0 + ty;
-        for (; r + 3 * nty < r1; r += 4 * nty) {
-            Pack8 d[4], xv[4], yv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const size_t o = (size_t)(r + k * nty) * C + t * 8;
-                d[k].v = *(const i32x4*)(dy + o);
-                xv[k].v = *(const i32x4*)(x + o);
-                yv[k].v = *(const i32x4*)(ysrc + o);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) add_row(d[k], xv[k], yv[k]);
-        }
-        for (; r < r1; r += nty) {
-            Pack8 d, xv, yv;
-            const size_t o = (size_t)r * C + t * 8;
-            d.v = *(const i32x4*)(dy + o);
-            xv.v = *(const i32x4*)(x + o);
-            yv.v = *(const i32x4*)(ysrc + o);
-            add_row(d, xv, yv);
         }
     }
     bn_block_reduce(s, q, part, blk, (int)gridDim.y, C, t < c8 ? t : C, ty, nty, c8w);
@@ -531,23 +510,22 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const h16* __restrict_
     const size_t p = idx / c8;
     const int w = (int)(p % W), h = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // (as in col2im: unconditional loads of dy and of the 8 argmax bytes as ONE 8-byte word, selected afterwards)
     for (int kh = 0; kh < K; ++kh) {
         const int th = h + pad - kh;
+        if (th < 0 || th % stride) continue;
         const int ho = th / stride;
-        const bool okh = th >= 0 && (th % stride) == 0 && ho < Ho;
-#pragma unroll 4
+        if (ho >= Ho) continue;
         for (int kw = 0; kw < K; ++kw) {
             const int tw = w + pad - kw;
+            if (tw < 0 || tw % stride) continue;
             const int wo = tw / stride;
-            const bool ok = okh && tw >= 0 && (tw % stride) == 0 && wo < Wo;
-            const size_t o = ok ? (((size_t)b * Ho + ho) * Wo + wo) * C + cc * 8 : 0;
+            if (wo >= Wo) continue;
+            const size_t o = (((size_t)b * Ho + ho) * Wo + wo) * C + cc * 8;
             Pack8 d;
             d.v = *(const i32x4*)(dy + o);
-            const uint64_t a8 = *(const uint64_t*)(arg + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                acc[e] += (ok && (uint8_t)(a8 >> (8 * e)) == (uint8_t)(kh * K + kw)) ? mh_bf2f(d.e[e]) : 0.f;
+                if (arg[o + e] == (uint8_t)(kh * K + kw)) acc[e] += mh_bf2f(d.e[e]);
         }
     }
     Pack8 o8;

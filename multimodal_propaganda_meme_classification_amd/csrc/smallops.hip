@@ -26,8 +26,18 @@ struct F32Gemm {
 
 // One K tile of an operand in two halves: f32_load brings the thread's two 4-float chunks into registers, f32_store writes them
 // into the [k][row] LDS image.  Split so that the main loop can keep several tiles' loads in flight (see gemm_f32_kernel).
-template <int KMAJOR>
+template <int KMAJOR, bool FAST>
 MH_DEV void f32_load(const float* __restrict__ g, int ld, int r0, int k0, int rows, int K, int vec, int tid, f32x4 (&out)[2]) {
+    if (KMAJOR == 0 && FAST) {      // FAST kernels (16-B aligned rows, K % 4 == 0): branch-free, clamped address, masked at the LDS store --
+        const int r = tid & 63;     // a predicated load is a dependent one and would undo the prefetch
+        const int rc = min(r0 + r, rows - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + ((tid >> 6) + 4 * i) * 4;
+            out[i] = *(const f32x4*)(g + (size_t)rc * ld + min(k, K - 4));      // masked in f32_store (a select HERE would wait for the load)
+        }
+        return;
+    }
     if (KMAJOR == 0) {      // global [rows][K]: thread = (row, 4-float chunk of k)
         const int r = tid & 63;
 #pragma unroll
@@ -70,15 +80,18 @@ MH_DEV void f32_load(const float* __restrict__ g, int ld, int r0, int k0, int ro
         }
     }
 }
-template <int KMAJOR>
-MH_DEV void f32_store(const f32x4 (&in)[2], float* __restrict__ img, int tid) {
+// fast: the operand came through f32_load's branch-free path (rows / k past the end hold a clamped element): masked here
+template <int KMAJOR, bool FAST>
+MH_DEV void f32_store(const f32x4 (&in)[2], float* __restrict__ img, int tid, int r0, int k0, int rows, int K) {
+    constexpr bool fast = FAST && KMAJOR == 0;
     if (KMAJOR == 0) {      // transposed into the image
         const int r = tid & 63;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = (tid >> 6) + 4 * i;
+            const bool zero = fast && !(r0 + r < rows && k0 + c * 4 < K);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) img[(c * 4 + e) * F_LD + r] = in[i][e];
+            for (int e = 0; e < 4; ++e) img[(c * 4 + e) * F_LD + r] = zero ? 0.f : in[i][e];
         }
     } else {                // copied as is
         const int r = (tid & 15) * 4;
@@ -87,7 +100,7 @@ MH_DEV void f32_store(const f32x4 (&in)[2], float* __restrict__ img, int tid) {
     }
 }
 
-template <int LA, int LB>
+template <int LA, int LB, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Gemm g) {
     __shared__ __attribute__((aligned(16))) float smem[4 * F_BK * F_LD];      // A0 A1 B0 B1 images; reused by the epilogue
     constexpr int IMG_F = F_BK * F_LD;      // images: A0 A1 B0 B1
@@ -105,24 +118,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const F32Gemm g) {
     f32x4 ra[PF][2], rb[PF][2];
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-        if (p < nk) {
-            f32_load<LA>(g.A, g.lda, m0, p * F_BK, g.M, g.K, g.veca, tid, ra[p]);
-            f32_load<LB>(g.B, g.ldb, n0, p * F_BK, g.N, g.K, g.vecb, tid, rb[p]);
+        // (FAST: unconditional -- tiles past K re-read clamped elements and are never stored: with the loads behind `p < nk` the
+        //  compiler cannot count how many younger loads are in flight and waits for ALL of them before every tile)
+        if (FAST || p < nk) {
+            f32_load<LA, FAST>(g.A, g.lda, m0, p * F_BK, g.M, g.K, g.veca, tid, ra[p]);
+            f32_load<LB, FAST>(g.B, g.ldb, n0, p * F_BK, g.N, g.K, g.vecb, tid, rb[p]);
         }
     }
-    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+    // FAST: the trip count is rounded up to whole groups of PF tiles and the body has no exit -- tiles past K hold zeros (masked
+    // stores / bounded loads) and add nothing --, so every tile issues exactly its four loads and the compiler can count the
+    // younger ones in flight (vmcnt(12)) instead of waiting for all of them
+    const int nkp = FAST ? (nk + PF - 1) / PF * PF : nk;
+    for (int kt0 = 0; kt0 < nkp; kt0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int kt = kt0 + p;
-            if (kt >= nk) break;
+            if (!FAST && kt >= nk) break;
             const int cur = p & 1;          // PF is even: tile kt uses LDS buffer kt & 1 == p & 1
             // buffer `cur` was last read by the MFMAs of tile kt - 2, which every wave finished before it arrived at the barrier of
             // tile kt - 1: one barrier per tile is enough
-            f32_store<LA>(ra[p], smem + cur * IMG_F, tid);
-            f32_store<LB>(rb[p], smem + (2 + cur) * IMG_F, tid);
-            if (kt + PF < nk) {
-                f32_load<LA>(g.A, g.lda, m0, (kt + PF) * F_BK, g.M, g.K, g.veca, tid, ra[p]);
-                f32_load<LB>(g.B, g.ldb, n0, (kt + PF) * F_BK, g.N, g.K, g.vecb, tid, rb[p]);
+            f32_store<LA, FAST>(ra[p], smem + cur * IMG_F, tid, m0, kt * F_BK, g.M, g.K);
+            f32_store<LB, FAST>(rb[p], smem + (2 + cur) * IMG_F, tid, n0, kt * F_BK, g.N, g.K);
+            if (FAST || kt + PF < nk) {
+                f32_load<LA, FAST>(g.A, g.lda, m0, (kt + PF) * F_BK, g.M, g.K, g.veca, tid, ra[p]);
+                f32_load<LB, FAST>(g.B, g.ldb, n0, (kt + PF) * F_BK, g.N, g.K, g.vecb, tid, rb[p]);
             }
             __syncthreads();
             const float* a = smem + cur * IMG_F + (lane >> 5) * F_LD + wm * 32 + (lane & 31);
@@ -614,10 +633,18 @@ extern "C" int mh_gemm_f32(const MhGemmF32* p, int a_kmajor, int b_kmajor, mh_st
     }
     const dim3 grid((p->N + F_BM - 1) / F_BM, (p->M + F_BM - 1) / F_BM);
     hipStream_t s = (hipStream_t)stream;
-    if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<0, 0>), grid, dim3(256), 0, s, g);
-    else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<0, 1>), grid, dim3(256), 0, s, g);
-    else if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<1, 0>), grid, dim3(256), 0, s, g);
+    // FAST: every K-contiguous operand has 16-byte aligned rows and K % 4 == 0 (the branch-free operand loads)
+    const bool fast = (p->K % 4) == 0 && (a_kmajor || g.veca) && (b_kmajor || g.vecb) && !(a_kmajor && b_kmajor);
+#define F32_GO(LA_, LB_)                                                                                  \
+    do {                                                                                                  \
+        if (fast) hipLaunchKernelGGL((gemm_f32_kernel<LA_, LB_, true>), grid, dim3(256), 0, s, g);        \
+        else hipLaunchKernelGGL((gemm_f32_kernel<LA_, LB_, false>), grid, dim3(256), 0, s, g);            \
+    } while (0)
+    if (!a_kmajor && !b_kmajor) F32_GO(0, 0);
+    else if (!a_kmajor && b_kmajor) F32_GO(0, 1);
+    else if (a_kmajor && b_kmajor) F32_GO(1, 1);
+    else F32_GO(1, 0);
+#undef F32_GO
     return mh_launch_status();
 }
 
