@@ -509,8 +509,11 @@ int mh_bn2d_bwd(const void* dy, const void* x, const void* y, const float* gamma
  *                 ldk == KH*KW*C take the wave-uniform tap walk).  bn_part (or NULL): f32 [2][Cout][ceil(B*Ho*Wo / 128)] -- per
  *                 128-row tile the column sums of y and y^2 (of the 16-bit values as stored), the layout mh_bn2d_fwd_parts reads:
  *                 train-mode BatchNorm2d (Multimodal_example_task2C.txt:164 resnet50) then needs no statistics pass.
- *   mh_conv_dgrad dx[B*H*W][C] = the input gradient from dy[B*Ho*Wo][Cout]; stride 1, KH == KW, Cout % 64 == 0 (a strided
- *                 convolution keeps the explicit dgrad GEMM + mh_col2im_nhwc).
+ *   mh_conv_dgrad dx[B*H*W][C] = the input gradient from dy[B*Ho*Wo][Cout]; KH == KW, Cout % 64 == 0; stride 1, or stride 2 with
+ *                 KH > 1 on an even H x W image -- then the four parity classes of input pixels (each meets only every second filter
+ *                 tap) run as four stride-1 problems of ONE launch, scattered into every second row / column of dx, and a `bn`
+ *                 part buffer holds 4 * ceil(B*(H/2)*(W/2) / 128) partial columns.  Other strided shapes return MH_ESHAPE and keep
+ *                 the explicit dgrad GEMM + mh_col2im_nhwc (1x1 / stride 2: three of the four classes have no tap).
  *   mh_conv_wgrad slabs[ksplit][Cout][ldk] (f32) = alpha * dy^T im2col(x), the contraction over B*Ho*Wo pixels cut into
  *                 `ksplit` chunks (mh_gemm_ksplit_for(B*Ho*Wo, want)); mh_conv_wgrad_finish_batched sums the slabs.
  * Limits: every tensor < 2 GiB, B*H*W and B*Ho*Wo < 2^24. */

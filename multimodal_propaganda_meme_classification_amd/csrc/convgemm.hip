@@ -50,6 +50,13 @@ struct ConvArgs {
     int bn_relu;
     const h16* bn_add;                     // gradient arriving at the same tensor through the other branch of a residual block, or NULL
     const h16* bn_y;                       // ReLU mask source when the ReLU followed a residual add (y > 0), or NULL (recompute from z)
+    // dgrad of a STRIDED convolution = one problem per parity class (ph, pw) of input pixels: the class's pixels (2h'+ph, 2w'+pw) see
+    // only the filter taps kh = wkh0 + 2 j, i.e. a small stride-1 window over dY, and land in every second row / column of dX.
+    // All zero (ConvArgs a = {}) = the plain stride-1 problem.
+    int wstep;                             // 0 / 1: every tap (weight tap = the flipped window tap); 2: taps wkh0, wkh0 + 2, ... of a KHfull x wkwfull filter
+    int wkh0, wkw0, wkwfull;
+    int out_s, out_ph, out_pw, out_H, out_W;   // out_s = 2: GEMM row (b, h', w') is row (b, 2h'+ph, 2w'+pw) of the [B][out_H][out_W] output (and of z / addend / mask)
+    int part_tm0, part_tiles;              // BatchNorm partials of a multi-problem launch: this problem's first tile / the launch's tile count
 };
 
 // m -> (image, row, column) of the anchored pixel grid.  m < 2^24 (checked on the host): the float quotient is off by at
@@ -206,7 +213,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
         if (MODE == MODE_FWD) {
             dma_tile<0, 2>(rr, a.ldreg, n0, k0, wave, lane, lb);          // Wk [cout][(tap,ci)], K-contiguous
         } else {
-            const int wtap = taps - 1 - (u_kh * a.KW + u_kw);              // the weight tap behind window tap (kh', kw')
+            // the weight tap behind window tap (kh', kw'): the flipped tap, or (parity class of a strided convolution) every second one
+            const int wtap = a.wstep > 1 ? (a.wkh0 + a.wstep * (a.KH - 1 - u_kh)) * a.wkwfull + a.wkw0 + a.wstep * (a.KW - 1 - u_kw)
+                                         : taps - 1 - (u_kh * a.KW + u_kw);
             dma_tile<1, 2>(rr, a.ldreg, wtap * a.Cw + n0, u_c0, wave, lane, lb);   // rows co = u_c0.., columns = the tap's ci
         }
 #pragma unroll
@@ -276,6 +285,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
                 cs[cs_index(wm0 + i * 16 + (lane >> 4) * 4 + r, wn0 + j * 16 + (lane & 15))] = acc[i][j][r];
     __syncthreads();
     const float alpha = a.alpha;
+    // GEMM row -> row of the output tensor (identity, or the parity-class scatter of a strided convolution's input gradient)
+    auto orow = [&](int gm) -> size_t {
+        if (a.out_s <= 1) return (size_t)gm;
+        int b, po, qo;
+        pix_decomp(a, gm, b, po, qo);
+        return ((size_t)b * a.out_H + (size_t)(po * a.out_s + a.out_ph)) * a.out_W + (size_t)(qo * a.out_s + a.out_pw);
+    };
+    const int ptiles = a.part_tiles > 0 ? a.part_tiles : a.tiles_m;
     if (split) {
         float* slab = (float*)(MODE == MODE_WGRAD ? a.out : (void*)a.part) + (size_t)ks * (size_t)a.M * (size_t)a.ldc;
 #pragma unroll
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
 #pragma unroll
         for (int it = 0; it < EIT; ++it) {
             const int gmc = min(m0 + ((it * NW * 64 + tid) >> 4), a.M - 1);
-            const size_t o = (size_t)gmc * a.ldc + (gn < a.N ? gn : 0);
+            const size_t o = orow(gmc) * a.ldc + (gn < a.N ? gn : 0);
             zs[it].v = *(const i32x4*)(a.bn_z + o);
             as[it].v = i32x4{0, 0, 0, 0};
             ys[it].v = i32x4{0, 0, 0, 0};
@@ -347,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
                 s[e] += g;
                 q2[e] += g * xh;
             }
-            *(i32x4*)((h16*)a.out + (size_t)gm * a.ldc + gn) = u.v;
+            *(i32x4*)((h16*)a.out + orow(gm) * a.ldc + gn) = u.v;
         }
         // the 32 threads that share cc: 4 lanes per wave (xor 16, 32), then the 8 waves through LDS in wave order
 #pragma unroll
@@ -371,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * 128 + c];
-            if (n0 + c < a.N) a.bn_part[((size_t)which * a.N + n0 + c) * a.tiles_m + tm] = v;
+            if (n0 + c < a.N) a.bn_part[((size_t)which * a.N + n0 + c) * ptiles + a.part_tm0 + tm] = v;
         }
         return;
     }
@@ -386,7 +403,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
         Pack8 u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { u.e[e] = mh_f2bf(x0[e] * alpha); u.e[4 + e] = mh_f2bf(x1[e] * alpha); }
-        *(i32x4*)((h16*)a.out + (size_t)gm * a.ldc + gn) = u.v;
+        *(i32x4*)((h16*)a.out + orow(gm) * a.ldc + gn) = u.v;
     }
     if (MODE == MODE_FWD && a.part) {
         // column sums over the tile's rows (rows past M hold zeros), of the values as stored: four row quarters in
@@ -587,6 +604,7 @@ extern "C" int mh_conv_splitk(const MhConvGeom* g, int dgrad) {
         on = (e && atoi(e) == 0) ? 0 : 1;
     }
     if (!on) return 1;
+    if (dgrad && g->stride != 1) return 1;      // (the parity-class problems of a strided input gradient are launched together: never split)
     const int M = dgrad ? g->B * g->H * g->W : g->B * Ho * Wo, N = dgrad ? g->C : g->Cout;
     const int K = dgrad ? g->KH * g->KW * g->Cout : g->ldk;
     const bool uni = dgrad ? true : ((g->C % BK) == 0 && g->ldk == g->KH * g->KW * g->C);
@@ -654,8 +672,57 @@ extern "C" int mh_conv_dgrad(const void* dy, const void* wk, void* dx, float* wo
     if (st != MH_OK) return st;
     if (!dy || !wk || !dx) return MH_EINVAL;
     if (((uintptr_t)dy | (uintptr_t)wk | (uintptr_t)dx) & 15) return MH_EINVAL;
-    // stride 1 (a strided convolution's input gradient has parity classes with different tap sets: the explicit path serves
-    // it), window inside the padding, a K tile inside one tap of dY
+    if (g->stride == 2 && g->KH == g->KW && !(g->H & 1) && !(g->W & 1) && g->pad <= g->KH - 1 && (g->Cout % BK) == 0 && g->KH > 1) {
+        // STRIDE 2 (round 4, second session): input pixel (h, w) only meets the taps kh = (h + pad) mod 2 + 2 j (same along w), so the
+        // pixels of one parity class (ph, pw) form a stride-1 problem over dY with a ceil / floor(K / 2)-tap window whose result lands in
+        // every second row and column of dX: four problems (1 + 2 + 2 + 4 taps for a 3x3 filter: every multiply-add useful) in ONE
+        // launch, no [M][K*K*C] panel in HBM and no col2im pass.  `bn`: as for stride 1, the epilogue masks the gradient and leaves
+        // the BatchNorm sums -- part holds 2 x C x (4 x ceil(B (H/2) (W/2) / 128)) partials (mh_bn2d_bwd_parts sums them all).
+        if (bn && (!bn->z || !bn->mean || !bn->rstd || !bn->gamma || !bn->beta || !bn->part)) return MH_EINVAL;
+        ConvGroup grp = {};
+        const int Hh = g->H / 2, Wh = g->W / 2;
+        int total = 0, ptiles = 0, n = 0;
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                const int kh0 = (ph + g->pad) & 1, kw0 = (pw + g->pad) & 1;
+                const int nkh = (g->KH - kh0 + 1) / 2, nkw = (g->KW - kw0 + 1) / 2;
+                if (nkh < 1 || nkw < 1) return MH_ESHAPE;              // (a class without taps: 1x1 filters keep the explicit path)
+                const int padh = nkh - 1 - (ph + g->pad - kh0) / 2, padw = nkw - 1 - (pw + g->pad - kw0) / 2;
+                if (padh != padw || padh < 0) return MH_ESHAPE;
+                ConvArgs a = {};
+                a.src = (const h16*)dy; a.reg = (const h16*)wk; a.out = dx; a.part = nullptr;
+                a.src_bytes = (uint32_t)((size_t)g->B * Ho * Wo * g->Cout * 2);
+                a.reg_bytes = (uint32_t)((size_t)g->Cout * g->ldk * 2);
+                a.H = Ho; a.W = Wo; a.C = g->Cout;
+                a.KH = nkh; a.KW = nkw; a.stride = 1; a.pad = padh;
+                a.Ho = Hh; a.Wo = Wh; a.Mpix = g->B * Hh * Wh;
+                a.M = a.Mpix; a.N = g->C; a.K = nkh * nkw * g->Cout;
+                a.ldreg = g->ldk; a.ldc = g->C; a.Cw = g->C;
+                a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
+                a.total_tiles = a.tiles_m * a.tiles_n;
+                a.group_m = group_m_setting();
+                a.kchunk = 0; a.nsplit = 1; a.alpha = 1.f;
+                a.inv_wo = 1.0f / (float)a.Wo; a.inv_howo = 1.0f / (float)(a.Ho * a.Wo);
+                a.wstep = 2; a.wkh0 = kh0; a.wkw0 = kw0; a.wkwfull = g->KW;
+                a.out_s = 2; a.out_ph = ph; a.out_pw = pw; a.out_H = g->H; a.out_W = g->W;
+                a.part_tm0 = ptiles;
+                if (bn) {
+                    a.bn_z = (const h16*)bn->z; a.bn_mean = bn->mean; a.bn_rstd = bn->rstd; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta;
+                    a.bn_part = bn->part; a.bn_relu = bn->relu;
+                    a.bn_add = (const h16*)bn->addend; a.bn_y = (const h16*)bn->y_mask;
+                }
+                grp.tile_start[n] = total;
+                grp.a[n++] = a;
+                total += a.total_tiles;
+                ptiles += a.tiles_m;
+            }
+        for (int i = 0; i < n; ++i) grp.a[i].part_tiles = ptiles;
+        grp.n = n;
+        grp.total_tiles = total;
+        return conv_launch_group<MODE_DGRAD, true>(grp, (hipStream_t)stream);
+    }
+    // stride 1 (or the strided case above), window inside the padding, a K tile inside one tap of dY; other strided shapes (1x1 / s2
+    // downsampling, stride 3, odd images) keep the explicit path: GEMM into a per-tap panel + mh_col2im_nhwc
     if (g->stride != 1 || g->KH != g->KW || g->pad > g->KH - 1 || (g->Cout % BK)) return MH_ESHAPE;
     ConvArgs a = {};
     a.src = (const h16*)dy;

@@ -104,7 +104,8 @@ class _Conv:
         weight-gradient kernel -- which nothing later in the backward chain reads -- runs on that stream beside the input-gradient
         chain of the layers below (the operands are kept alive in `wjobs` until the streams join).
         Weight gradient: implicit GEMM over x (mh_conv_wgrad).  Input gradient: stride 1 -> mh_conv_dgrad (1x1: the plain GEMM,
-        which is the same thing); strided -> dgrad GEMM into a per-tap panel + mh_col2im_nhwc (3 + 3 layers of ResNet-50)."""
+        which is the same thing); 3x3 / stride 2 -> mh_conv_dgrad as four parity-class problems in one launch (3 layers of ResNet-50);
+        1x1 / stride 2 (the 3 downsampling convolutions) -> dgrad GEMM into a per-tap panel + mh_col2im_nhwc."""
         M = B * Ho * Wo
         dev = dy.device
         if side is not None:
@@ -127,7 +128,10 @@ class _Conv:
             ops.gemm_grouped([ops.Gemm(dy, wk, dx, M, self.ldk, self.cout, self.cout, self.ldk, self.ldk)], False, True)
             return dx, None
         dx = torch.empty((B * H * W, self.cp), dtype=dy.dtype, device=dev)
-        if self.stride == 1 and self.kh == self.kw and self.cout % 64 == 0:
+        # stride 2, k x k (k > 1) on an even image: the four parity classes of input pixels as one grouped implicit launch (round 4)
+        strided_implicit = (self.stride == 2 and self.kh > 1 and H % 2 == 0 and W % 2 == 0 and
+                            os.environ.get("MEMEHIP_STRIDED_DGRAD", "1") != "0")
+        if (self.stride == 1 or strided_implicit) and self.kh == self.kw and self.cout % 64 == 0:
             geom = self.geom(B, H, W)
             sp = int(lib.mh_conv_splitk(geom, 1))
             ws = torch.empty((sp, B * H * W, self.cp), dtype=F32, device=dev) if sp > 1 else None
@@ -135,7 +139,8 @@ class _Conv:
             if bnb is not None:      # dx is the dy of the BatchNorm (+ReLU) that produced x: mask it and sum its statistics right here
                 z_prev, bn_mod, sm_prev, sr_prev, relu_prev = bnb[:5]
                 addend, y_mask = (bnb[5], bnb[6]) if len(bnb) > 5 else (None, None)
-                part = torch.empty((2, self.cp, (B * H * W + 127) // 128), dtype=F32, device=dev)
+                nblk = (B * H * W + 127) // 128 if self.stride == 1 else 4 * ((B * (H // 2) * (W // 2) + 127) // 128)
+                part = torch.empty((2, self.cp, nblk), dtype=F32, device=dev)
                 fuse = _lib.MhConvBnBwd()
                 fuse.z, fuse.mean, fuse.rstd = z_prev.data_ptr(), sm_prev.data_ptr(), sr_prev.data_ptr()
                 fuse.gamma, fuse.beta, fuse.part, fuse.relu = bn_mod.weight.data_ptr(), bn_mod.bias.data_ptr(), part.data_ptr(), int(relu_prev)

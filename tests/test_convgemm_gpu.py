@@ -57,7 +57,17 @@ CASES = [
     (3, 64, 4, 4, 64, 3, 1, 1),       # 4x4 images: every window touches the padding
     (2, 72, 9, 9, 40, 3, 3, 0),       # stride 3, no padding, channel counts that are multiples of 8 only
     (1, 128, 3, 3, 128, 3, 1, 0),     # one output pixel per image
+    (2, 64, 12, 10, 128, 3, 2, 1),    # stride 2 on an even image: the input gradient runs as four parity-class problems
+    (3, 128, 8, 8, 64, 3, 2, 1),
+    (2, 192, 14, 14, 256, 3, 2, 1),   # more than one row tile per class, two column tiles
 ]
+
+
+def _dgrad_is_implicit(k, s, p, H, W, Cout):
+    """what mh_conv_dgrad serves without a panel: stride 1, or 3x3-style stride 2 on even images (parity classes)"""
+    if Cout % 64:
+        return False
+    return s == 1 or (s == 2 and k > 1 and H % 2 == 0 and W % 2 == 0)
 
 
 @pytest.mark.parametrize("T16", [F16, BF16])
@@ -97,7 +107,7 @@ def test_implicit_conv_input_gradient_is_exact_on_integers(pkg, T16):
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(12)
     for (B, C, H, W, Cout, k, s, p) in CASES:
-        if s != 1 or Cout % 64:
+        if not _dgrad_is_implicit(k, s, p, H, W, Cout):
             geom = _geom(pkg, B, H, W, C, k, s, p, Cout, (k * k * C + 63) // 64 * 64)
             d = torch.zeros(16, dtype=T16, device="cuda")
             assert lib.mh_conv_dgrad(d.data_ptr(), d.data_ptr(), d.data_ptr(), None, geom, None, st) == 2       # MH_ESHAPE: the explicit path serves it
@@ -229,6 +239,47 @@ def test_split_k_forward_and_dgrad_equal_the_unsplit_kernels_on_integers(pkg, T1
             pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None if ws is None else ws.data_ptr(), geom, None, st), "dgrad")
             res.append(dx)
         assert torch.equal(res[0], res[1]) and torch.equal(_nchw(res[1], B, H, W), xr.grad.to(T16).float())
+
+
+def test_strided_dgrad_runs_as_parity_classes_with_the_batchnorm_epilogue(pkg):
+    """3x3 / stride 2 (ResNet-50's layer2-4 first blocks): mh_conv_dgrad launches the four parity classes of input pixels as one grouped
+    implicit-GEMM launch -- against the explicit path (GEMM into the tap panel + col2im) on integers, and, with `bn`, the masked
+    gradient and the TOTALS of the per-tile BatchNorm sums (tiles are per class, mh_bn2d_bwd_parts adds them all)."""
+    lib = pkg._lib.load("fp16")
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(21)
+    for (B, C, H, W, Cout) in ((4, 128, 28, 28, 128), (2, 256, 14, 14, 256), (3, 64, 10, 6, 64)):
+        k, s_, p = 3, 2, 1
+        Ho, Wo = H // 2, W // 2
+        Mi = B * H * W
+        w = torch.randint(-1, 2, (Cout, C, k, k), generator=g).float()
+        dy = torch.randint(-2, 3, (B, Cout, Ho, Wo), generator=g).float()
+        x = torch.zeros((B, C, H, W), requires_grad=True)
+        F.conv2d(x, w, stride=s_, padding=p).backward(dy)
+        ldk = k * k * C
+        wk, dyd = _pack(pkg, lib, w, C, ldk, F16), _nhwc(dy, F16)
+        geom = _geom(pkg, B, H, W, C, k, s_, p, Cout, ldk)
+        assert int(lib.mh_conv_splitk(geom, 1)) == 1
+        dx_ref = torch.full((Mi, C), 7.0, dtype=F16, device="cuda")
+        pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx_ref.data_ptr(), None, geom, None, st), "strided dgrad")
+        assert torch.equal(_nchw(dx_ref, B, H, W), x.grad.to(F16).float()), (B, C, H, W)
+        z = (torch.randn((Mi, C), generator=g) * 1.3 + 0.2).to(F16).cuda()
+        mean, rstd = (torch.randn(C, generator=g) * 0.3).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+        nblk = 4 * ((B * Ho * Wo + 127) // 128)
+        f = pkg._lib.MhConvBnBwd()
+        part = torch.full((2, C, nblk), -7.0, dtype=F32, device="cuda")
+        f.z, f.mean, f.rstd, f.gamma, f.beta, f.part, f.relu = z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), 1
+        dx = torch.empty_like(dx_ref)
+        pkg._lib.check(lib.mh_conv_dgrad(dyd.data_ptr(), wk.data_ptr(), dx.data_ptr(), None, geom, f, st), "strided dgrad + bn")
+        xh = (z.float() - mean) * rstd
+        v = xh * gamma + beta
+        keep = v.to(F16).float() > 0
+        want = torch.where(keep, dx_ref.float(), torch.zeros_like(v))
+        sure = v.abs() > 1e-3
+        assert torch.equal(dx.float()[sure], want[sure]), (B, C, H, W)
+        gm = dx.float()
+        assert torch.allclose(part[0].sum(1), gm.sum(0), rtol=1e-4, atol=5e-2) and torch.allclose(part[1].sum(1), (gm * xh).sum(0), rtol=1e-4, atol=5e-2)
 
 
 def test_dgrad_epilogue_does_the_producing_batchnorms_mask_and_statistics(pkg):
