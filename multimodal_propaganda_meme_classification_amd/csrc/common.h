@@ -55,14 +55,58 @@ union Pack4 {
     h16 e[4];
 };
 
+// Wave-wide all-reduce, result in every lane.  Round 4 (second session): the xor butterfly of __shfl_xor compiles to six DEPENDENT
+// ds_bpermute_b32 (an LDS crossbar round trip each, ~100+ clocks); here the partner lane ^ o of every butterfly level comes from a
+// register-file operation instead: gfx950's v_permlane32_swap / v_permlane16_swap for o = 32 / 16, DPP row rotations for o = 8 / 4 and
+// DPP quad permutations for o = 2 / 1 (a few clocks each).  Same levels, same partners, so the result is BIT-IDENTICAL to the
+// butterfly's (a + b is commutative; tools/lab/probe/wave_probe.hip checks it on the device) -- LayerNorm rows, the head's 32 dot
+// products per column and the loss kernels are chains of such reductions.
+template <int CTRL>
+MH_DEV float mh_dpp_f_(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+#define mh_dpp_f(v, ctrl) mh_dpp_f_<ctrl>(v)
+#define MH_DPP_XOR1 0xB1          /* quad_perm [1,0,3,2]: lane ^ 1 */
+#define MH_DPP_XOR2 0x4E          /* quad_perm [2,3,0,1]: lane ^ 2 */
+#define MH_DPP_ROR4 0x124         /* row_ror:4:  lane i reads lane (i - 4) mod 16 of its 16-lane row */
+#define MH_DPP_ROR8 0x128         /* row_ror:8:  lane ^ 8 */
+#define MH_DPP_ROR12 0x12C        /* row_ror:12: lane i reads lane (i + 4) mod 16 */
+MH_DEV unsigned mh_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// value of lane ^ 16 (W = 16) or lane ^ 32 (W = 32).  The swap instructions exchange halves of TWO registers; given one value twice
+// the compiler hands them ONE register and the exchange is lost (both results equal -- measured), hence the opaque copy.
+template <int W>
+MH_DEV float mh_swap_partner(float v, unsigned lane) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("" : "+v"(b));
+    const auto r = W == 16 ? __builtin_amdgcn_permlane16_swap(a, b, false, false) : __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return __builtin_bit_cast(float, (lane & W) ? r[0] : r[1]);      // r[0]: lower halves / even rows twice, r[1]: upper halves / odd rows twice
+}
+// lane ^ 4: row_ror:n makes lane i read lane (i - n) mod 16.  BOTH rotations run with every lane active and the select comes after (the
+// opaque barrier keeps the compiler from sinking them into the two sides of a branch, where half the source lanes would be disabled
+// and read as zero -- measured)
+MH_DEV float mh_xor4_partner(float v, unsigned lane) {
+    float a = mh_dpp_f(v, MH_DPP_ROR4), b = mh_dpp_f(v, MH_DPP_ROR12);
+    asm volatile("" : "+v"(a), "+v"(b));
+    return (lane & 4) ? a : b;
+}
 MH_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const unsigned lane = mh_lane_id();
+    v += mh_swap_partner<32>(v, lane);
+    v += mh_swap_partner<16>(v, lane);
+    v += mh_dpp_f(v, MH_DPP_ROR8);
+    v += mh_xor4_partner(v, lane);
+    v += mh_dpp_f(v, MH_DPP_XOR2);
+    v += mh_dpp_f(v, MH_DPP_XOR1);
     return v;
 }
 MH_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const unsigned lane = mh_lane_id();
+    v = fmaxf(v, mh_swap_partner<32>(v, lane));
+    v = fmaxf(v, mh_swap_partner<16>(v, lane));
+    v = fmaxf(v, mh_dpp_f(v, MH_DPP_ROR8));
+    v = fmaxf(v, mh_xor4_partner(v, lane));
+    v = fmaxf(v, mh_dpp_f(v, MH_DPP_XOR2));
+    v = fmaxf(v, mh_dpp_f(v, MH_DPP_XOR1));
     return v;
 }
 
