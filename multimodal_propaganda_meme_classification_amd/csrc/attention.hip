@@ -318,7 +318,7 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
                         mx = fmaxf(mx, v);
                     }
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = fmaxf(mx, mh_xor_partner<32>(mx, (unsigned)lane));      // (lane ^ 32 from the register file, not the LDS crossbar)
                 // lazy reference maximum: m moves only when a score exceeds it by more than 2^LAZY_LOG2 (P then stays <= 64:
                 // exact in the 16-bit operand and in the f32 sums; lse = m + log2(l) is unchanged in value).  The PV accumulators
                 // live in AGPRs, so the online-softmax rescale is 32 reads + 16 packed multiplies + 32 writes per 32-key sub-tile
@@ -359,7 +359,7 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
             }
         }
         if (!active) continue;
-        l += __shfl_xor(l, 32, 64);
+        l += mh_xor_partner<32>(l, (unsigned)lane);
         const float inv = 1.0f / l;
         store_rows_from_T(out + r0 * H * HD + hh * HD, (size_t)H * HD, wq0, Sb, lane, o, inv);
         const int q = wq0 + (lane & 31);
@@ -451,7 +451,7 @@ MH_DEV void attn_bwd_dq_body(const AttnArgs& A, const int bx, const int gx, cons
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dl += (float)dof[s4][j] * (float)of[s4][j];
-            dl += __shfl_xor(dl, 32, 64);
+            dl += mh_xor_partner<32>(dl, (unsigned)lane);
         }
         float lse2 = 0.f;
         if (q < Sb) {
@@ -610,7 +610,7 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
                     for (int j = 0; j < 8; ++j) dl += (float)a.h[j] * (float)o.h[j];
                 }
             }
-            dl += __shfl_xor(dl, 1, 64);
+            dl += mh_xor_partner<1>(dl, 0u);
             if (hf == 0) dl_t[slot * TILE + i] = dl;
         }
     };
@@ -686,7 +686,7 @@ MH_DEV void attn_bwd_dkv_body(const AttnArgs& A, const int bx, const int gx, con
 #pragma unroll
                     for (int j = 0; j < 8; ++j) dl += (float)a.h[j] * (float)o.h[j];
                 }
-                dl += __shfl_xor(dl, 1, 64);
+                dl += mh_xor_partner<1>(dl, 0u);
                 if ((tid & 1) == 0) dl_t[tid >> 1] = dl;
             }
         };
@@ -919,7 +919,7 @@ MH_DEV void attn_bwd_onepass_body(const AttnArgs& A, const int bh, char* smem) {
                 for (int j = 0; j < 8; ++j) dl += (float)a.h[j] * (float)o.h[j];
             }
         }
-        dl += __shfl_xor(dl, 1, 64);
+        dl += mh_xor_partner<1>(dl, 0u);
         if (hf == 0) {
             dl_t[i] = dl;
             // rows past S: lse = +big makes P = exp2(-big) = 0, so they add nothing

@@ -89,6 +89,22 @@ MH_DEV float mh_xor4_partner(float v, unsigned lane) {
     asm volatile("" : "+v"(a), "+v"(b));
     return (lane & 4) ? a : b;
 }
+// the value of lane ^ O, O in {32, 16, 8, 4, 2, 1}: what __shfl_xor(v, O, 64) returns, without the LDS crossbar (all lanes active)
+template <int O>
+MH_DEV float mh_xor_partner(float v, unsigned lane) {
+    if (O == 32 || O == 16) return mh_swap_partner<(O == 32 ? 32 : 16)>(v, lane);
+    if (O == 8) return mh_dpp_f(v, MH_DPP_ROR8);
+    if (O == 4) return mh_xor4_partner(v, lane);
+    if (O == 2) return mh_dpp_f(v, MH_DPP_XOR2);
+    return mh_dpp_f(v, MH_DPP_XOR1);
+}
+template <int O>
+MH_DEV double mh_xor_partner_f64(double v, unsigned lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const float lo = mh_xor_partner<O>(__builtin_bit_cast(float, (unsigned)u), lane);
+    const float hi = mh_xor_partner<O>(__builtin_bit_cast(float, (unsigned)(u >> 32)), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)__builtin_bit_cast(unsigned, hi) << 32) | __builtin_bit_cast(unsigned, lo));
+}
 MH_DEV float wave_sum(float v) {
     const unsigned lane = mh_lane_id();
     v += mh_swap_partner<32>(v, lane);

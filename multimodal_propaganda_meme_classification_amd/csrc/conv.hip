@@ -288,9 +288,14 @@ __global__ __launch_bounds__(256) void bn2d_stats_kernel(const h16* __restrict__
     }
     bn_block_reduce(s, q, part, blk, (int)gridDim.y, C, t < c8 ? t : C, ty, nty, c8w);
 }
-MH_DEV double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+MH_DEV double wave_sum_f64(double v) {      // the butterfly of common.h's wave_sum on the two halves of a double (bit-identical to __shfl_xor)
+    const unsigned lane = mh_lane_id();
+    v += mh_xor_partner_f64<32>(v, lane);
+    v += mh_xor_partner_f64<16>(v, lane);
+    v += mh_xor_partner_f64<8>(v, lane);
+    v += mh_xor_partner_f64<4>(v, lane);
+    v += mh_xor_partner_f64<2>(v, lane);
+    v += mh_xor_partner_f64<1>(v, lane);
     return v;
 }
 // finish: mean / rstd (biased variance), running statistics (unbiased); one WAVE per channel (the lanes split the row

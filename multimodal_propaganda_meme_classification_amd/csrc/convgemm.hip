@@ -369,10 +369,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
         // the 32 threads that share cc: 4 lanes per wave (xor 16, 32), then the 8 waves through LDS in wave order
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            s[e] += __shfl_xor(s[e], 16, 64);
-            s[e] += __shfl_xor(s[e], 32, 64);
-            q2[e] += __shfl_xor(q2[e], 16, 64);
-            q2[e] += __shfl_xor(q2[e], 32, 64);
+            s[e] += mh_xor_partner<16>(s[e], (unsigned)lane);
+            s[e] += mh_xor_partner<32>(s[e], (unsigned)lane);
+            q2[e] += mh_xor_partner<16>(q2[e], (unsigned)lane);
+            q2[e] += mh_xor_partner<32>(q2[e], (unsigned)lane);
         }
         float* red = (float*)(smem + LDS_BYTES);          // [8 waves][2][128 columns]
         if (lane < 16) {
