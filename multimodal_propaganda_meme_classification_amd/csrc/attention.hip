@@ -231,11 +231,14 @@ MH_DEV void attn_fwd_body(const AttnArgs& A, const int bx, const int gx, const i
         if (tid < TILE) {   // wave 0, all 64 lanes: additive key bias + "any key" flags of every tile
             int64_t km[NTL];
 #pragma unroll
-            for (int t = 0; t < NTL; ++t) {
-                const int key = t * TILE + tid;
-                km[t] = (key < Sb) ? 1 : 0;
-                if (key_mask && key < Sb) km[t] = key_mask[r0 + key];
+            for (int t = 0; t < NTL; ++t) km[t] = 1;
+            if (key_mask) {      // (uniform branch, unconditional clamped loads inside: the tiles' mask words in flight together)
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) km[t] = key_mask[r0 + max(min(t * TILE + tid, Sb - 1), 0)];
             }
+#pragma unroll
+            for (int t = 0; t < NTL; ++t)
+                if (t * TILE + tid >= Sb) km[t] = 0;
 #pragma unroll
             for (int t = 0; t < NTL; ++t) {
                 const float bias = km[t] != 0 ? 0.f : NEG_BIG;

@@ -109,3 +109,28 @@ def test_isa_guard_bands_hold(lib):
     assert got[k]["loop_mfma"] == 16 and got[k]["vgpr_spill_count"] == 0 and got[k]["waterfall_loops"] == 0
     # the accident of round 3 (112 -> 90 VGPRs) would have left the band
     assert not (bands[k]["vgpr_count"][0] <= 90 <= bands[k]["vgpr_count"][1])
+
+
+def test_load_chain_guard_and_skeleton_tool(lib):
+    """round 4, second session: the guard's `load_chain` (longest run of load - s_waitcnt vmcnt(0) - load: dependent memory round trips)
+    is zero for the kernels that were rewritten for it, and tools/isa_loadchain.py prints a kernel's memory skeleton from the source."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_guard
+    bands = json.load(open(os.path.join(ROOT, "tools", "isa_bands.json")))["kernels"]
+    got = isa_guard.collect()
+    for k in ("layernorm.f16.o:ln_fwd_kernel<2, 2>", "head.f16.o:linear_fwd_kernel", "layernorm.f16.o:colsum_partials_kernel"):
+        assert bands[k]["load_chain"] == [0, 0] and got[k]["load_chain"] == 0, k
+    # a synthetic chain is counted: load, wait, load, wait
+    insns = [(0, "global_load_dwordx4 v[0:3], v[4:5], off"), (4, "s_waitcnt vmcnt(0)"), (8, "s_cbranch_execz 12"),
+             (12, "global_load_dwordx4 v[0:3], v[4:5], off"), (16, "s_waitcnt vmcnt(0) lgkmcnt(1)"), (20, "global_store_dword v0, v1, off")]
+    assert isa_guard.load_chain(insns) == 2
+    assert isa_guard.load_chain([(0, "global_load_dword v0, v1, off"), (4, "global_load_dword v2, v1, off"), (8, "s_waitcnt vmcnt(1)")]) == 0
+    tool = os.path.join(ROOT, "tools", "isa_loadchain.py")
+    src = os.path.join(ROOT, "multimodal_propaganda_meme_classification_amd", "csrc", "dwconv.hip")
+    r = subprocess.run([sys.executable, tool, src, "dwconv_weight_pack"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 2 and "dwconv_weight_pack_kernel" in lines[0] and set(lines[1].split()) >= {"L", "S", "$"}

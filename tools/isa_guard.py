@@ -9,6 +9,9 @@ tools/isa_bands.json:
 
   * `.vgpr_count`, `.agpr_count`, `.sgpr_count`, `.vgpr_spill_count`, `.sgpr_spill_count`, `.private_segment_fixed_size`,
     `.group_segment_fixed_size` from the code-object notes against the committed band (min / max per field);
+  * `load_chain`: the longest run of dependent memory round trips (load - s_waitcnt vmcnt(0) - load - ...; round 4's second session found the
+    attention staging, LayerNorm rows and a dozen small kernels spending most of their time in such chains: predicated loads the compiler
+    serialises) must not grow beyond the committed number;
   * the disassembly: the kernel's hot loop -- the innermost backward-branch region that contains MFMA instructions -- must hold
     its committed MFMA count and no `scratch_` access (a spill inside the loop); and the number of WATERFALL loops anywhere in the
     kernel (a short `s_cbranch_execnz` loop around `v_readfirstlane` + `s_and_saveexec` + a memory instruction: hipcc's wrapper for a
@@ -137,6 +140,31 @@ def waterfall_loops(insns):
     return n
 
 
+def load_chain(insns):
+    """longest run of DEPENDENT memory round trips in program order: a VMEM load followed by `s_waitcnt vmcnt(0)` before the next VMEM
+    load, repeated (the L w0 L w0 ... pattern of tools/isa_loadchain.py: predicated loads the compiler serialised, one-load-per-trip
+    loops).  Branches and labels are skipped; a store, a barrier or a counted wait ends a run."""
+    best = cur = 0
+    pending = False
+    for _, t in insns:
+        if t.startswith(("global_load", "buffer_load", "flat_load")):
+            pending = True
+            continue
+        if t.startswith("s_waitcnt") and "vmcnt" in t:
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m and int(m.group(1)) == 0 and pending:
+                cur += 1
+                best = max(best, cur)
+            elif m and int(m.group(1)) != 0:
+                cur = 0
+            pending = False
+            continue
+        if t.startswith(("global_store", "buffer_store", "flat_store", "s_barrier", "global_atomic")):
+            cur = 0
+            pending = False
+    return best
+
+
 def collect():
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -158,6 +186,7 @@ def collect():
                 rec["loop_mfma"] = sum(1 for _, x in loop if x.startswith("v_mfma"))
                 rec["loop_forbidden"] = sorted({f for _, x in loop for f in FORBIDDEN_IN_LOOP if x.startswith(f)})
                 rec["waterfall_loops"] = waterfall_loops(dis.get(sym, []))
+                rec["load_chain"] = load_chain(dis.get(sym, []))
                 rec["_loop"] = loop
                 out[f"{fn}:{name}"] = rec
     return out
@@ -169,7 +198,8 @@ def main(argv):
         pat = argv[argv.index("--show") + 1]
         for k, r in got.items():
             if pat in k:
-                print(k, {f: r[f] for f in FIELDS}, "loop:", r["loop_insns"], "insns,", r["loop_mfma"], "mfma", r["loop_forbidden"], "waterfall loops:", r["waterfall_loops"])
+                print(k, {f: r[f] for f in FIELDS}, "loop:", r["loop_insns"], "insns,", r["loop_mfma"], "mfma", r["loop_forbidden"], "waterfall loops:", r["waterfall_loops"],
+                      "load chain:", r["load_chain"])
                 if "--loop" in argv:
                     for a, t in r["_loop"]:
                         print(f"    {a:08x}  {t}")
@@ -198,6 +228,7 @@ def main(argv):
                                    "private_segment_fixed_size": [0, r["private_segment_fixed_size"]],
                                    "group_segment_fixed_size": [0, r["group_segment_fixed_size"]],
                                    "loop_mfma": [r["loop_mfma"], r["loop_mfma"]], "waterfall_loops": [0, r["waterfall_loops"]],
+                                   "load_chain": [0, r["load_chain"]],
                                    "loop_forbidden": []}
         json.dump(bands, open(BANDS, "w"), indent=1, sort_keys=True)
         print(f"wrote {len(bands['kernels'])} kernels to {BANDS}")
