@@ -33,6 +33,7 @@ struct GemmGroup {
     float* sk_partial;           // stream-K (gemm_sk_kernel): one accumulator image (512 threads x 32 f32) per workgroup
     unsigned* sk_flags;          //   [0..grid): "workgroup b's partial is stored"; [grid]: spin time-out marker
     unsigned long long* trace;   // debug (mh_gemm_set_trace): per workgroup 4 x 100-MHz stamps {entry, first stage landed, main loop done, stores issued}
+    const int* rows_any;         // one of the problems' rows_dev pointers (NULL when no problem has one): a valid address for the unconditional loads of the live counts
     DevProblem d[MH_GEMM_MAX_GROUP];
 };
 MH_DEV void trace_stamp(const GemmGroup& g, int k) {
@@ -43,16 +44,18 @@ MH_DEV void trace_stamp(const GemmGroup& g, int k) {
 // 3-4 row panels x ALL column tiles: every K step touches the whole of B (3.5-4.7 MB at N = 2304 / 3072, K = 768),
 // which together with the A panels overflows the XCD's 4-MB L2.  Blocked order: GROUP_M row panels x 8 column
 // tiles at once = 8 + 8 operand panels, each re-used 8 times while it is hot.
-MH_DEV void tile_coords(const DevProblem& d, int group_m, int lt, int& tm, int& tn) {
+MH_DEV void tile_coords(int tiles_n, int tiles_m, int group_m, int lt, int& tm, int& tn);
+MH_DEV void tile_coords(const DevProblem& d, int group_m, int lt, int& tm, int& tn) { tile_coords(d.tiles_n, d.tiles_m, group_m, lt, tm, tn); }      // (lab kernels)
+MH_DEV void tile_coords(int tiles_n, int tiles_m, int group_m, int lt, int& tm, int& tn) {
     if (group_m <= 1) {
-        tm = lt / d.tiles_n;
-        tn = lt % d.tiles_n;
+        tm = lt / tiles_n;
+        tn = lt % tiles_n;
         return;
     }
-    const int per_group = group_m * d.tiles_n;
+    const int per_group = group_m * tiles_n;
     const int g = lt / per_group;
     const int r = lt - g * per_group;
-    const int rows = min(group_m, d.tiles_m - g * group_m);
+    const int rows = min(group_m, tiles_m - g * group_m);
     tn = r / rows;
     tm = g * group_m + (r - tn * rows);
 }
@@ -240,19 +243,58 @@ __global__ __launch_bounds__(512, 4) void gemm_kernel(const GemmGroup g) {
 
     // ---- which tile ----------------------------------------------------------------------------
     trace_stamp(g, 0);
-    const int nwg = g.total_tiles;
+    // LIVE tiles (row layouts, LA == 0).  A problem over packed token rows (rows_dev) is laid out on the host for its MAXIMUM row
+    // count; the row panels past the live count are tiles that only exit.  In the host's tile order they all sit at the END of the
+    // list, i.e. in the last XCDs' contiguous runs: at 2 093 live of 4 096 text rows an N = 3072 launch gave XCD 7 nothing but dead
+    // tiles and XCD 6 half of them -- the live work ran on 6.5 of the 8 XCDs.  The list is therefore re-counted here with the live row
+    // panels only, and THAT list is cut into the eight XCD runs; the surplus workgroups (the highest block indices of every XCD,
+    // dispatched last) exit.  Everything below is wave-uniform scalar arithmetic.
+    int cnt[MH_GEMM_MAX_GROUP], tml[MH_GEMM_MAX_GROUP], liv[MH_GEMM_MAX_GROUP];
+#pragma unroll
+    for (int i = 0; i < MH_GEMM_MAX_GROUP; ++i) liv[i] = 0x7fffffff;
+    if (LA == 0 && g.rows_any) {      // every problem's live count requested at once (a load behind `if (rows_dev)` is a dependent one)
+        int v[MH_GEMM_MAX_GROUP];
+#pragma unroll
+        for (int i = 0; i < MH_GEMM_MAX_GROUP; ++i) {
+            const int* src = (i < g.n && g.d[i].p.rows_dev) ? g.d[i].p.rows_dev : g.rows_any;
+            v[i] = *src;
+        }
+#pragma unroll
+        for (int i = 0; i < MH_GEMM_MAX_GROUP; ++i)
+            if (i < g.n && g.d[i].p.rows_dev) liv[i] = __builtin_amdgcn_readfirstlane(v[i]);
+    }
+    int nwg = 0;
+#pragma unroll
+    for (int i = 0; i < MH_GEMM_MAX_GROUP; ++i) {
+        cnt[i] = 0; tml[i] = 0;
+        if (i < g.n) {
+            tml[i] = g.d[i].tiles_m;
+            cnt[i] = (i + 1 < g.n ? g.d[i + 1].tile_start : g.total_tiles) - g.d[i].tile_start;
+            if (LA == 0 && g.d[i].p.rows_dev) {      // (never split-K: the host rejects rows_dev with ksplit)
+                tml[i] = min(tml[i], (max(liv[i], 0) + BM - 1) / BM);
+                cnt[i] = tml[i] * g.d[i].tiles_n;
+            }
+            nwg += cnt[i];
+        }
+    }
     int t;
     {
         const int b = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, x = b & 7;
-        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        const int q = nwg >> 3, r = nwg & 7, x = b & 7, j = b >> 3;
+        if (j >= q + (x < r ? 1 : 0)) return;      // beyond this XCD's run of live tiles
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    int pi = 0;
+    int pi = 0, tstart = 0, tm_live = tml[0], live = liv[0];
+    {
+        int acc = 0;
 #pragma unroll
-    for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i)
-        if (i < g.n && t >= g.d[i].tile_start) pi = i;
+        for (int i = 1; i < MH_GEMM_MAX_GROUP; ++i) {
+            acc += cnt[i - 1];
+            if (i < g.n && t >= acc) { pi = i; tstart = acc; tm_live = tml[i]; live = liv[i]; }
+        }
+    }
     const MhGemmProblem& P = g.d[pi].p;
-    int lt = t - g.d[pi].tile_start;
+    int lt = t - tstart;
     // split-K: the problem's tiles are replicated ksplit times; split s contracts over [s * kchunk, (s+1) * kchunk) and
     // writes its own f32 partial output at C + s * M * ldc (summed by the caller: mh_colsum_partials_f32)
     const int kchunk = g.d[pi].kchunk;
@@ -263,19 +305,17 @@ __global__ __launch_bounds__(512, 4) void gemm_kernel(const GemmGroup g) {
         lt -= ksplit_idx * per;
     }
     int tm, tn;
-    tile_coords(g.d[pi], g.group_m, lt, tm, tn);
+    tile_coords(g.d[pi].tiles_n, tm_live, g.group_m, lt, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     int M = P.M, K = P.K;
     const int N = P.N;
     if (P.rows_dev) {   // packed (padding-free) token rows: the live row count is only known on the device
-        const int live = __builtin_amdgcn_readfirstlane(*P.rows_dev);      // (uniform: a VGPR here puts the operand's buffer resource in VGPRs and a waterfall loop around every LDS-DMA load)
         if (LA == 0) {
             M = min(M, live);
-            if (m0 >= M) return;     // whole tile past the live rows (uniform per workgroup).  (Issuing stage 0 BEFORE this read: measured, the
-                                     // fill time did not move -- 1.6-1.9 us is the burst of 512 workgroups x 32 KB, not the dependent load)
+            if (m0 >= M) return;     // (cannot happen for live tiles; kept as the bound of the partial last panel)
         } else {
-            K = min(K, live);
+            K = min(K, __builtin_amdgcn_readfirstlane(*P.rows_dev));      // (uniform: a VGPR here puts the operand's buffer resource in VGPRs and a waterfall loop around every LDS-DMA load)
         }
     }
     const int kbeg = ksplit_idx * kchunk;                       // 0 without split-K
@@ -473,6 +513,9 @@ extern "C" int mh_gemm_bf16_grouped(const MhGemmProblem* problems, int n_problem
     g.trace = g_trace;
     g.sk_partial = nullptr;
     g.sk_flags = nullptr;
+    g.rows_any = nullptr;
+    for (int i = 0; i < n_problems; ++i)
+        if (problems[i].rows_dev && !g.rows_any) g.rows_any = problems[i].rows_dev;
     hipStream_t s = (hipStream_t)stream;
     if (!a_kmajor && !b_kmajor) return launch<0, 0>(g, s);
     if (!a_kmajor && b_kmajor) return launch<0, 1>(g, s);
