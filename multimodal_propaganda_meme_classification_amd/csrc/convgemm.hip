@@ -88,19 +88,29 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_gemm_kernel(const ConvGr
     constexpr int LB = (MODE == MODE_FWD) ? 0 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    int t;
+    // blocks b, b+8, ... share an XCD (and its L2).  Every XCD gets a contiguous EIGHTH of EVERY problem's tile list (round 4, second
+    // session): with one run over the concatenated list a launch of several problems gave whole problems to single XCDs, and the
+    // problems' tiles differ in length -- the grouped weight gradients of a bottleneck (13 K steps per tile for the 1x1 layers, 25
+    // for the 3x3) left the XCDs holding the long tiles with 1.5x the mean work, the parity classes of a strided input gradient (1 / 2 /
+    // 2 / 4 taps) likewise.  The grid is 8 x the largest per-XCD tile count (host: conv_launch_group); surplus blocks exit.
+    int t, pi = 0;
     {
-        const int nwg = grp.total_tiles;
-        const int b = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, x = b & 7;       // blocks b, b+8, ... share an XCD (and its L2): contiguous tile runs
-        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
-    int pi = 0;
+        const int x = blockIdx.x & 7;
+        int j = blockIdx.x >> 3;
+        bool found = false;
+        t = 0;
 #pragma unroll
-    for (int i = 1; i < CONV_MAX_GROUP; ++i)
-        if (i < grp.n && t >= grp.tile_start[i]) pi = i;
+        for (int i = 0; i < CONV_MAX_GROUP; ++i) {
+            if (i < grp.n && !found) {
+                const int n_i = (i + 1 < grp.n ? grp.tile_start[i + 1] : grp.total_tiles) - grp.tile_start[i];
+                const int lo = (int)(((long long)x * n_i) >> 3), hi = (int)(((long long)(x + 1) * n_i) >> 3);
+                if (j < hi - lo) { pi = i; t = lo + j; found = true; }
+                else j -= hi - lo;
+            }
+        }
+        if (!found) return;
+    }
     const ConvArgs& a = grp.a[pi];
-    t -= grp.tile_start[pi];
     int ks = 0;
     if (MODE == MODE_WGRAD || a.nsplit > 1) {
         const int per = a.tiles_m * a.tiles_n;
@@ -555,7 +565,16 @@ int conv_launch_group(const ConvGroup& grp, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<MODE, UNI>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, UNI>), dim3(grp.total_tiles), dim3(NW * 64), CONV_LDS, s, grp);
+    int per_xcd = 0;      // the largest per-XCD tile count when every XCD takes its eighth of every problem (see the kernel's prologue)
+    for (int x = 0; x < 8; ++x) {
+        int c = 0;
+        for (int i = 0; i < grp.n; ++i) {
+            const long long n_i = (i + 1 < grp.n ? grp.tile_start[i + 1] : grp.total_tiles) - grp.tile_start[i];
+            c += (int)(((x + 1) * n_i) >> 3) - (int)((x * n_i) >> 3);
+        }
+        per_xcd = c > per_xcd ? c : per_xcd;
+    }
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, UNI>), dim3(8 * per_xcd), dim3(NW * 64), CONV_LDS, s, grp);
     return mh_launch_status();
 }
 template <int MODE, bool UNI>
