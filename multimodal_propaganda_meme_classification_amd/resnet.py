@@ -401,7 +401,9 @@ class ResNet50(nn.Module):
         wjobs = []      # (conv, split-K slabs of its weight gradient, nsplit, operands kept alive): finished in one launch at the end
         side = None      # (weight-gradient GEMMs on a second stream: measured SLOWER, 9.39 vs 8.76 ms/step -- 53 cross-stream edges of ~10 us for 26-us GEMMs)
 
-        group = int(os.environ.get("MEMEHIP_WGRAD_GROUP", "4"))       # weight gradients launched together (1: one launch each)
+        # weight gradients launched together (1: one launch each).  6 since the conv kernels deal every problem's tiles to all eight XCDs
+        # (round 4, second session: 6.29 -> 6.24 ms; with one run over the concatenated tile list 4 was the best)
+        group = int(os.environ.get("MEMEHIP_WGRAD_GROUP", "6"))
         group = max(1, min(group, _lib.MH_CONV_MAX_GROUP))
         wq = [] if (group > 1 and side is None) else None
 
